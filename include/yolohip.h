@@ -1,0 +1,262 @@
+/*
+ * yolohip.h — C ABI of libyolohip.so, the MI355X (gfx950) kernels behind the
+ * yl-jiang/YOLOSeries detection hot path.
+ *
+ * The reference has no FFI layer of its own (it is pure PyTorch);
+ * every entry point below replaces a Python op sequence of the reference, cited
+ * as  file:line  relative to the reference tree.  The Python mirror in
+ * yoloseries_amd/ binds these with ctypes.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller unless the name
+ *    says host.  Kernels are only enqueued on `stream`; nothing here
+ *    allocates, frees, synchronises or copies to the host, so every call is
+ *    legal inside hipStreamBeginCapture.
+ *  - Activations are NHWC bf16 (raw uint16 storage), `ld` = elements between
+ *    consecutive pixels, so a channel slice of a wider buffer is (ptr+coff, ld).
+ *    Channel counts and channel offsets of activation operands are multiples of 8
+ *    (16-byte vector access).
+ *  - Return value: 0 on success, negative yh_status otherwise;
+ *    yh_last_error() gives a thread-local message.
+ */
+#ifndef YOLOHIP_H
+#define YOLOHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* yh_stream;          /* hipStream_t */
+typedef uint16_t yh_bf16;         /* raw bfloat16 bits */
+
+enum yh_status {
+    YH_OK = 0,
+    YH_EINVAL = -1,               /* bad shape / alignment / null pointer */
+    YH_ELAUNCH = -2,              /* hipLaunch reported an error */
+    YH_EUNSUPPORTED = -3
+};
+
+const char* yh_last_error(void);
+int yh_version(void);
+/* number of compute units of the current device (for workspace sizing) */
+int yh_device_cus(void);
+
+/* ------------------------------------------------------------------------ *
+ * Implicit-GEMM convolution (MFMA 32x32x16 bf16, fp32 accumulate)
+ * replaces nn.Conv2d inside ConvBnAct / Detect:
+ *   utils/layer_tools.py:82-94 (ConvBnAct), :454-470 (Detect),
+ *   torch.cat / nn.Upsample in the neck: models/normal/yolov5s.py:101-114
+ * ------------------------------------------------------------------------ */
+
+/* One channel segment of the (virtually concatenated) conv input. */
+typedef struct yh_seg {
+    const yh_bf16* ptr;   /* first channel of this segment at pixel 0          */
+    int32_t ld;           /* elements per pixel of the underlying buffer        */
+    int32_t C;            /* channels in this segment (multiple of 8)           */
+    int32_t ups;          /* 1: buffer is (H/2,W/2), read with nearest-2x upsample */
+    int32_t _pad;
+} yh_seg;
+
+#define YH_CONV_FWD   0   /* hi = ho*stride - pad + kh                          */
+#define YH_CONV_DGRAD 1   /* hi = (ho + pad - kh)/stride, only when divisible   */
+
+#define YH_ACT_NONE 0
+#define YH_ACT_SILU 1
+
+typedef struct yh_conv_desc {
+    yh_seg   seg[2];      /* input = concat(seg[0], seg[1]) along channels      */
+    int32_t  nseg;
+    int32_t  mode;        /* YH_CONV_FWD / YH_CONV_DGRAD                        */
+    int32_t  B, Ho, Wo;   /* output pixel grid; rows M = B*Ho*Wo                */
+    int32_t  Hi, Wi;      /* logical input grid (of the concatenated input)     */
+    int32_t  KH, KW, stride, pad;
+    const yh_bf16* w;     /* packed weights [Npad][KH*KW*Ctot], k = tap*Ctot+c  */
+    int32_t  N;           /* real output channels                               */
+    int32_t  Npad;        /* rows allocated in w (multiple of 128, zero filled) */
+    /* epilogue: v = acc (+bias[n]); if scale: v = v*scale[n]+shift[n];
+     *           act; out = v (+res) (+out if accumulate)                        */
+    const float* bias;    /* [N] or NULL                                         */
+    const float* scale;   /* [N] or NULL  (folded BN, inference)                 */
+    const float* shift;   /* [N] or NULL                                         */
+    int32_t  act;
+    int32_t  accumulate;  /* 1: out += result (gradient accumulation)            */
+    yh_bf16* out0; int32_t ld0;   /* columns [0,nsplit)  -> out0[m*ld0 + n]          */
+    int32_t  nsplit;              /* multiple of 8; == N when a single destination   */
+    yh_bf16* out1; int32_t ld1;   /* columns [nsplit,N)  -> out1[m*ld1 + n-nsplit]   */
+    const yh_bf16* res; int32_t ldr;  /* residual added after act to out0 columns, or NULL */
+    /* per-channel batch statistics of the stored (bf16-rounded) pre-activation,
+     * as per-block partial sums: stats[(blk*2+0)*Npad + n] = sum, [(blk*2+1)*Npad+n] = sumsq,
+     * blk in [0, yh_conv_stat_blocks()).  NULL: not collected.                   */
+    float*   stats;
+} yh_conv_desc;
+
+/* number of partial-sum rows the conv kernel writes for this shape */
+int yh_conv_stat_blocks(const yh_conv_desc* d);
+int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream);
+
+/* Weight gradient: dW[n][tap*Ctot + coff_k + c] += sum_m gy[m][n] * X[src(m,tap)][c]
+ * (fp32 atomics into a zeroed packed buffer).  One launch per input segment.
+ * replaces the autograd backward of nn.Conv2d (train_yolov5.py:337). */
+typedef struct yh_wgrad_desc {
+    const yh_bf16* gy; int32_t ldg;   /* [M][ldg] gradient of the conv output      */
+    int32_t  N;                       /* output channels                            */
+    yh_seg   seg;                     /* ONE input segment                          */
+    int32_t  coff_k;                  /* channel offset of this segment inside Ctot */
+    int32_t  Ctot;
+    int32_t  B, Ho, Wo, Hi, Wi, KH, KW, stride, pad;
+    float*   dw;                      /* [N][KH*KW*Ctot] fp32, accumulated          */
+    int32_t  splits;                  /* split of the M (pixel) reduction, >=1      */
+} yh_wgrad_desc;
+int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
+
+/* ------------------------------------------------------------------------ *
+ * BatchNorm (training statistics) + SiLU, forward and backward
+ * replaces nn.BatchNorm2d(eps=1e-3, momentum=0.03) + nn.SiLU
+ *   utils/layer_tools.py:87-91
+ * ------------------------------------------------------------------------ */
+/* reduce conv partial sums -> mean/invstd/scale/shift, update running stats.
+ * ws layout (fp32, 4*C): scale | shift | mean | invstd                        */
+int yh_bn_finalize(const float* stats, int nblk, int ldstat, int C, int64_t count,
+                   const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches,
+                   float eps, float momentum, float* ws, yh_stream stream);
+/* inference fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale         */
+int yh_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv,
+               float eps, int C, float* scale, float* shift, yh_stream stream);
+/* out = silu(y*scale+shift) (+res) ; all bf16 NHWC slices                      */
+int yh_bn_silu_apply(const yh_bf16* y, int ldy, const float* ws, int C, int64_t M,
+                     yh_bf16* out, int ldo, const yh_bf16* res, int ldr, yh_stream stream);
+/* pass 1 of the backward: partial sums of gz and gz*xhat per channel
+ * part layout: [nblk][2][C], nblk = yh_ew_blocks(M)                            */
+int yh_ew_blocks(int64_t M);
+int yh_bn_silu_bwd_reduce(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy,
+                          const float* ws, int C, int64_t M, float* part, yh_stream stream);
+/* combine partials -> dgamma, dbeta (+= into grads) and coefficients
+ * coef layout (fp32, 2*C): mean(gz) | mean(gz*xhat)                            */
+int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M,
+                       float* dgamma, float* dbeta, float* coef, yh_stream stream);
+/* pass 2: gy = gamma*invstd*(gz - c1 - xhat*c2); optional residual pass-through
+ * gres (op)= ga                                                                */
+int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy,
+                         const float* ws, const float* gamma, const float* coef,
+                         int C, int64_t M, yh_bf16* gy, int ldgy,
+                         yh_bf16* gres, int ldgres, int gres_accumulate, yh_stream stream);
+/* column sums of a bf16 matrix (bias gradient of Detect): out[c] += sum_m g[m][c] */
+int yh_colsum(const yh_bf16* g, int ldg, int C, int64_t M, float* part, float* out, yh_stream stream);
+
+/* ------------------------------------------------------------------------ *
+ * SPPF max-pool 5x5 s1 p2 (utils/layer_tools.py:270-288), NHWC bf16
+ * idx: int8 per element, window position (0..24) of the first maximum
+ * ------------------------------------------------------------------------ */
+int yh_maxpool5_fwd(const yh_bf16* x, int ldx, int B, int H, int W, int C,
+                    yh_bf16* out, int ldo, int8_t* idx, yh_stream stream);
+int yh_maxpool5_bwd(const yh_bf16* gout, int ldgo, const int8_t* idx, int B, int H, int W, int C,
+                    yh_bf16* gin, int ldgi, int accumulate, yh_stream stream);
+/* gradient of nearest-2x upsample: glo (op)= sum of the 2x2 block of ghi        */
+int yh_upsample2_bwd(const yh_bf16* ghi, int ldh, int B, int Hlo, int Wlo, int C,
+                     yh_bf16* glo, int ldl, int accumulate, yh_stream stream);
+/* input image NCHW fp32 (B,3,H,W) -> space-to-depth NHWC bf16 (B,H/2,W/2,16):
+ * channel = (dy*2+dx)*3 + c, channels 12..15 zero.  The 6x6/s2/p2 stem conv of
+ * models/normal/yolov5s.py:16 becomes a 3x3/s1/p1 conv on this tensor.          */
+int yh_input_s2d(const float* x, int B, int Cin, int H, int W, yh_bf16* out, yh_stream stream);
+int yh_fill_u32(void* p, uint32_t v, int64_t n_words, yh_stream stream);
+
+/* ------------------------------------------------------------------------ *
+ * Parameter arena: gather/scatter between the fp32 master parameters and the
+ * packed bf16 weight images the conv kernels read.
+ * ------------------------------------------------------------------------ */
+/* dst_bf16[i] = idx[i] >= 0 ? bf16(src[idx[i]]) : 0                             */
+int yh_pack_bf16(const float* src, const int32_t* idx, int64_t n, yh_bf16* dst, yh_stream stream);
+/* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0   (packed fp32 grads -> parameter layout) */
+int yh_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, yh_stream stream);
+/* SGD with momentum/nesterov on a flat arena; group[i] selects lr/wd.
+ * torch.optim.SGD semantics (train_yolov5.py:258-280):
+ *   g += wd*p ; buf = first ? g : mom*buf + g ; g = nesterov ? g + mom*buf : buf ; p -= lr*g */
+int yh_sgd_step(float* p, const float* g, float* buf, const uint8_t* group, int64_t n,
+                const float* lr, const float* wd, int ngroups, float momentum, int nesterov,
+                int first_step, const float* grad_scale, yh_stream stream);
+/* sum of squares of a flat fp32 buffer (for clip_grad_norm_, train_yolov5.py:344) */
+int yh_sumsq(const float* x, int64_t n, float* part, float* out, yh_stream stream);
+/* EMA: e = d*e + (1-d)*p over a flat arena (trainer/ema_model.py:20-28)         */
+int yh_ema_update(float* ema, const float* p, int64_t n, float decay, yh_stream stream);
+
+/* ------------------------------------------------------------------------ *
+ * YOLOv5 loss (loss/yolov5_loss.py:30-235)
+ * ------------------------------------------------------------------------ */
+typedef struct yh_v5loss_desc {
+    int32_t B, maxbox, num_class, num_anchor, num_stage;
+    int32_t H[4], W[4];           /* stage feature-map sizes                       */
+    float   img_size0, img_size1; /* hyp['input_img_size'][0], [1]                */
+    float   anchors[4][3][2];     /* pixels, anchors[stage][a] = (w,h)            */
+    float   anchor_thr;           /* hyp['anchor_match_thr']                      */
+    float   cls_smooth, cls_pos_weight, cof_pos_weight;
+    int32_t use_focal; float focal_gamma, focal_alpha;
+    float   iou_scale, cof_scale, cls_scale;
+    int32_t pred_is_f32;          /* 0: bf16 predictions, 1: fp32                  */
+    int32_t ldp[4];               /* elements per cell of each prediction buffer   */
+} yh_v5loss_desc;
+
+/* workspace sizes in bytes */
+size_t yh_v5loss_ws_bytes(const yh_v5loss_desc* d);
+/* Target assignment for all stages (YOLOV5Loss.match, loss/yolov5_loss.py:142-214).
+ * targets: [B][maxbox][6] fp32 (xmin,ymin,xmax,ymax,cls,img_id), padding rows -1.
+ * Per stage s, with cap = 5*A*B*maxbox rows:
+ *   count[s]                    int32
+ *   tbox  [s][cap][4] fp32      (x-cx, y-cy, w, h) grid units
+ *   tidx  [s][cap][5] int32     (cls, img, anchor, gy, gx)                       */
+int yh_v5_assign(const yh_v5loss_desc* d, const float* targets,
+                 int32_t* count, float* tbox, int32_t* tidx, void* ws, yh_stream stream);
+/* Forward loss. preds[s]: [B][H][W][ldp] with channel a*(5+nc)+e.
+ * balances: [num_stage] fp32 device state, updated in place.
+ * result (fp32[8]): tot, iou, cof, cls, tar_nums, 0,0,0  (iou/cof/cls already x B)
+ * saved: opaque per-call state for the backward, yh_v5loss_saved_bytes()         */
+size_t yh_v5loss_saved_bytes(const yh_v5loss_desc* d);
+int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds, const float* targets,
+                   float* balances, float* result, void* saved, void* ws, yh_stream stream);
+/* Backward: gpreds[s] same geometry/dtype as preds[s], fully overwritten.
+ * gout: device pointer to d(loss)/d(tot) scalar.                                 */
+int yh_v5_loss_bwd(const yh_v5loss_desc* d, const void* const* preds, const float* gout,
+                   const void* saved, void* const* gpreds, void* ws, yh_stream stream);
+
+/* Box utilities (utils/bbox_tools.py:164-339) fp32 */
+int yh_iou_matrix(const float* b1, int n1, const float* b2, int n2, float eps_clamp, float* out, yh_stream stream);
+/* kind: 0 giou 1 diou 2 ciou ; pairwise (N,) ; grad (optional) d out/d b1 [N][4] */
+int yh_iou_pairwise(int kind, const float* b1, const float* b2, int n, float* out, float* grad_b1, yh_stream stream);
+
+/* ------------------------------------------------------------------------ *
+ * Inference post-processing (trainer/eval_yolov5.py:182-317, utils/nms.py:10-27)
+ * ------------------------------------------------------------------------ */
+typedef struct yh_decode_desc {
+    int32_t B, num_class, num_anchor, num_stage;
+    int32_t H[4], W[4];
+    float   stride[4];
+    float   anchors[4][3][2];     /* pixels */
+    int32_t pred_is_f32;
+    int32_t ldp[4];
+    int32_t yolox;                /* 0: v5 decode, 1: YOLOX decode (eval_yolox.py:123-150) */
+} yh_decode_desc;
+/* Full decode to (B, sum(A*H*W), 5+nc) fp32, the tensor do_inference returns.    */
+int yh_decode_full(const yh_decode_desc* d, const void* const* preds, float* out, yh_stream stream);
+/* Fused decode + candidate filter, order preserving.
+ *  cand: [B][cap][6] fp32 (xmin,ymin,xmax,ymax,conf,cls) ; ncand: [B] int32 (may exceed cap: overflow)
+ *  conf_ge: obj >= conf_thr ; cls_gt: cls_conf > cls_thr (v5) / obj*max>=conf & cls>=thr (yolox) */
+int yh_decode_filter(const yh_decode_desc* d, const void* const* preds, float conf_thr, float cls_thr,
+                     float* cand, int32_t* ncand, int cap, yh_stream stream);
+/* Greedy NMS per image on candidate lists, selection order = reference order.
+ *  class_aware: add cls*4096 to the box before IoU (hyp['agnostic'] == True in the reference)
+ *  thr_inclusive: 1 -> suppress when iou >= thr (numba_nms), 0 -> iou > thr (gpu_nms)
+ *  merge_filter: postprocess_bbox filter (eval_yolov5.py:306-315)
+ *  out: [B][max_keep][6] ; nkeep [B] ; keep_idx [B][max_keep] index into the candidate list
+ *  ws: yh_nms_ws_bytes                                                            */
+size_t yh_nms_ws_bytes(int B, int cap);
+int yh_nms_batched(const float* cand, const int32_t* ncand, int B, int cap,
+                   float iou_thr, int class_aware, int thr_inclusive, int max_keep, int merge_filter,
+                   float* out, int32_t* nkeep, int32_t* keep_idx, void* ws, yh_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOHIP_H */

@@ -1,0 +1,157 @@
+"""GPU parity of the implicit-GEMM conv / dgrad / wgrad kernels against a plain
+PyTorch fp32 reference of the same op on identical (bf16-representable) inputs.
+
+Tolerance: the kernels accumulate in fp32 and round the result once to bf16, so
+|err| <= 2^-8 * |ref| (half a bf16 ulp, rtol 4e-3) plus fp32 accumulation-order
+noise; we allow rtol=8e-3, atol=2e-2*scale.  wgrad is fp32 output: rtol 2e-3.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(B, H, W, C, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn(B, H, W, C, generator=g) * scale).to(torch.bfloat16)
+    return x.to(dev)
+
+
+def _nchw(x_nhwc):
+    return x_nhwc.float().permute(0, 3, 1, 2).contiguous()
+
+
+def _close(got, ref, rtol, atol):
+    got = got.float()
+    err = (got - ref).abs()
+    lim = atol + rtol * ref.abs()
+    bad = (err > lim)
+    assert not bad.any(), f"max err {err.max().item():.4g} (ref max {ref.abs().max().item():.4g}), {bad.sum().item()} / {bad.numel()} out of tol"
+
+
+CASES = [
+    # B, H, W, Cin, Cout, k, s, p
+    (2, 16, 16, 64, 32, 1, 1, 0),
+    (2, 16, 16, 32, 64, 3, 1, 1),
+    (2, 16, 16, 32, 64, 3, 2, 1),
+    (1, 20, 20, 128, 255, 1, 1, 0),      # Detect-like, N not a multiple of 8
+    (3, 12, 20, 16, 32, 3, 1, 1),        # stem-like (K tile spans two taps), rows not multiple of 128
+    (2, 8, 8, 256, 512, 3, 2, 1),        # several N tiles
+    (1, 40, 40, 64, 128, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CASES)
+def test_conv_fwd(dev, B, H, W, Cin, Cout, k, s, p):
+    from yoloseries_amd import hipk
+    x = _nhwc(B, H, W, Cin, dev, 1)
+    g = torch.Generator().manual_seed(2)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(torch.bfloat16).float().to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    ldo = ((Cout + 7) // 8) * 8
+    out = torch.full((B, Ho, Wo, ldo), 7.0, dtype=torch.bfloat16, device=dev)
+    wp = hipk.pack_weight_fwd(w)
+    d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, Ho, Wo, H, W, k, s, p, wp, Cout, hipk.full(out), bias=bias)
+    nblk = hipk.conv_stat_blocks(d)
+    stats = torch.zeros(nblk, 2, wp.shape[0], device=dev)
+    d.stats = stats.data_ptr()
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    ref = F.conv2d(_nchw(x), w, bias, stride=s, padding=p).permute(0, 2, 3, 1)
+    _close(out[..., :Cout], ref, 8e-3, 2e-2)
+    # statistics are taken over the stored (bf16-rounded) values
+    o = out[..., :Cout].float().reshape(-1, Cout)
+    ssum = stats[:, 0, :Cout].double().sum(0)
+    ssq = stats[:, 1, :Cout].double().sum(0)
+    assert torch.allclose(ssum, o.double().sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(ssq, (o.double() ** 2).sum(0), rtol=1e-4, atol=1e-2)
+
+
+def test_conv_fwd_concat_upsample_silu_res(dev):
+    """Two-segment input (first one read through nearest-2x upsample), folded BN + SiLU
+    epilogue, residual add and split destination."""
+    from yoloseries_amd import hipk
+    B, H, W = 2, 16, 16
+    lo = _nhwc(B, H // 2, W // 2, 64, dev, 3)
+    skip_buf = _nhwc(B, H, W, 96, dev, 4)         # use channels [32, 96) of a wider buffer
+    g = torch.Generator().manual_seed(5)
+    Cin, Cout = 128, 64
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).to(torch.bfloat16).float().to(dev)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=g).to(dev)
+    res = _nhwc(B, H, W, 32, dev, 6)
+    out0 = torch.zeros(B, H, W, 32, dtype=torch.bfloat16, device=dev)
+    out1 = torch.zeros(B, H, W, 64, dtype=torch.bfloat16, device=dev)   # write into channels [32,64)
+    wp = hipk.pack_weight_fwd(w)
+    d = hipk.conv_desc([hipk.Slice(lo, 0, 64, ups=1), hipk.Slice(skip_buf, 32, 64)], hipk.YH_CONV_FWD,
+                       B, H, W, H, W, 1, 1, 0, wp, Cout, hipk.full(out0), nsplit=32,
+                       out1=hipk.Slice(out1, 32, 32), scale=scale, shift=shift, act=hipk.YH_ACT_SILU, res=hipk.full(res))
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    xin = torch.cat([F.interpolate(_nchw(lo), scale_factor=2, mode="nearest"), _nchw(skip_buf[..., 32:96])], 1)
+    z = F.conv2d(xin, w) * scale[None, :, None, None] + shift[None, :, None, None]
+    a = F.silu(z).permute(0, 2, 3, 1)
+    _close(out0, a[..., :32].to(torch.bfloat16).float() + res.float(), 1e-2, 3e-2)
+    _close(out1[..., 32:], a[..., 32:], 8e-3, 2e-2)
+    assert (out1[..., :32] == 0).all()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [c for c in CASES if c[4] % 8 == 0])
+def test_conv_dgrad(dev, B, H, W, Cin, Cout, k, s, p):
+    from yoloseries_amd import hipk
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    gy = _nhwc(B, Ho, Wo, Cout, dev, 7)
+    g = torch.Generator().manual_seed(8)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cout * k * k) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wd = hipk.pack_weight_dgrad(w)
+    gx = _nhwc(B, H, W, Cin, dev, 9)          # pre-existing gradient, accumulate on top
+    gx0 = gx.clone()
+    d = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, Ho, Wo, k, s, p, wd, Cin, hipk.full(gx), accumulate=1)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    x = torch.zeros(B, Cin, H, W, device=dev, requires_grad=True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    (ref,) = torch.autograd.grad(y, x, _nchw(gy))
+    ref = ref.permute(0, 2, 3, 1).to(torch.bfloat16).float() + gx0.float()
+    _close(gx, ref, 1e-2, 4e-2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CASES)
+@pytest.mark.parametrize("splits", [1, 5])
+def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits):
+    from yoloseries_amd import hipk
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    ldg = ((Cout + 7) // 8) * 8
+    gyb = torch.zeros(B, Ho, Wo, ldg, dtype=torch.bfloat16, device=dev)
+    gyb[..., :Cout] = _nhwc(B, Ho, Wo, Cout, dev, 10)
+    x = _nhwc(B, H, W, Cin, dev, 11)
+    dw = torch.zeros(Cout, k * k * Cin, device=dev)
+    d = hipk.wgrad_desc(hipk.full(gyb), Cout, hipk.full(x), 0, Cin, B, Ho, Wo, H, W, k, s, p, dw, splits)
+    hipk.wgrad_launch(d)
+    torch.cuda.synchronize()
+    w = torch.zeros(Cout, Cin, k, k, device=dev, requires_grad=True)
+    y = F.conv2d(_nchw(x), w, stride=s, padding=p)
+    (ref,) = torch.autograd.grad(y, w, _nchw(gyb[..., :Cout]))
+    ref = ref.permute(0, 2, 3, 1).reshape(Cout, -1)
+    scale = ref.abs().max().item()
+    _close(dw, ref, 2e-3, 2e-3 * scale)
+
+
+def test_conv_wgrad_segment_upsampled(dev):
+    """wgrad of one segment of a concat input, read through the 2x upsample."""
+    from yoloseries_amd import hipk
+    B, H, W, C0, C1, Cout = 2, 16, 16, 32, 64, 64
+    lo = _nhwc(B, H // 2, W // 2, C0, dev, 12)
+    sk = _nhwc(B, H, W, C1, dev, 13)
+    gy = _nhwc(B, H, W, Cout, dev, 14)
+    dw = torch.zeros(Cout, C0 + C1, device=dev)
+    hipk.wgrad_launch(hipk.wgrad_desc(hipk.full(gy), Cout, hipk.Slice(lo, 0, C0, ups=1), 0, C0 + C1, B, H, W, H, W, 1, 1, 0, dw, 3))
+    hipk.wgrad_launch(hipk.wgrad_desc(hipk.full(gy), Cout, hipk.full(sk), C0, C0 + C1, B, H, W, H, W, 1, 1, 0, dw, 2))
+    torch.cuda.synchronize()
+    xin = torch.cat([F.interpolate(_nchw(lo), scale_factor=2, mode="nearest"), _nchw(sk)], 1)
+    w = torch.zeros(Cout, C0 + C1, 1, 1, device=dev, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xin, w), w, _nchw(gy))
+    ref = ref.reshape(Cout, -1)
+    _close(dw, ref, 2e-3, 2e-3 * ref.abs().max().item())

@@ -1,0 +1,169 @@
+"""GPU parity of the BN/SiLU, pooling, upsample-grad, input-transform and arena kernels
+against plain PyTorch fp32 references on identical bf16-representable inputs.
+Tolerances: outputs are rounded once to bf16 (rtol 8e-3); fp32 reductions rtol 1e-4.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_bf16(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+
+def _close(got, ref, rtol, atol):
+    err = (got.float() - ref.float()).abs()
+    lim = atol + rtol * ref.float().abs()
+    assert not (err > lim).any(), f"max err {err.max().item():.4g}, {(err > lim).sum().item()} of {err.numel()} out of tol"
+
+
+@pytest.mark.parametrize("C,M", [(32, 1000), (64, 4096 + 17), (256, 777), (1024, 300)])
+def test_bn_silu_fwd_bwd(dev, C, M):
+    from yoloseries_amd import hipk
+    # conv output held in a wider buffer (channel slice) to exercise ld != C
+    ybuf = _rand_bf16((M, C + 16), dev, 1, 2.0)
+    y = hipk.Slice(ybuf, 8, C)
+    yv = ybuf[:, 8:8 + C].float()
+    gamma = (torch.rand(C) + 0.5).to(dev)
+    beta = torch.randn(C).to(dev)
+    rm = torch.zeros(C, device=dev)
+    rv = torch.ones(C, device=dev)
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+    # per-"block" partial stats as the conv kernel would emit (2 fake blocks)
+    half = M // 2
+    stats = torch.zeros(2, 2, C, device=dev)
+    stats[0, 0] = yv[:half].sum(0); stats[0, 1] = (yv[:half] ** 2).sum(0)
+    stats[1, 0] = yv[half:].sum(0); stats[1, 1] = (yv[half:] ** 2).sum(0)
+    ws = torch.zeros(4 * C, device=dev)
+    eps, mom = 1e-3, 0.03
+    hipk.bn_finalize(stats, 2, C, C, M, gamma, beta, rm, rv, nbt, eps, mom, ws)
+    res = _rand_bf16((M, C), dev, 2)
+    out = torch.zeros(M, C, dtype=torch.bfloat16, device=dev)
+    hipk.bn_silu_apply(y, ws, M, hipk.full(out), hipk.full(res))
+    torch.cuda.synchronize()
+
+    x = yv.clone().requires_grad_(True)
+    g_ = gamma.clone().requires_grad_(True)
+    b_ = beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    z = F.batch_norm(x, rm_ref, rv_ref, g_, b_, True, mom, eps)
+    a = F.silu(z)
+    _close(out, a.detach().to(torch.bfloat16).float() + res.float(), 8e-3, 2e-2)
+    assert torch.allclose(rm, rm_ref, rtol=1e-4, atol=1e-5) and torch.allclose(rv, rv_ref, rtol=1e-4, atol=1e-5)
+    assert nbt.item() == 1
+    mean, var = yv.mean(0), yv.var(0, unbiased=False)
+    assert torch.allclose(ws[2 * C:3 * C], mean, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(ws[3 * C:], (var + eps).rsqrt(), rtol=1e-4, atol=1e-4)
+
+    # backward
+    ga = _rand_bf16((M, C), dev, 3)
+    (gx_ref, gg_ref, gb_ref) = torch.autograd.grad(a, (x, g_, b_), ga.float())
+    nblk = hipk.ew_blocks(M)
+    part = torch.zeros(nblk, 2, C, device=dev)
+    hipk.bn_silu_bwd_reduce(hipk.full(ga), y, ws, M, part)
+    dgamma, dbeta, coef = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(2 * C, device=dev)
+    hipk.bn_bwd_finalize(part, nblk, C, M, dgamma, dbeta, coef)
+    gy = torch.zeros(M, C, dtype=torch.bfloat16, device=dev)
+    gres = _rand_bf16((M, C), dev, 4)
+    gres0 = gres.clone()
+    hipk.bn_silu_bwd_apply(hipk.full(ga), y, ws, gamma, coef, M, hipk.full(gy), hipk.full(gres), 1)
+    torch.cuda.synchronize()
+    sc = gx_ref.abs().max().item()
+    _close(gy, gx_ref, 1e-2, 1e-2 * sc)
+    assert torch.allclose(dgamma, gg_ref, rtol=2e-3, atol=2e-3 * gg_ref.abs().max().item())
+    assert torch.allclose(dbeta, gb_ref, rtol=2e-3, atol=2e-3 * gb_ref.abs().max().item())
+    _close(gres, gres0.float() + ga.float(), 8e-3, 1e-2)
+
+
+def test_bn_fold_and_colsum(dev):
+    from yoloseries_amd import hipk
+    C, M = 264, 5000
+    gamma, beta, rm = torch.randn(C, device=dev), torch.randn(C, device=dev), torch.randn(C, device=dev)
+    rv = torch.rand(C, device=dev) + 0.1
+    scale, shift = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    hipk.bn_fold(gamma, beta, rm, rv, 1e-3, C, scale, shift)
+    s = gamma / torch.sqrt(rv + 1e-3)
+    assert torch.allclose(scale, s, rtol=1e-5, atol=1e-6) and torch.allclose(shift, beta - rm * s, rtol=1e-5, atol=1e-5)
+    g = _rand_bf16((M, C), dev, 5)
+    part = torch.zeros(hipk.ew_blocks(M), 2, C, device=dev)
+    out = torch.zeros(C, device=dev)
+    hipk.colsum(hipk.full(g), M, part, out)
+    torch.cuda.synchronize()
+    assert torch.allclose(out, g.float().sum(0), rtol=1e-4, atol=1e-2)
+
+
+def test_maxpool5_fwd_bwd(dev):
+    from yoloseries_amd import hipk
+    B, H, W, C = 2, 20, 20, 64
+    x = _rand_bf16((B, H, W, C), dev, 6)
+    # coarse values create ties, which must resolve to the first maximum in window order
+    x = (x.float() * 2).round().div(2).to(torch.bfloat16)
+    out = torch.zeros_like(x)
+    idx = torch.zeros(B, H, W, C, dtype=torch.int8, device=dev)
+    hipk.maxpool5_fwd(hipk.full(x), B, H, W, hipk.full(out), idx)
+    xn = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.max_pool2d(xn, 5, 1, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(out.float(), ref.permute(0, 2, 3, 1))
+    go = _rand_bf16((B, H, W, C), dev, 7)
+    (gref,) = torch.autograd.grad(ref, xn, go.float().permute(0, 3, 1, 2))
+    gin = torch.zeros_like(x)
+    hipk.maxpool5_bwd(hipk.full(go), idx, B, H, W, hipk.full(gin), 0)
+    torch.cuda.synchronize()
+    _close(gin, gref.permute(0, 2, 3, 1), 8e-3, 2e-2)
+
+
+def test_upsample2_bwd_and_s2d(dev):
+    from yoloseries_amd import hipk
+    B, Hl, Wl, C = 2, 10, 12, 32
+    ghi = _rand_bf16((B, 2 * Hl, 2 * Wl, C), dev, 8)
+    glo = _rand_bf16((B, Hl, Wl, C), dev, 9)
+    glo0 = glo.clone()
+    hipk.upsample2_bwd(hipk.full(ghi), B, Hl, Wl, hipk.full(glo), 1)
+    ref = ghi.float().reshape(B, Hl, 2, Wl, 2, C).sum((2, 4)) + glo0.float()
+    torch.cuda.synchronize()
+    _close(glo, ref, 8e-3, 2e-2)
+    x = torch.rand(2, 3, 16, 24, device=dev)
+    out = torch.ones(2, 8, 12, 16, dtype=torch.bfloat16, device=dev)
+    hipk.input_s2d(x, out)
+    torch.cuda.synchronize()
+    ref = x.reshape(2, 3, 8, 2, 12, 2).permute(0, 2, 4, 3, 5, 1).reshape(2, 8, 12, 12).to(torch.bfloat16)
+    assert torch.equal(out[..., :12], ref) and (out[..., 12:] == 0).all()
+
+
+def test_arena_kernels(dev):
+    from yoloseries_amd import hipk
+    n = 100003
+    src = torch.randn(n, device=dev)
+    idx = torch.randint(-1, n, (2 * n,), dtype=torch.int32, device=dev)
+    dst = torch.zeros(2 * n, dtype=torch.bfloat16, device=dev)
+    hipk.pack_bf16(src, idx, dst)
+    ref = torch.where(idx >= 0, src[idx.clamp(min=0).long()], torch.zeros((), device=dev)).to(torch.bfloat16)
+    assert torch.equal(dst, ref)
+    d2 = torch.zeros(2 * n, device=dev)
+    hipk.gather_f32(src, idx, d2)
+    assert torch.equal(d2, torch.where(idx >= 0, src[idx.clamp(min=0).long()], torch.zeros((), device=dev)))
+    # SGD nesterov vs torch.optim.SGD, two groups with different lr/wd, two steps
+    p = torch.randn(n, device=dev)
+    p_ref = [p[:n // 2].clone().requires_grad_(True), p[n // 2:].clone().requires_grad_(True)]
+    opt = torch.optim.SGD([{"params": [p_ref[0]], "lr": 0.1, "weight_decay": 0.0},
+                           {"params": [p_ref[1]], "lr": 0.01, "weight_decay": 5e-4}], lr=0.1, momentum=0.937, nesterov=True)
+    group = torch.zeros(n, dtype=torch.uint8, device=dev); group[n // 2:] = 1
+    lr = torch.tensor([0.1, 0.01], device=dev); wd = torch.tensor([0.0, 5e-4], device=dev)
+    buf = torch.zeros(n, device=dev)
+    for step in range(2):
+        g = torch.randn(n, device=dev)
+        p_ref[0].grad, p_ref[1].grad = g[:n // 2].clone(), g[n // 2:].clone()
+        opt.step()
+        hipk.sgd_step(p, g, buf, group, lr, wd, 0.937, True, step == 0)
+    torch.cuda.synchronize()
+    assert torch.allclose(p, torch.cat([p_ref[0], p_ref[1]]).detach(), rtol=1e-5, atol=1e-6)
+    part, out = torch.zeros(4096, device=dev), torch.zeros(1, device=dev)
+    hipk.sumsq(src, part, out)
+    assert torch.allclose(out, (src.double() ** 2).sum().float(), rtol=1e-5)
+    e = torch.randn(n, device=dev); e0 = e.clone()
+    hipk.ema_update(e, src, 0.99)
+    assert torch.allclose(e, 0.99 * e0 + 0.01 * src, rtol=1e-5, atol=1e-6)

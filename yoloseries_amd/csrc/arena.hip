@@ -1,0 +1,141 @@
+// Flat parameter-arena kernels: index-map gather between the fp32 master parameters
+// (PyTorch OIHW layout, state_dict compatible) and the packed bf16 weight images read
+// by conv_igemm.hip, plus the optimizer-side streaming kernels (SGD-nesterov with
+// per-element parameter groups, grad-norm, EMA) of train_yolov5.py:258-280,342-350 and
+// trainer/ema_model.py:20-28.  All HBM-bound, one launch per step each.
+#include "common.h"
+#include <stdarg.h>
+
+namespace {
+constexpr int TH = 256;
+inline int grid_for(long n) {
+    long g = (n + TH - 1) / TH;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__global__ void pack_bf16_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, long n, uint16_t* __restrict__ dst)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int32_t j = idx[i];
+        dst[i] = j >= 0 ? f2bf(src[j]) : (uint16_t)0;
+    }
+}
+__global__ void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, long n, float* __restrict__ dst)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int32_t j = idx[i];
+        dst[i] = j >= 0 ? src[j] : 0.f;
+    }
+}
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                           const uint8_t* __restrict__ group, long n, const float* __restrict__ lr,
+                           const float* __restrict__ wd, float momentum, int nesterov, int first,
+                           const float* __restrict__ grad_scale)
+{
+    const float gs = grad_scale ? *grad_scale : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int gi = group ? group[i] : 0;
+        float pv = p[i];
+        float gv = g[i] * gs + wd[gi] * pv;
+        float b = first ? gv : momentum * buf[i] + gv;
+        buf[i] = b;
+        float upd = nesterov ? gv + momentum * b : b;
+        p[i] = pv - lr[gi] * upd;
+    }
+}
+__global__ __launch_bounds__(TH) void sumsq_part_kernel(const float* __restrict__ x, long n, float* __restrict__ part)
+{
+    __shared__ double sw[TH / 64];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        s += (double)v * (double)v;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+        for (int w = 0; w < TH / 64; ++w) tsum += sw[w];
+        part[blockIdx.x] = (float)tsum;
+    }
+}
+__global__ void sum_final_kernel(const float* __restrict__ part, int nb, float* out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nb; ++i) s += (double)part[i];
+        *out = (float)s;
+    }
+}
+__global__ void ema_kernel(float* __restrict__ e, const float* __restrict__ p, long n, float decay)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        e[i] = decay * e[i] + (1.f - decay) * p[i];
+}
+}  // namespace
+
+// ---- error plumbing shared by every translation unit ------------------------
+static thread_local char g_err[512] = "";
+void yh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* yh_last_error(void) { return g_err; }
+extern "C" int yh_version(void) { return 100; }
+extern "C" int yh_device_cus(void) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    return prop.multiProcessorCount;
+}
+
+extern "C" int yh_pack_bf16(const float* src, const int32_t* idx, int64_t n, yh_bf16* dst, yh_stream stream)
+{
+    YH_CHECK_ARG(src && idx && dst && n >= 0, "yh_pack_bf16: bad args");
+    if (n == 0) return YH_OK;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid_for(n)), dim3(TH), 0, (hipStream_t)stream, src, idx, (long)n, dst);
+    YH_CHECK_LAUNCH("yh_pack_bf16");
+    return YH_OK;
+}
+extern "C" int yh_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, yh_stream stream)
+{
+    YH_CHECK_ARG(src && idx && dst && n >= 0, "yh_gather_f32: bad args");
+    if (n == 0) return YH_OK;
+    hipLaunchKernelGGL(gather_f32_kernel, dim3(grid_for(n)), dim3(TH), 0, (hipStream_t)stream, src, idx, (long)n, dst);
+    YH_CHECK_LAUNCH("yh_gather_f32");
+    return YH_OK;
+}
+extern "C" int yh_sgd_step(float* p, const float* g, float* buf, const uint8_t* group, int64_t n,
+                           const float* lr, const float* wd, int ngroups, float momentum, int nesterov,
+                           int first_step, const float* grad_scale, yh_stream stream)
+{
+    YH_CHECK_ARG(p && g && buf && lr && wd && n >= 0 && ngroups >= 1 && ngroups <= 256, "yh_sgd_step: bad args");
+    if (n == 0) return YH_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(TH), 0, (hipStream_t)stream,
+                       p, g, buf, group, (long)n, lr, wd, momentum, nesterov, first_step, grad_scale);
+    YH_CHECK_LAUNCH("yh_sgd_step");
+    return YH_OK;
+}
+extern "C" int yh_sumsq(const float* x, int64_t n, float* part, float* out, yh_stream stream)
+{
+    YH_CHECK_ARG(x && part && out && n > 0, "yh_sumsq: bad args (part needs 4096 floats)");
+    int nb = grid_for(n);
+    hipLaunchKernelGGL(sumsq_part_kernel, dim3(nb), dim3(TH), 0, (hipStream_t)stream, x, (long)n, part);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, nb, out);
+    YH_CHECK_LAUNCH("yh_sumsq");
+    return YH_OK;
+}
+extern "C" int yh_ema_update(float* ema, const float* p, int64_t n, float decay, yh_stream stream)
+{
+    YH_CHECK_ARG(ema && p && n >= 0, "yh_ema_update: bad args");
+    if (n == 0) return YH_OK;
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(TH), 0, (hipStream_t)stream, ema, p, (long)n, decay);
+    YH_CHECK_LAUNCH("yh_ema_update");
+    return YH_OK;
+}

@@ -1,0 +1,353 @@
+// Implicit-GEMM convolution for gfx950: NHWC bf16 activations, packed bf16 weights
+// [Npad][taps*Ctot], fp32 accumulate on v_mfma_f32_32x32x16_bf16.
+//
+//   out[m][n] = sum_{tap,c} X[src(m,tap)][c] * W[n][tap*Ctot + c]      m = (img,ho,wo)
+//
+// One kernel serves the forward conv (ConvBnAct / Detect, utils/layer_tools.py:82-94,
+// :454-470) and the data gradient (transposed gather, YH_CONV_DGRAD); the input may be
+// a virtual channel-concat of two buffers, one of them read through a nearest-2x
+// upsample (the neck joins of models/normal/yolov5s.py:101-114 are never materialised).
+//
+// Tile: BM=128 pixels x BN in {32,64,128} channels x BK=32, 256 threads = 4 waves.
+// A/B tiles are register-staged (global_load_dwordx4 -> ds_write_b128) so that padding
+// taps can be zero-filled; LDS rows are padded to 80 B which makes the ds_read_b128
+// fragment reads conflict-free.  Double-buffered LDS, next tile's global loads are
+// issued before the MFMAs of the current one.  The epilogue transposes through LDS
+// so every global store is a 16-byte row chunk, and optionally emits per-channel
+// sum / sum-of-squares partials (training-mode BatchNorm statistics) per block.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDSP = 40;   // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
+
+struct ConvK {
+    yh_conv_desc d;
+    int M, Ctot, Ktot, nkt, mtiles;
+    int sa, sb, sc, sdshift;
+};
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
+{
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr int NBL = (BN * 4 + 255) / 256;       // B chunks per thread
+    constexpr int CP = BN + 8;                      // sC row pitch (elements)
+    constexpr int MAIN_BYTES = (2 * (BM + BN) * LDSP * 2) > (BM * CP * 2) ? (2 * (BM + BN) * LDSP * 2) : (BM * CP * 2);
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* sA = reinterpret_cast<uint16_t*>(smem);            // [2][BM][LDSP]
+    uint16_t* sB = sA + 2 * BM * LDSP;                            // [2][BN][LDSP]
+    uint16_t* sC = reinterpret_cast<uint16_t*>(smem);            // [BM][CP] (aliases sA/sB)
+    float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);  // [WM][2][BN]
+
+    const yh_conv_desc& d = p.d;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int kc = t & 3;
+    const int rowA = t >> 2;
+    const int n0 = blockIdx.y * BN;
+    const int HoWo = d.Ho * d.Wo;
+    const int sdmask = (1 << p.sdshift) - 1;
+
+    float run_s = 0.f, run_q = 0.f;
+
+    for (int mt = blockIdx.x; mt < p.mtiles; mt += gridDim.x) {
+        const int m0 = mt * BM;
+        int hb[2], wb[2], img[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = m0 + rowA + 64 * i;
+            if (m < p.M) {
+                int im = m / HoWo;
+                int rem = m - im * HoWo;
+                int ho = rem / d.Wo;
+                int wo = rem - ho * d.Wo;
+                img[i] = im; hb[i] = ho * p.sa + p.sc; wb[i] = wo * p.sa + p.sc;
+            } else {
+                img[i] = 0; hb[i] = -(1 << 28); wb[i] = -(1 << 28);
+            }
+        }
+
+        f32x16_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        uint4 ra[2], rb[NBL];
+
+        auto load_tile = [&](int kt) {
+            const int k = kt * BK + kc * 8;
+            const bool kvalid = k < p.Ktot;
+            int tap = 0, c = 0;
+            if (kvalid) { tap = k / p.Ctot; c = k - tap * p.Ctot; }
+            const int kh = tap / d.KW;
+            const int kw = tap - kh * d.KW;
+            const int sidx = (d.nseg > 1 && c >= d.seg[0].C) ? 1 : 0;
+            const yh_seg& sg = d.seg[sidx];
+            const int cc = c - (sidx ? d.seg[0].C : 0);
+            const int ups = sg.ups;
+            const int Hs = d.Hi >> ups, Ws = d.Wi >> ups;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int hn = hb[i] + kh * p.sb;
+                int wn_ = wb[i] + kw * p.sb;
+                bool ok = kvalid && hn >= 0 && wn_ >= 0 && (((hn | wn_) & sdmask) == 0);
+                int hs = hn >> p.sdshift, ws = wn_ >> p.sdshift;
+                ok = ok && hs < d.Hi && ws < d.Wi;
+                hs >>= ups; ws >>= ups;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    size_t pix = ((size_t)img[i] * Hs + hs) * Ws + ws;
+                    v = *reinterpret_cast<const uint4*>(sg.ptr + pix * sg.ld + cc);
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                int id = t + i * 256;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (id < BN * 4 && kvalid) {
+                    int n = id >> 2;
+                    v = *reinterpret_cast<const uint4*>(d.w + (size_t)(n0 + n) * p.Ktot + k);
+                }
+                rb[i] = v;
+            }
+        };
+        auto store_tile = [&](int buf) {
+            uint16_t* a = sA + buf * BM * LDSP;
+            uint16_t* b = sB + buf * BN * LDSP;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<uint4*>(a + (rowA + 64 * i) * LDSP + kc * 8) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                int id = t + i * 256;
+                if (id < BN * 4) *reinterpret_cast<uint4*>(b + (id >> 2) * LDSP + kc * 8) = rb[i];
+            }
+        };
+
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+
+        for (int kt = 0; kt < p.nkt; ++kt) {
+            const int buf = kt & 1;
+            const bool more = (kt + 1) < p.nkt;
+            if (more) load_tile(kt + 1);
+            const uint16_t* a = sA + buf * BM * LDSP;
+            const uint16_t* b = sB + buf * BN * LDSP;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t af[TM], bfr[TN];
+                const int koff = (ks * 2 + (lane >> 5)) * 8;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    int r = wm * (TM * 32) + i * 32 + (lane & 31);
+                    uint4 v = *reinterpret_cast<const uint4*>(a + r * LDSP + koff);
+                    af[i] = __builtin_bit_cast(bf16x8_t, v);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    int r = wn * (TN * 32) + j * 32 + (lane & 31);
+                    uint4 v = *reinterpret_cast<const uint4*>(b + r * LDSP + koff);
+                    bfr[j] = __builtin_bit_cast(bf16x8_t, v);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+
+        // ---- epilogue: registers -> LDS (bf16, transposed to row-major) ----
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = wn * (TN * 32) + j * 32 + (lane & 31);
+            const int n = n0 + c;
+            const bool nv = n < d.N;
+            const float bs = (d.bias && nv) ? d.bias[n] : 0.f;
+            const float scl = (d.scale && nv) ? d.scale[n] : 1.f;
+            const float sft = (d.shift && nv) ? d.shift[n] : 0.f;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r] + bs;
+                    v = v * scl + sft;
+                    if (d.act == YH_ACT_SILU) v = siluf_(v);
+                    uint16_t hb16 = f2bf(v);
+                    sC[row * CP + c] = hb16;
+                    float vr = bf2f(hb16);
+                    s += vr; q += vr * vr;
+                }
+            }
+            if (d.stats) {
+                s += __shfl_xor(s, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (lane < 32) {
+                    sStat[(wm * 2 + 0) * BN + c] = s;
+                    sStat[(wm * 2 + 1) * BN + c] = q;
+                }
+            }
+        }
+        __syncthreads();
+
+        constexpr int CPR = BN / 8;                 // chunks per row
+        constexpr int NCH = BM * CPR / 256;         // chunks per thread
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int id = t + i * 256;
+            int row = id / CPR;
+            int cch = id - row * CPR;
+            int m = m0 + row;
+            int n = n0 + cch * 8;
+            if (m < p.M && n < d.N) {
+                uint4 v = *reinterpret_cast<const uint4*>(sC + row * CP + cch * 8);
+                uint16_t* dst;
+                bool first = n < d.nsplit;
+                if (first) dst = d.out0 + (size_t)m * d.ld0 + n;
+                else       dst = d.out1 + (size_t)m * d.ld1 + (n - d.nsplit);
+                const bool addres = (d.res != nullptr) && first;
+                if (addres || d.accumulate) {
+                    float f[8];
+                    unpack8(v, f);
+                    if (addres) {
+                        uint4 rv = *reinterpret_cast<const uint4*>(d.res + (size_t)m * d.ldr + n);
+                        float g[8]; unpack8(rv, g);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += g[e];
+                    }
+                    if (d.accumulate) {
+                        uint4 ov = *reinterpret_cast<const uint4*>(dst);
+                        float g[8]; unpack8(ov, g);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += g[e];
+                    }
+                    v = pack8(f);
+                }
+                *reinterpret_cast<uint4*>(dst) = v;
+            }
+        }
+        if (d.stats && t < BN) {
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                run_s += sStat[(w * 2 + 0) * BN + t];
+                run_q += sStat[(w * 2 + 1) * BN + t];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (d.stats && t < BN) {
+        d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
+        d.stats[((size_t)blockIdx.x * 2 + 1) * d.Npad + n0 + t] = run_q;
+    }
+}
+
+template <int BN, int WM, int WN>
+constexpr size_t conv_smem_bytes() {
+    size_t a = 2 * (BM + BN) * LDSP * 2;
+    size_t c = BM * (BN + 8) * 2;
+    return (a > c ? a : c) + WM * 2 * BN * 4;
+}
+
+int pick_bn(int N) { return N <= 32 ? 32 : (N <= 64 ? 64 : 128); }
+
+void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
+    long M = (long)d->B * d->Ho * d->Wo;
+    int mtiles = (int)((M + BM - 1) / BM);
+    int b = pick_bn(d->N);
+    int nt = (d->N + b - 1) / b;
+    int cap = 2048 / nt;
+    cap = (cap / 8) * 8;
+    if (cap < 8) cap = 8;
+    int g = mtiles < cap ? mtiles : cap;
+    *gx = g; *gy = nt; *bn = b;
+}
+
+}  // namespace
+
+extern "C" int yh_conv_stat_blocks(const yh_conv_desc* d) {
+    if (!d) return 0;
+    int gx, gy, bn;
+    conv_grid(d, &gx, &gy, &bn);
+    return gx;
+}
+
+extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream)
+{
+    YH_CHECK_ARG(d != nullptr, "yh_conv_igemm: null desc");
+    YH_CHECK_ARG(d->nseg == 1 || d->nseg == 2, "yh_conv_igemm: nseg must be 1 or 2 (got %d)", d->nseg);
+    YH_CHECK_ARG(d->mode == YH_CONV_FWD || d->mode == YH_CONV_DGRAD, "yh_conv_igemm: bad mode");
+    YH_CHECK_ARG(d->stride == 1 || d->stride == 2, "yh_conv_igemm: stride must be 1 or 2");
+    YH_CHECK_ARG(d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->Hi > 0 && d->Wi > 0, "yh_conv_igemm: bad dims");
+    YH_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->KH <= 7 && d->KW <= 7, "yh_conv_igemm: bad kernel size");
+    int Ctot = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const yh_seg& g = d->seg[s];
+        YH_CHECK_ARG(g.ptr && yh_aligned16(g.ptr), "yh_conv_igemm: seg %d pointer null/unaligned", s);
+        YH_CHECK_ARG(g.C > 0 && g.C % 8 == 0 && g.ld % 8 == 0 && g.ld >= g.C, "yh_conv_igemm: seg %d C=%d ld=%d must be multiples of 8", s, g.C, g.ld);
+        YH_CHECK_ARG(g.ups == 0 || g.ups == 1, "yh_conv_igemm: seg %d bad ups", s);
+        if (g.ups) YH_CHECK_ARG(d->Hi % 2 == 0 && d->Wi % 2 == 0, "yh_conv_igemm: upsampled segment needs even Hi/Wi");
+        Ctot += g.C;
+    }
+    YH_CHECK_ARG(d->w && yh_aligned16(d->w), "yh_conv_igemm: weights null/unaligned");
+    YH_CHECK_ARG(d->N > 0 && d->Npad >= d->N && d->Npad % 128 == 0, "yh_conv_igemm: N=%d Npad=%d (Npad must be a multiple of 128)", d->N, d->Npad);
+    YH_CHECK_ARG(d->out0 && yh_aligned16(d->out0) && d->ld0 % 8 == 0, "yh_conv_igemm: out0 null/unaligned");
+    YH_CHECK_ARG(d->nsplit > 0 && d->nsplit % 8 == 0 || d->nsplit >= d->N, "yh_conv_igemm: nsplit must be a multiple of 8");
+    if (d->nsplit < d->N) YH_CHECK_ARG(d->out1 && yh_aligned16(d->out1) && d->ld1 % 8 == 0, "yh_conv_igemm: out1 null/unaligned");
+    if (d->res) YH_CHECK_ARG(yh_aligned16(d->res) && d->ldr % 8 == 0, "yh_conv_igemm: res unaligned");
+    if (d->mode == YH_CONV_FWD) {
+        YH_CHECK_ARG((d->Hi + 2 * d->pad - d->KH) / d->stride + 1 == d->Ho && (d->Wi + 2 * d->pad - d->KW) / d->stride + 1 == d->Wo,
+                     "yh_conv_igemm: fwd geometry mismatch Hi=%d Ho=%d k=%d s=%d p=%d", d->Hi, d->Ho, d->KH, d->stride, d->pad);
+    } else {
+        YH_CHECK_ARG((d->Ho + 2 * d->pad - d->KH) / d->stride + 1 == d->Hi && (d->Wo + 2 * d->pad - d->KW) / d->stride + 1 == d->Wi,
+                     "yh_conv_igemm: dgrad geometry mismatch Ho=%d Hi=%d k=%d s=%d p=%d", d->Ho, d->Hi, d->KH, d->stride, d->pad);
+    }
+    long M = (long)d->B * d->Ho * d->Wo;
+    YH_CHECK_ARG(M < (1L << 31) - BM, "yh_conv_igemm: too many output pixels");
+
+    ConvK k;
+    k.d = *d;
+    k.M = (int)M;
+    k.Ctot = Ctot;
+    k.Ktot = d->KH * d->KW * Ctot;
+    k.nkt = (k.Ktot + BK - 1) / BK;
+    k.mtiles = (int)((M + BM - 1) / BM);
+    if (d->mode == YH_CONV_FWD) { k.sa = d->stride; k.sb = 1; k.sc = -d->pad; k.sdshift = 0; }
+    else { k.sa = 1; k.sb = -1; k.sc = d->pad; k.sdshift = d->stride == 2 ? 1 : 0; }
+    if (k.d.nsplit > k.d.N) k.d.nsplit = k.d.N + 8;   // everything goes to out0
+
+    int gx, gy, bn;
+    conv_grid(d, &gx, &gy, &bn);
+    YH_CHECK_ARG(gy * bn <= d->Npad, "yh_conv_igemm: Npad too small for tile");
+    dim3 grid(gx, gy), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (bn == 32) {
+        const size_t sm = conv_smem_bytes<32, 4, 1>();
+        conv_igemm_kernel<32, 4, 1><<<grid, block, sm, st>>>(k);
+    } else if (bn == 64) {
+        const size_t sm = conv_smem_bytes<64, 4, 1>();
+        conv_igemm_kernel<64, 4, 1><<<grid, block, sm, st>>>(k);
+    } else {
+        const size_t sm = conv_smem_bytes<128, 2, 2>();
+        conv_igemm_kernel<128, 2, 2><<<grid, block, sm, st>>>(k);
+    }
+    YH_CHECK_LAUNCH("yh_conv_igemm");
+    return YH_OK;
+}

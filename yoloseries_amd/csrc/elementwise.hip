@@ -1,0 +1,535 @@
+// HBM-bound NHWC bf16 kernels around the convolutions: training-mode BatchNorm
+// statistics finalisation, BN+SiLU apply and its two-pass backward
+// (utils/layer_tools.py:87-91), SPPF max-pool (utils/layer_tools.py:270-288),
+// nearest-upsample gradient, and the stem's space-to-depth input transform.
+// Every global access is a 16-byte chunk of 8 channels; reductions are
+// deterministic (per-block partial slabs combined in a fixed order, fp64).
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+// ---------------------------------------------------------------- BN finalize
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int ldstat, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, int64_t* num_batches,
+                                   float eps, float momentum, float* ws)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches) *num_batches += 1;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)stats[((size_t)b * 2 + 0) * ldstat + c];
+        q += (double)stats[((size_t)b * 2 + 1) * ldstat + c];
+    }
+    double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma[c], bt = beta[c];
+    float scale = g * invstd;
+    ws[c] = scale;
+    ws[C + c] = bt - (float)mean * scale;
+    ws[2 * C + c] = (float)mean;
+    ws[3 * C + c] = invstd;
+    if (running_mean) {
+        double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                               float eps, int C, float* scale, float* shift)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - rm[c] * s;
+}
+
+// ---------------------------------------------------------------- BN+SiLU apply
+__global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, const float* __restrict__ ws, int C, int cpr,
+                                     long nchunks, uint16_t* __restrict__ out, int ldo,
+                                     const uint16_t* __restrict__ res, int ldr)
+{
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < nchunks; id += (long)gridDim.x * blockDim.x) {
+        long m = id / cpr;
+        int c = (int)(id - m * cpr) * 8;
+        uint4 v = *reinterpret_cast<const uint4*>(y + m * ldy + c);
+        float f[8];
+        unpack8(v, f);
+        const float4 s0 = *reinterpret_cast<const float4*>(ws + c);
+        const float4 s1 = *reinterpret_cast<const float4*>(ws + c + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(ws + C + c);
+        const float4 h1 = *reinterpret_cast<const float4*>(ws + C + c + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = siluf_(f[e] * sc[e] + sh[e]);
+        if (res) {
+            uint4 rv = *reinterpret_cast<const uint4*>(res + m * ldr + c);
+            float g[8];
+            unpack8(rv, g);
+            // residual is added to the bf16-rounded activation, as x += x_res does on stored tensors
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bf_round(f[e]) + g[e];
+        }
+        *reinterpret_cast<uint4*>(out + m * ldo + c) = pack8(f);
+    }
+}
+
+// ---------------------------------------------------------------- column reductions
+// Block b owns rows [b*rpb, (b+1)*rpb).  Thread (rg, cch) accumulates 8 channels over
+// rows rg, rg+RG, ...; row groups are combined through LDS.
+template <int MODE>   // 0: BN+SiLU backward sums (gz, gz*xhat) ; 1: plain column sum of g
+__global__ __launch_bounds__(EW_THREADS) void col_reduce_kernel(const uint16_t* __restrict__ ga, int ldga,
+                                                                const uint16_t* __restrict__ y, int ldy,
+                                                                const float* __restrict__ ws, int C, int cpr,
+                                                                long M, long rpb, float* __restrict__ part)
+{
+    __shared__ float sP[EW_THREADS * 16];
+    const int t = threadIdx.x;
+    const int RG = EW_THREADS / cpr;
+    const int rg = t / cpr;
+    const int cch = t - rg * cpr;
+    const int c = cch * 8;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (rg < RG) {
+        float sc[8], sh[8], mu[8], is[8];
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = ws[c + e]; sh[e] = ws[C + c + e]; mu[e] = ws[2 * C + c + e]; is[e] = ws[3 * C + c + e]; }
+        }
+        long r0 = (long)blockIdx.x * rpb;
+        long r1 = min(M, r0 + rpb);
+        for (long m = r0 + rg; m < r1; m += RG) {
+            uint4 gv = *reinterpret_cast<const uint4*>(ga + m * ldga + c);
+            float g[8];
+            unpack8(gv, g);
+            if (MODE == 0) {
+                uint4 yv = *reinterpret_cast<const uint4*>(y + m * ldy + c);
+                float yy[8];
+                unpack8(yv, yy);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float z = yy[e] * sc[e] + sh[e];
+                    float sg = sigmoidf_(z);
+                    float gz = g[e] * (sg * (1.f + z * (1.f - sg)));
+                    float xh = (yy[e] - mu[e]) * is[e];
+                    a1[e] += gz; a2[e] += gz * xh;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a1[e] += g[e];
+            }
+        }
+    }
+    // sP layout [rg][2][C]  (RG*2*C = 256/cpr*2*cpr*8 <= 4096 floats)
+    if (rg < RG) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sP[(rg * 2 + 0) * C + c + e] = a1[e];
+            sP[(rg * 2 + 1) * C + c + e] = a2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * C; i += EW_THREADS) {
+        int which = i / C;
+        int cc = i - which * C;
+        float s = 0.f;
+        for (int r = 0; r < RG; ++r) s += sP[(r * 2 + which) * C + cc];
+        part[((size_t)blockIdx.x * 2 + which) * C + cc] = s;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
+                                       float* dgamma, float* dbeta, float* coef)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)part[((size_t)b * 2 + 0) * C + c];
+        s2 += (double)part[((size_t)b * 2 + 1) * C + c];
+    }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    if (coef) { coef[c] = (float)(s1 / M); coef[C + c] = (float)(s2 / M); }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[((size_t)b * 2 + 0) * C + c];
+    out[c] = (float)s;
+}
+
+__global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ldga, const uint16_t* __restrict__ y, int ldy,
+                                         const float* __restrict__ ws, const float* __restrict__ gamma,
+                                         const float* __restrict__ coef, int C, int cpr, long nchunks,
+                                         uint16_t* __restrict__ gy, int ldgy, uint16_t* gres, int ldgres, int gres_acc)
+{
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < nchunks; id += (long)gridDim.x * blockDim.x) {
+        long m = id / cpr;
+        int c = (int)(id - m * cpr) * 8;
+        uint4 gv = *reinterpret_cast<const uint4*>(ga + m * ldga + c);
+        uint4 yv = *reinterpret_cast<const uint4*>(y + m * ldy + c);
+        float g[8], yy[8], o[8];
+        unpack8(gv, g);
+        unpack8(yv, yy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float sc = ws[c + e], sh = ws[C + c + e], mu = ws[2 * C + c + e], is = ws[3 * C + c + e];
+            float z = yy[e] * sc + sh;
+            float sg = sigmoidf_(z);
+            float gz = g[e] * (sg * (1.f + z * (1.f - sg)));
+            float xh = (yy[e] - mu) * is;
+            o[e] = gamma[c + e] * is * (gz - coef[c + e] - xh * coef[C + c + e]);
+        }
+        *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
+        if (gres) {
+            uint16_t* dst = gres + m * ldgres + c;
+            if (gres_acc) {
+                uint4 ov = *reinterpret_cast<const uint4*>(dst);
+                float f[8];
+                unpack8(ov, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += g[e];
+                *reinterpret_cast<uint4*>(dst) = pack8(f);
+            } else {
+                *reinterpret_cast<uint4*>(dst) = gv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- max-pool 5x5 s1 p2
+__global__ void maxpool5_fwd_kernel(const uint16_t* __restrict__ x, int ldx, int B, int H, int W, int cpr,
+                                    uint16_t* __restrict__ out, int ldo, int8_t* __restrict__ idx)
+{
+    long total = (long)B * H * W * cpr;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        long pix = id / cpr;
+        int c = (int)(id - pix * cpr) * 8;
+        int w = (int)(pix % W);
+        long t2 = pix / W;
+        int h = (int)(t2 % H);
+        long b = t2 / H;
+        float best[8];
+        int bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        bool any = false;
+        for (int i = 0; i < 5; ++i) {
+            int hh = h - 2 + i;
+            if (hh < 0 || hh >= H) continue;
+            for (int j = 0; j < 5; ++j) {
+                int ww = w - 2 + j;
+                if (ww < 0 || ww >= W) continue;
+                uint4 v = *reinterpret_cast<const uint4*>(x + ((b * H + hh) * W + ww) * ldx + c);
+                float f[8];
+                unpack8(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (!any || f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; bi[e] = i * 5 + j; }
+                }
+                any = true;
+            }
+        }
+        *reinterpret_cast<uint4*>(out + pix * ldo + c) = pack8(best);
+        if (idx) {
+            uint2 pk;
+            pk.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+            pk.y = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+            *reinterpret_cast<uint2*>(idx + pix * (cpr * 8) + c) = pk;
+        }
+    }
+}
+
+__global__ void maxpool5_bwd_kernel(const uint16_t* __restrict__ gout, int ldgo, const int8_t* __restrict__ idx,
+                                    int B, int H, int W, int cpr, uint16_t* __restrict__ gin, int ldgi, int acc)
+{
+    long total = (long)B * H * W * cpr;
+    const int C = cpr * 8;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        long pix = id / cpr;
+        int c = (int)(id - pix * cpr) * 8;
+        int w = (int)(pix % W);
+        long t2 = pix / W;
+        int h = (int)(t2 % H);
+        long b = t2 / H;
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        for (int i = 0; i < 5; ++i) {
+            int oh = h + 2 - i;
+            if (oh < 0 || oh >= H) continue;
+            for (int j = 0; j < 5; ++j) {
+                int ow = w + 2 - j;
+                if (ow < 0 || ow >= W) continue;
+                long op = (b * H + oh) * W + ow;
+                uint2 pk = *reinterpret_cast<const uint2*>(idx + op * C + c);
+                uint4 gv = *reinterpret_cast<const uint4*>(gout + op * ldgo + c);
+                float g[8];
+                unpack8(gv, g);
+                const int want = i * 5 + j;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int k = (int)(((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xff);
+                    if (k == want) s[e] += g[e];
+                }
+            }
+        }
+        uint16_t* dst = gin + pix * ldgi + c;
+        if (acc) {
+            uint4 ov = *reinterpret_cast<const uint4*>(dst);
+            float f[8];
+            unpack8(ov, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += f[e];
+        }
+        *reinterpret_cast<uint4*>(dst) = pack8(s);
+    }
+}
+
+__global__ void upsample2_bwd_kernel(const uint16_t* __restrict__ ghi, int ldh, int B, int Hlo, int Wlo, int cpr,
+                                     uint16_t* __restrict__ glo, int ldl, int acc)
+{
+    long total = (long)B * Hlo * Wlo * cpr;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        long pix = id / cpr;
+        int c = (int)(id - pix * cpr) * 8;
+        int w = (int)(pix % Wlo);
+        long t2 = pix / Wlo;
+        int h = (int)(t2 % Hlo);
+        long b = t2 / Hlo;
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                long hp = ((b * (2 * Hlo) + 2 * h + dy) * (2L * Wlo) + 2 * w + dx);
+                uint4 v = *reinterpret_cast<const uint4*>(ghi + hp * ldh + c);
+                float g[8];
+                unpack8(v, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += g[e];
+            }
+        uint16_t* dst = glo + pix * ldl + c;
+        if (acc) {
+            uint4 ov = *reinterpret_cast<const uint4*>(dst);
+            float f[8];
+            unpack8(ov, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += f[e];
+        }
+        *reinterpret_cast<uint4*>(dst) = pack8(s);
+    }
+}
+
+// ---------------------------------------------------------------- input transform
+__global__ void input_s2d_kernel(const float* __restrict__ x, int B, int Cin, int H, int W, uint16_t* __restrict__ out)
+{
+    const int H2 = H / 2, W2 = W / 2;
+    long total = (long)B * H2 * W2;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        int w2 = (int)(id % W2);
+        long t2 = id / W2;
+        int h2 = (int)(t2 % H2);
+        long b = t2 / H2;
+        float f[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] = 0.f;
+        for (int c = 0; c < Cin; ++c) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const float2 v = *reinterpret_cast<const float2*>(x + ((b * Cin + c) * H + 2 * h2 + dy) * (long)W + 2 * w2);
+                f[(dy * 2 + 0) * Cin + c] = v.x;
+                f[(dy * 2 + 1) * Cin + c] = v.y;
+            }
+        }
+        uint4* o = reinterpret_cast<uint4*>(out + id * 16);
+        o[0] = pack8(f);
+        o[1] = pack8(f + 8);
+    }
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+inline int ew_grid(long nthreads) {
+    long g = (nthreads + EW_THREADS - 1) / EW_THREADS;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int yh_ew_blocks(int64_t M) {
+    long b = (M + 255) / 256;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int yh_bn_finalize(const float* stats, int nblk, int ldstat, int C, int64_t count,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              int64_t* num_batches, float eps, float momentum, float* ws, yh_stream stream)
+{
+    YH_CHECK_ARG(stats && gamma && beta && ws && nblk > 0 && C > 0 && count > 0 && ldstat >= C, "yh_bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       stats, nblk, ldstat, C, (double)count, gamma, beta, running_mean, running_var, num_batches, eps, momentum, ws);
+    YH_CHECK_LAUNCH("yh_bn_finalize");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv,
+                          float eps, int C, float* scale, float* shift, yh_stream stream)
+{
+    YH_CHECK_ARG(gamma && beta && rm && rv && scale && shift && C > 0, "yh_bn_fold: bad args");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps, C, scale, shift);
+    YH_CHECK_LAUNCH("yh_bn_fold");
+    return YH_OK;
+}
+
+#define YH_CHECK_SLICE(name, p, ld, C) \
+    YH_CHECK_ARG((p) && yh_aligned16(p) && (ld) % 8 == 0 && (ld) >= (C), name ": slice null/unaligned (ld=%d C=%d)", (int)(ld), (int)(C))
+
+extern "C" int yh_bn_silu_apply(const yh_bf16* y, int ldy, const float* ws, int C, int64_t M,
+                                yh_bf16* out, int ldo, const yh_bf16* res, int ldr, yh_stream stream)
+{
+    YH_CHECK_ARG(C > 0 && C % 8 == 0 && M > 0 && ws && yh_aligned16(ws), "yh_bn_silu_apply: bad C/M/ws");
+    YH_CHECK_SLICE("yh_bn_silu_apply", y, ldy, C);
+    YH_CHECK_SLICE("yh_bn_silu_apply", out, ldo, C);
+    if (res) YH_CHECK_SLICE("yh_bn_silu_apply", res, ldr, C);
+    int cpr = C / 8;
+    long nch = (long)M * cpr;
+    hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       y, ldy, ws, C, cpr, nch, out, ldo, res, ldr);
+    YH_CHECK_LAUNCH("yh_bn_silu_apply");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_silu_bwd_reduce(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy,
+                                     const float* ws, int C, int64_t M, float* part, yh_stream stream)
+{
+    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && ws && part, "yh_bn_silu_bwd_reduce: bad args");
+    YH_CHECK_SLICE("yh_bn_silu_bwd_reduce", ga, ldga, C);
+    YH_CHECK_SLICE("yh_bn_silu_bwd_reduce", y, ldy, C);
+    int nblk = yh_ew_blocks(M);
+    long rpb = (M + nblk - 1) / nblk;
+    hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       ga, ldga, y, ldy, ws, C, C / 8, (long)M, rpb, part);
+    YH_CHECK_LAUNCH("yh_bn_silu_bwd_reduce");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M,
+                                  float* dgamma, float* dbeta, float* coef, yh_stream stream)
+{
+    YH_CHECK_ARG(part && nblk > 0 && C > 0 && M > 0, "yh_bn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       part, nblk, C, (double)M, dgamma, dbeta, coef);
+    YH_CHECK_LAUNCH("yh_bn_bwd_finalize");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy,
+                                    const float* ws, const float* gamma, const float* coef,
+                                    int C, int64_t M, yh_bf16* gy, int ldgy,
+                                    yh_bf16* gres, int ldgres, int gres_accumulate, yh_stream stream)
+{
+    YH_CHECK_ARG(C > 0 && C % 8 == 0 && M > 0 && ws && gamma && coef, "yh_bn_silu_bwd_apply: bad args");
+    YH_CHECK_SLICE("yh_bn_silu_bwd_apply", ga, ldga, C);
+    YH_CHECK_SLICE("yh_bn_silu_bwd_apply", y, ldy, C);
+    YH_CHECK_SLICE("yh_bn_silu_bwd_apply", gy, ldgy, C);
+    if (gres) YH_CHECK_SLICE("yh_bn_silu_bwd_apply", gres, ldgres, C);
+    int cpr = C / 8;
+    long nch = (long)M * cpr;
+    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       ga, ldga, y, ldy, ws, gamma, coef, C, cpr, nch, gy, ldgy, gres, ldgres, gres_accumulate);
+    YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply");
+    return YH_OK;
+}
+
+extern "C" int yh_colsum(const yh_bf16* g, int ldg, int C, int64_t M, float* part, float* out, yh_stream stream)
+{
+    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && part && out, "yh_colsum: bad args");
+    YH_CHECK_SLICE("yh_colsum", g, ldg, C);
+    int nblk = yh_ew_blocks(M);
+    long rpb = (M + nblk - 1) / nblk;
+    hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       g, ldg, (const uint16_t*)nullptr, 0, (const float*)nullptr, C, C / 8, (long)M, rpb, part);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, part, nblk, C, out);
+    YH_CHECK_LAUNCH("yh_colsum");
+    return YH_OK;
+}
+
+extern "C" int yh_maxpool5_fwd(const yh_bf16* x, int ldx, int B, int H, int W, int C,
+                               yh_bf16* out, int ldo, int8_t* idx, yh_stream stream)
+{
+    YH_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "yh_maxpool5_fwd: bad dims");
+    YH_CHECK_SLICE("yh_maxpool5_fwd", x, ldx, C);
+    YH_CHECK_SLICE("yh_maxpool5_fwd", out, ldo, C);
+    if (idx) YH_CHECK_ARG((((uintptr_t)idx) & 7) == 0, "yh_maxpool5_fwd: idx unaligned");
+    long n = (long)B * H * W * (C / 8);
+    hipLaunchKernelGGL(maxpool5_fwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, ldx, B, H, W, C / 8, out, ldo, idx);
+    YH_CHECK_LAUNCH("yh_maxpool5_fwd");
+    return YH_OK;
+}
+
+extern "C" int yh_maxpool5_bwd(const yh_bf16* gout, int ldgo, const int8_t* idx, int B, int H, int W, int C,
+                               yh_bf16* gin, int ldgi, int accumulate, yh_stream stream)
+{
+    YH_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && idx, "yh_maxpool5_bwd: bad dims");
+    YH_CHECK_SLICE("yh_maxpool5_bwd", gout, ldgo, C);
+    YH_CHECK_SLICE("yh_maxpool5_bwd", gin, ldgi, C);
+    long n = (long)B * H * W * (C / 8);
+    hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, gout, ldgo, idx, B, H, W, C / 8, gin, ldgi, accumulate);
+    YH_CHECK_LAUNCH("yh_maxpool5_bwd");
+    return YH_OK;
+}
+
+extern "C" int yh_upsample2_bwd(const yh_bf16* ghi, int ldh, int B, int Hlo, int Wlo, int C,
+                                yh_bf16* glo, int ldl, int accumulate, yh_stream stream)
+{
+    YH_CHECK_ARG(B > 0 && Hlo > 0 && Wlo > 0 && C > 0 && C % 8 == 0, "yh_upsample2_bwd: bad dims");
+    YH_CHECK_SLICE("yh_upsample2_bwd", ghi, ldh, C);
+    YH_CHECK_SLICE("yh_upsample2_bwd", glo, ldl, C);
+    long n = (long)B * Hlo * Wlo * (C / 8);
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, ghi, ldh, B, Hlo, Wlo, C / 8, glo, ldl, accumulate);
+    YH_CHECK_LAUNCH("yh_upsample2_bwd");
+    return YH_OK;
+}
+
+extern "C" int yh_input_s2d(const float* x, int B, int Cin, int H, int W, yh_bf16* out, yh_stream stream)
+{
+    YH_CHECK_ARG(x && out && B > 0 && Cin > 0 && Cin <= 4 && H % 2 == 0 && W % 2 == 0, "yh_input_s2d: bad dims (Cin<=4, even H/W)");
+    YH_CHECK_ARG((((uintptr_t)x) & 7) == 0 && yh_aligned16(out), "yh_input_s2d: unaligned pointers");
+    long n = (long)B * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(input_s2d_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, B, Cin, H, W, out);
+    YH_CHECK_LAUNCH("yh_input_s2d");
+    return YH_OK;
+}
+
+extern "C" int yh_fill_u32(void* p, uint32_t v, int64_t n_words, yh_stream stream)
+{
+    YH_CHECK_ARG(p && n_words >= 0 && (((uintptr_t)p) & 3) == 0, "yh_fill_u32: bad args");
+    if (n_words == 0) return YH_OK;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(ew_grid(n_words)), dim3(EW_THREADS), 0, (hipStream_t)stream, (uint32_t*)p, v, (long)n_words);
+    YH_CHECK_LAUNCH("yh_fill_u32");
+    return YH_OK;
+}
