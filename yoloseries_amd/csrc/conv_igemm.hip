@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
                     if (d.act == YH_ACT_SILU) v = siluf_(v);
                     uint16_t hb16 = f2bf(v);
                     sC[row * CP + c] = hb16;
-                    float vr = bf2f(hb16);
+                    float vr = (m0 + row < p.M) ? bf2f(hb16) : 0.f;   // rows past M carry only the bias
                     s += vr; q += vr * vr;
                 }
             }
