@@ -210,12 +210,12 @@ size_t yh_v5loss_ws_bytes(const yh_v5loss_desc* d);
 int yh_v5_assign(const yh_v5loss_desc* d, const float* targets,
                  int32_t* count, float* tbox, int32_t* tidx, void* ws, yh_stream stream);
 /* Forward loss. preds[s]: [B][H][W][ldp] with channel a*(5+nc)+e.
- * balances: [num_stage] fp32 device state, updated in place.
+ * balances: [num_stage] fp64 device state (python floats in the reference), updated in place.
  * result (fp32[8]): tot, iou, cof, cls, tar_nums, 0,0,0  (iou/cof/cls already x B)
  * saved: opaque per-call state for the backward, yh_v5loss_saved_bytes()         */
 size_t yh_v5loss_saved_bytes(const yh_v5loss_desc* d);
 int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds, const float* targets,
-                   float* balances, float* result, void* saved, void* ws, yh_stream stream);
+                   double* balances, float* result, void* saved, void* ws, yh_stream stream);
 /* Backward: gpreds[s] same geometry/dtype as preds[s], fully overwritten.
  * gout: device pointer to d(loss)/d(tot) scalar.                                 */
 int yh_v5_loss_bwd(const yh_v5loss_desc* d, const void* const* preds, const float* gout,

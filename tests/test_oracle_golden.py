@@ -1,0 +1,113 @@
+"""CPU: the oracle (oracle/*.py) against the golden vectors generated from the reference
+(tools/gen_golden.py).  Integer/index outputs must be bit-exact; float outputs of pure
++,-,*,/ chains must be bit-exact too; transcendental chains (sigmoid/atan/exp) within 1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bbox, postproc, v5loss
+from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_head_outputs, synth_targets
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_g1_boxes():
+    g = load("g1_boxes.npz")
+    b1, b2 = g["b1"], g["b2"]
+    np.testing.assert_array_equal(bbox.gpu_iou(b1[:96], b2[:80]), g["iou_mat"])
+    np.testing.assert_array_equal(bbox.numba_iou(b1[480:], b2[470:]), g["numba_iou_mat"])   # NaN == NaN positions too
+    np.testing.assert_array_equal(bbox.gpu_giou(b1, b2), g["giou"])
+    np.testing.assert_array_equal(bbox.gpu_diou(b1, b2), g["diou"])
+    np.testing.assert_allclose(bbox.gpu_ciou(b1, b2), g["ciou"], rtol=0, atol=2e-6)     # atan: libm vs torch
+    np.testing.assert_array_equal(bbox.xyxy2xywh(b2), g["xyxy2xywh"])
+    np.testing.assert_array_equal(bbox.xywh2xyxy(b2), g["xywh2xyxy"])
+    np.testing.assert_array_equal(bbox.xyxy2xywhn(b2, [640, 640]), g["xyxy2xywhn"])
+    # torch restatement of CIoU and its gradient
+    t1 = torch.from_numpy(b1).requires_grad_(True)
+    c = v5loss._ciou_t(t1, torch.from_numpy(b2))
+    (gr,) = torch.autograd.grad(c.sum(), t1)
+    np.testing.assert_allclose(c.detach().numpy(), g["ciou"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(gr.numpy(), g["ciou_grad_b1"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("key", ["hand", "synth"])
+def test_g2_match(key):
+    g = load("g2_match.npz")
+    if key == "hand":
+        targets = g["targets"]
+    else:
+        b, img, nc, mb, seed = g["synth_args"]
+        targets = synth_targets(int(b), int(img), int(nc), int(mb), seed=int(seed))
+    for s, fm in enumerate((80, 40, 20)):
+        tbox, cls, img_i, anc, gy, gx = v5loss.match(targets, COCO_ANCHORS[s], fm, fm, [640, 640], 4.0)
+        assert len(tbox) == len(g[f"{key}_s{s}_tbox"]) and len(tbox) > 0
+        for name, val in (("cls", cls), ("img", img_i), ("anc", anc), ("gy", gy), ("gx", gx)):
+            np.testing.assert_array_equal(val, g[f"{key}_s{s}_{name}"])
+        np.testing.assert_array_equal(tbox, g[f"{key}_s{s}_tbox"])
+
+
+def _hyp(img, focal, nc=80):
+    return dict(device="cpu", num_class=nc, input_img_size=[img, img], use_focal_loss=focal, focal_loss_gamma=1.5,
+                focal_loss_alpha=0.25, iou_loss_scale=0.05, cls_loss_scale=0.5, cof_loss_scale=1.0, anchor_match_thr=4.0,
+                class_smooth_factor=1.0, cls_pos_weight=1.0, cof_pos_weight=1.0)
+
+
+@pytest.mark.parametrize("key", ["small_focal", "small_plain", "big_focal"])
+def test_g3_loss(key):
+    g = load("g3_loss.npz")
+    img, batch, focal, seed_t, seed_p, ncalls, pscale = g[f"{key}_args"]
+    img, batch, ncalls = int(img), int(batch), int(ncalls)
+    lf = v5loss.V5LossOracle(COCO_ANCHORS, _hyp(img, bool(focal)))
+    for call in range(ncalls):
+        t = synth_targets(batch, img, 80, 6 if img < 640 else 20, seed=int(seed_t) + call)
+        heads = synth_head_outputs(batch, img, 80, 3, seed=int(seed_p) + call, scale=float(pscale))
+        preds = [torch.from_numpy(h).requires_grad_(True) for h in heads]
+        out = lf(preds, t)
+        vals = g[f"{key}_c{call}_vals"]
+        got = np.array([out["tot_loss"].item(), out["iou_loss"], out["cof_loss"], out["cls_loss"], out["tar_nums"]])
+        np.testing.assert_allclose(got, vals, rtol=2e-6, atol=1e-7)
+        assert got[4] == vals[4]
+        np.testing.assert_allclose(lf.balances, g[f"{key}_c{call}_balances"], rtol=1e-7)
+        grads = torch.autograd.grad(out["tot_loss"], preds)
+        for s, gr in enumerate(grads):
+            if f"{key}_c{call}_grad{s}" in g:
+                np.testing.assert_allclose(gr.numpy(), g[f"{key}_c{call}_grad{s}"], rtol=1e-4, atol=1e-8)
+            else:
+                flat = gr.numpy().reshape(-1)
+                np.testing.assert_allclose(flat[g[f"{key}_c{call}_gidx{s}"]], g[f"{key}_c{call}_gval{s}"], rtol=1e-4, atol=1e-9)
+                np.testing.assert_allclose([flat.astype(np.float64).sum(), np.abs(flat.astype(np.float64)).sum()],
+                                           g[f"{key}_c{call}_gsum{s}"], rtol=1e-5)
+
+
+def test_g4_decode():
+    g = load("g4_decode.npz")
+    b, img, nc, a, seed, scale = g["args"]
+    heads = synth_head_outputs(int(b), int(img), int(nc), int(a), seed=int(seed), scale=float(scale))
+    dec = postproc.decode_v5(heads, COCO_ANCHORS, (8, 16, 32))
+    np.testing.assert_allclose(dec, g["decoded"], rtol=2e-5, atol=1e-5)   # sigmoid: numpy vs torch CPU, contract is 1e-4
+
+
+@pytest.mark.parametrize("key", ["std", "metric", "nonagn", "nopost", "cap", "tie", "zero", "empty"])
+def test_g5_nms(key):
+    g = load("g5_nms.npz")
+    dec = g[f"{key}_dec"]
+    metric, agn, post, maxp = (int(v) for v in g[f"{key}_cfg"])
+    conf, cls_t, iou_t = (0.001, 0.001, 0.65) if metric else (0.3, 0.3, 0.2)
+    outs = postproc.postprocess_v5(dec, conf, cls_t, iou_t, class_aware=bool(agn), max_keep=maxp, merge_filter=bool(post))
+    ns = g[f"{key}_n"]
+    assert [(-1 if o is None else len(o)) for o in outs] == list(ns)
+    for i, o in enumerate(outs):
+        if o is not None:
+            np.testing.assert_array_equal(o, g[f"{key}_out{i}"])     # same rows in the same (pick) order, bit-exact
+
+
+def test_g5_numba_nms_function():
+    g = load("g5_nms.npz")
+    keep = postproc.numba_nms(g["fn_boxes"], g["fn_scores"], 0.45)
+    np.testing.assert_array_equal(np.array(keep), g["fn_numba_keep_0.45"])

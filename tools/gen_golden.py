@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only where /root/reference exists (the build container); never on the GPU box.
+The reference is imported read-only with stub modules for absent third-party
+packages (numba -> identity decorator, loguru/cv2/emoji/seaborn -> no-ops), exactly
+as SURVEY.md §8(c) describes.  Only inputs/outputs (data) are written — no reference
+source.  Inputs that are large are described by RandomState seeds
+(yoloseries_amd/utils/synth.py) instead of being stored.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def install_shims():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    ident = lambda f=None, *a, **k: (f if callable(f) else (lambda g: g))  # noqa: E731
+    stub("numba", njit=ident, jit=ident)
+
+    class _L:
+        def __getattr__(self, n):
+            if n == "catch":
+                return ident
+            return lambda *a, **k: None
+    stub("loguru", logger=_L())
+
+    class _Sink(types.ModuleType):
+        def __getattr__(self, n):
+            if n.startswith("__"):
+                raise AttributeError(n)
+            return _Sink(n)
+
+        def __call__(self, *a, **k):
+            return None
+    sys.modules["cv2"] = _Sink("cv2")
+    stub("emoji", emojize=lambda s, *a, **k: s)
+    stub("seaborn")
+
+
+def make_hyp(num_class=80, img=640, focal=True, **kw):
+    hyp = dict(device="cpu", num_class=num_class, input_img_size=[img, img],
+               use_focal_loss=focal, focal_loss_gamma=1.5, focal_loss_alpha=0.25,
+               iou_loss_scale=0.05, cls_loss_scale=0.5, cof_loss_scale=1.0, anchor_match_thr=4.0,
+               class_smooth_factor=1.0, cls_pos_weight=1.0, cof_pos_weight=1.0,
+               iou_threshold=0.2, conf_threshold=0.3, cls_threshold=0.3, max_predictions_per_img=300,
+               iou_type="iou", mutil_label=False, agnostic=True, postprocess_bbox=True, wfb=False,
+               use_tta=False, half=False,
+               compute_metric_conf_threshold=0.001, compute_metric_iou_threshold=0.65,
+               compute_metric_cls_threshold=0.001)
+    hyp.update(kw)
+    return hyp
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("tools/gen_golden.py needs /root/reference (build container only)")
+    sys.dont_write_bytecode = True
+    install_shims()
+    sys.path.insert(0, REF)
+    sys.path.insert(1, ROOT)
+    import torch
+    import loss as ref_loss
+    import models as ref_models
+    import trainer as ref_trainer
+    import utils as ref_utils
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_head_outputs, synth_targets
+
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    anchors_t = torch.from_numpy(COCO_ANCHORS.copy())
+
+    # ------------------------------------------------------------------ G1 boxes
+    rs = np.random.RandomState(101)
+
+    def rand_boxes(n, lo=0, hi=100):
+        c = rs.uniform(lo, hi, (n, 2)); wh = np.exp(rs.uniform(np.log(1), np.log(60), (n, 2)))
+        return np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    b1 = rand_boxes(512); b2 = rand_boxes(512)
+    b2[:64] = b1[:64] + rs.uniform(-2, 2, (64, 4)).astype(np.float32)        # strongly overlapping pairs
+    b2[:64, 2:] = np.maximum(b2[:64, 2:], b2[:64, :2] + 0.5)
+    deg1 = np.array([[0, 0, 10, 10], [0, 0, 10, 10], [5, 5, 5, 5], [0, 0, 1, 1], [0, 0, 4, 8], [3, 3, 9, 9], [0, 0, 10, 10], [2, 2, 4, 4]] * 4, np.float32)
+    deg2 = np.array([[0, 0, 10, 10], [20, 20, 30, 30], [5, 5, 5, 5], [1, 1, 2, 2], [0, 0, 8, 4], [3, 3, 9, 9], [10, 0, 20, 10], [0, 0, 10, 10]] * 4, np.float32)
+    p1 = np.concatenate([b1, deg1]); p2 = np.concatenate([b2, deg2])
+    t1 = torch.from_numpy(p1).requires_grad_(True); t2 = torch.from_numpy(p2)
+    ciou = ref_utils.gpu_CIoU(t1, t2)
+    (gc,) = torch.autograd.grad(ciou.sum(), t1)
+    np.savez_compressed(os.path.join(OUT, "g1_boxes.npz"), b1=p1, b2=p2,
+                        ciou=ciou.detach().numpy(), ciou_grad_b1=gc.numpy(),
+                        giou=ref_utils.gpu_Giou(t1.detach(), t2).numpy(), diou=ref_utils.gpu_DIoU(t1.detach(), t2).numpy(),
+                        iou_mat=ref_utils.gpu_iou(t1.detach()[:96], t2[:80]).numpy(),
+                        numba_iou_mat=ref_utils.numba_iou(p1[480:], p2[470:]),
+                        xyxy2xywh=ref_utils.xyxy2xywh(t2).numpy(), xywh2xyxy=ref_utils.xywh2xyxy(t2).numpy(),
+                        xyxy2xywhn=ref_utils.xyxy2xywhn(t2, [640, 640]).numpy())
+
+    # ------------------------------------------------------------------ G2 match
+    hyp = make_hyp()
+    lf = ref_loss.YOLOV5Loss(anchors_t, hyp)
+    B, MB = 4, 12
+    tg = -np.ones((B, MB, 6), np.float32)
+    hand = [  # xmin ymin xmax ymax : borders, cell boundaries (multiples of 8/16/32), edges of the image
+        [0, 0, 64, 64], [100, 120, 164, 200], [8, 8, 24, 24], [16, 16, 48, 80], [320, 320, 352, 352],
+        [600, 600, 640, 640], [0, 300, 30, 420], [255.5, 127.5, 287.5, 159.5], [4, 4, 12, 12],
+        [630, 10, 640, 30], [300, 0, 420, 20], [63.9, 63.9, 192.1, 192.1]]
+    rs = np.random.RandomState(7)
+    for b in range(B):
+        n = [12, 7, 1, 0][b]
+        for j in range(n):
+            box = hand[(j + 3 * b) % len(hand)] if (j % 2 == 0) else None
+            if box is None:
+                c = rs.uniform(20, 620, 2); wh = np.exp(rs.uniform(np.log(6), np.log(400), 2))
+                box = [max(c[0] - wh[0] / 2, 0), max(c[1] - wh[1] / 2, 0), min(c[0] + wh[0] / 2, 640), min(c[1] + wh[1] / 2, 640)]
+            tg[b, j, :4] = box; tg[b, j, 4] = rs.randint(80); tg[b, j, 5] = b
+    g2 = {"targets": tg}
+
+    def run_match(targets_np, key):
+        t = torch.from_numpy(targets_np.copy())
+        bsz, mb = t.shape[:2]
+        tt = t.clone()
+        tt[..., :4] = ref_utils.xyxy2xywhn(tt[..., :4], hyp["input_img_size"])
+        tt = tt.repeat(3, 1, 1, 1).contiguous()
+        aid = torch.arange(3, dtype=torch.float32).reshape(-1, 1)[:, None, None, :].repeat(1, bsz, mb, 1)
+        tt = torch.cat([tt, aid], -1).contiguous()
+        for i, fm in enumerate((80, 40, 20)):
+            ds = 640 / torch.tensor(fm)
+            outs = lf.match(tt, anchors_t[i] / ds, (torch.tensor(fm), torch.tensor(fm)))
+            for name, o in zip(("tbox", "cls", "img", "anc", "gy", "gx"), outs):
+                g2[f"{key}_s{i}_{name}"] = o.numpy()
+    run_match(tg, "hand")
+    g2["synth_args"] = np.array([8, 640, 80, 20, 11])      # batch, img, nc, max_boxes, seed
+    run_match(synth_targets(8, 640, 80, 20, seed=11), "synth")
+    np.savez_compressed(os.path.join(OUT, "g2_match.npz"), **g2)
+
+    # ------------------------------------------------------------------ G3 loss
+    g3 = {}
+
+    def run_loss(key, img, batch, focal, seed_t, seed_p, ncalls=1, store_full=True, pscale=1.0):
+        hyp3 = make_hyp(img=img, focal=focal)
+        lossf = ref_loss.YOLOV5Loss(anchors_t, hyp3)
+        g3[f"{key}_args"] = np.array([img, batch, int(focal), seed_t, seed_p, ncalls, pscale], np.float64)
+        for call in range(ncalls):
+            tnp = synth_targets(batch, img, 80, 6 if img < 640 else 20, seed=seed_t + call)
+            heads = synth_head_outputs(batch, img, 80, 3, seed=seed_p + call, scale=pscale)
+            preds = [torch.from_numpy(h).requires_grad_(True) for h in heads]
+            out = lossf(preds, torch.from_numpy(tnp))
+            grads = torch.autograd.grad(out["tot_loss"], preds)
+            g3[f"{key}_c{call}_vals"] = np.array([out["tot_loss"].item(), out["iou_loss"], out["cof_loss"], out["cls_loss"], out["tar_nums"]], np.float64)
+            g3[f"{key}_c{call}_balances"] = np.array(lossf.balances, np.float64)
+            for s, g in enumerate(grads):
+                gn = g.numpy()
+                if store_full:
+                    g3[f"{key}_c{call}_grad{s}"] = gn
+                else:
+                    flat = gn.reshape(-1)
+                    rsx = np.random.RandomState(1000 + s)
+                    idx = np.unique(np.concatenate([rsx.randint(0, flat.size, 4096), np.argsort(-np.abs(flat))[:512]]))
+                    g3[f"{key}_c{call}_gidx{s}"] = idx.astype(np.int64)
+                    g3[f"{key}_c{call}_gval{s}"] = flat[idx]
+                    g3[f"{key}_c{call}_gsum{s}"] = np.array([flat.astype(np.float64).sum(), np.abs(flat.astype(np.float64)).sum()])
+    run_loss("small_focal", 64, 2, True, 21, 31, ncalls=2)
+    run_loss("small_plain", 64, 2, False, 22, 32, ncalls=1)
+    run_loss("big_focal", 640, 2, True, 23, 33, ncalls=1, store_full=False)
+    np.savez_compressed(os.path.join(OUT, "g3_loss.npz"), **g3)
+
+    # ------------------------------------------------------------------ G4 decode
+    hyp4 = make_hyp(img=64)
+    heads = synth_head_outputs(2, 64, 80, 3, seed=41, scale=2.0)
+
+    class StubYolo:
+        def __call__(self, x):
+            return [torch.from_numpy(h) for h in heads]
+    ev = ref_trainer.YOLOV5Evaluator(StubYolo(), anchors_t, hyp4)
+    dec = ev.do_inference(torch.zeros(2, 3, 64, 64))
+    np.savez_compressed(os.path.join(OUT, "g4_decode.npz"), args=np.array([2, 64, 80, 3, 41, 2.0]), decoded=dec.numpy())
+
+    # ------------------------------------------------------------------ G5 NMS
+    g5 = {}
+    nc5 = 4
+
+    def clustered_decoded(seed, nimg, nclust, per, img=320, jitter=6.0, conf_lo=0.05, tie=False, zero_area=False):
+        r = np.random.RandomState(seed)
+        out = np.zeros((nimg, nclust * per + 40, 5 + nc5), np.float32)
+        for b in range(nimg):
+            rows = []
+            for k in range(nclust):
+                c = r.uniform(30, img - 30, 2); wh = r.uniform(20, 90, 2); cl = r.randint(nc5)
+                for _ in range(per):
+                    cc = c + r.uniform(-jitter, jitter, 2); ww = wh * r.uniform(0.8, 1.25, 2)
+                    if tie:
+                        cc = np.round(cc / 4) * 4; ww = np.round(ww / 8) * 8 + 8
+                    cls = r.uniform(0.0, 0.2, nc5); cls[cl] = r.uniform(0.5, 1.0)
+                    rows.append(np.concatenate([cc, ww, [r.uniform(conf_lo, 1.0)], cls]))
+            for _ in range(40):   # background rows, mostly below conf thresholds
+                rows.append(np.concatenate([r.uniform(0, img, 2), r.uniform(5, 50, 2), [r.uniform(0, 0.02)], r.uniform(0, 0.3, nc5)]))
+            arr = np.array(rows, np.float32)
+            if tie:   # exact score ties: quantise conf and class scores
+                arr[:, 4] = np.round(arr[:, 4] * 8) / 8
+                arr[:, 5:] = np.round(arr[:, 5:] * 8) / 8
+            if zero_area:
+                arr[::7, 2] = 0.0          # zero-width boxes -> 0/0 IoU with themselves
+            out[b] = arr[r.permutation(len(arr))]
+        return out
+
+    def run_nms(key, dec, compute_metric, agnostic, post, max_pred=300):
+        h = make_hyp(num_class=nc5, img=320, agnostic=agnostic, postprocess_bbox=post, max_predictions_per_img=max_pred)
+        e = ref_trainer.YOLOV5Evaluator(None, anchors_t, h, compute_metric=compute_metric)
+        res = e.numba_nms(torch.from_numpy(dec.copy()))
+        g5[f"{key}_dec"] = dec
+        g5[f"{key}_cfg"] = np.array([int(compute_metric), int(agnostic), int(post), max_pred])
+        g5[f"{key}_n"] = np.array([-1 if r is None else len(r) for r in res])
+        for i, r in enumerate(res):
+            if r is not None:
+                g5[f"{key}_out{i}"] = np.asarray(r, np.float32)
+    run_nms("std", clustered_decoded(51, 3, 12, 10), False, True, True)
+    run_nms("metric", clustered_decoded(52, 2, 10, 12, conf_lo=0.0005), True, True, True)
+    run_nms("nonagn", clustered_decoded(53, 2, 10, 10), False, False, True)
+    run_nms("nopost", clustered_decoded(54, 2, 10, 10), False, True, False)
+    run_nms("cap", clustered_decoded(55, 1, 120, 4, jitter=1.0), True, True, False, max_pred=50)
+    run_nms("tie", clustered_decoded(56, 2, 8, 12, tie=True), False, True, True)
+    run_nms("zero", clustered_decoded(57, 2, 8, 8, zero_area=True), False, True, True)
+    empty = clustered_decoded(58, 2, 4, 4); empty[0, :, 4] = 0.0
+    run_nms("empty", empty, False, True, True)
+    # function-level numba_nms / gpu_nms
+    r = np.random.RandomState(59)
+    fb = rand_boxes(300, 0, 200); fs = r.uniform(0, 1, 300).astype(np.float32); fs[::11] = 0.0
+    g5["fn_boxes"], g5["fn_scores"] = fb, fs
+    g5["fn_numba_keep_0.45"] = np.array(ref_utils.numba_nms(fb, fs, 0.45))
+    # utils.gpu_nms (utils/nms.py:30-65) raises IndexError for M > 1 in the reference (mask of shape
+    # (1,M) indexes a 1-D score tensor, :62-63), so it has no golden vector; see DESIGN.md.
+    np.savez_compressed(os.path.join(OUT, "g5_nms.npz"), **g5)
+
+    # ------------------------------------------------------------------ G6 blocks + G8 fuse
+    g6 = {}
+
+    def fill_state(mod, seed):
+        r = np.random.RandomState(seed)
+        sd = mod.state_dict()
+        for k2, v in sd.items():
+            if k2.endswith("num_batches_tracked"):
+                continue
+            shape = tuple(v.shape)
+            if k2.endswith("running_var"):
+                a = r.uniform(0.5, 1.5, shape)
+            elif k2.endswith("bn.weight"):
+                a = r.uniform(0.7, 1.3, shape)
+            elif k2.endswith(("running_mean", "bn.bias", ".bias")):
+                a = r.randn(*shape) * 0.2
+            else:
+                fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+                a = r.randn(*shape) / np.sqrt(fan_in)
+            sd[k2] = torch.from_numpy(a.astype(np.float32))
+        mod.load_state_dict(sd)
+
+    def run_block(key, mod, cin, seed, hw=8, multi=False):
+        fill_state(mod, seed)
+        r = np.random.RandomState(seed + 1)
+        x = (r.randn(2, cin, hw, hw)).astype(np.float32)
+        g6[f"{key}_args"] = np.array([seed, cin, hw])
+        mod.eval()
+        with torch.no_grad():
+            g6[f"{key}_eval"] = mod(torch.from_numpy(x.copy())).numpy()
+        mod.train()
+        xt = torch.from_numpy(x.copy()).requires_grad_(True)
+        y = mod(xt)
+        go = torch.from_numpy(r.randn(*y.shape).astype(np.float32))
+        params = [p for p in mod.parameters()]
+        grads = torch.autograd.grad(y, [xt] + params, go)
+        g6[f"{key}_train"] = y.detach().numpy()
+        g6[f"{key}_gout"] = go.numpy()
+        g6[f"{key}_gx"] = grads[0].numpy()
+        for (n, _), g in zip(mod.named_parameters(), grads[1:]):
+            gf = g.double().reshape(-1)     # signature instead of the full tensor keeps the fixture small
+            g6[f"{key}_gp_{n}"] = np.concatenate([[gf.sum().item(), gf.abs().sum().item(), gf.norm().item()], gf[:29].numpy()])
+        for n, b in mod.named_buffers():
+            g6[f"{key}_buf_{n}"] = b.numpy().copy()
+    run_block("cba1x1", ref_utils.ConvBnAct(32, 64, 1, 1), 32, 601)
+    run_block("cba3x3s2", ref_utils.ConvBnAct(32, 64, 3, 2, 1), 32, 602)
+    run_block("cba6x6s2", ref_utils.ConvBnAct(3, 32, 6, 2, 2), 3, 603, hw=16)
+    run_block("bneck", ref_utils.BasicBottleneck(32, 32, True, expand_ratio=1.0), 32, 604)
+    run_block("c3", ref_utils.C3BottleneckCSP(64, 64, shortcut=True, num_block=2), 64, 605)
+    run_block("c3ns", ref_utils.C3BottleneckCSP(128, 64, shortcut=False, num_block=1), 128, 606)
+    run_block("sppf", ref_utils.FastSPP(64, 64), 64, 607)
+    conv = torch.nn.Conv2d(16, 32, 3, 1, 1, bias=False); bn = torch.nn.BatchNorm2d(32, eps=1e-3)
+    cb = ref_utils.ConvBnAct(16, 32, 3, 1, 1); fill_state(cb, 608)
+    fused = ref_utils.fuse_conv_bn(cb.conv, cb.bn)
+    g6["fuse_args"] = np.array([608]); g6["fuse_w"] = fused.weight.detach().numpy(); g6["fuse_b"] = fused.bias.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "g6_blocks.npz"), **g6)
+
+    # ------------------------------------------------------------------ G7 full model (seeded init)
+    g7 = {}
+    for name, cls in (("s", ref_models.YOLOV5Small), ("l", ref_models.YOLOV5Large)):
+        torch.manual_seed(0)
+        m = cls(3, 80)
+        sd = m.state_dict()
+        g7[f"{name}_keys"] = np.array(list(sd.keys()))
+        g7[f"{name}_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        g7[f"{name}_psum"] = np.array([v.double().sum().item() for v in sd.values()])
+        g7[f"{name}_pabs"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+        if name == "s":
+            x = torch.from_numpy(np.random.RandomState(70).rand(2, 3, 64, 64).astype(np.float32))
+            m.eval()
+            with torch.no_grad():
+                outs = m(x)
+            for i, o in enumerate(outs):
+                g7[f"s_eval64_out{i}"] = o.numpy()
+            m.train()
+            outs = m(x)
+            for i, o in enumerate(outs):
+                g7[f"s_train64_out{i}"] = o.detach().numpy()
+            g7["s_train64_rm_focus"] = m.focus.bn.running_mean.numpy().copy()
+            g7["s_train64_rv_focus"] = m.focus.bn.running_var.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g7_model.npz"), **g7)
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden written:", sorted(os.listdir(OUT)), f"{total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,326 @@
+// Inference post-processing on gfx950 (trainer/eval_yolov5.py:182-317, trainer/eval_yolox.py:123-259,
+// utils/nms.py:10-65 of the reference):
+//   decode_full   — sigmoid / grid / anchor decode to the (B, N, 5+nc) tensor do_inference returns.
+//   decode_filter — fused decode + confidence filter + best-class selection; candidates are
+//                   compacted per image IN PREDICTION ORDER (wave ballots + block scan), so the
+//                   whole decoded tensor never leaves the GPU (the reference copies it to the host).
+//   nms_batched   — one workgroup per image: greedy arg-max NMS exactly as numba_nms does it
+//                   (first maximum on ties, class offset added in fp32 before the IoU, inclusive
+//                   threshold, NaN IoU never suppresses), early exit after max_keep picks, then
+//                   the "merge" filter of eval_yolov5.py:306-315.  Wave-level arg-max via shuffles.
+// All comparisons are in fp32 with the reference's operation order (compiled with -ffp-contract=off).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXS = 4;
+
+template <typename T> __device__ __forceinline__ float ldv(const T* p);
+template <> __device__ __forceinline__ float ldv<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldv<uint16_t>(const uint16_t* p) { return bf2f(*p); }
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct DecK {
+    yh_decode_desc d;
+    const void* pred[MAXS];
+    int start[MAXS + 1];      // first prediction index of each stage (per image)
+    int ntot;
+};
+
+// prediction index (within an image) -> stage, anchor, y, x
+__device__ __forceinline__ void locate(const DecK& k, int pi, int& s, int& a, int& y, int& x) {
+    s = 0;
+#pragma unroll
+    for (int i = 1; i < MAXS; ++i) if (i < k.d.num_stage && pi >= k.start[i]) s = i;
+    int r = pi - k.start[s];
+    const int hw = k.d.H[s] * k.d.W[s];
+    a = r / hw; r -= a * hw;
+    y = r / k.d.W[s];
+    x = r - y * k.d.W[s];
+}
+
+template <typename T>
+__device__ __forceinline__ const T* cell_ptr(const DecK& k, int b, int s, int a, int y, int x) {
+    const T* base = reinterpret_cast<const T*>(k.pred[s]);
+    return base + (((size_t)b * k.d.H[s] + y) * k.d.W[s] + x) * k.d.ldp[s] + a * (5 + k.d.num_class);
+}
+
+// box decode: returns center-format box (cx, cy, w, h) in pixels
+template <typename T>
+__device__ __forceinline__ void decode_box(const DecK& k, const T* row, int s, int a, int y, int x, float* box) {
+    const float st = k.d.stride[s];
+    if (k.d.yolox) {          // eval_yolox.py:140-143
+        box[0] = (ldv<T>(row + 0) + (float)x) * st;
+        box[1] = (ldv<T>(row + 1) + (float)y) * st;
+        box[2] = expf(ldv<T>(row + 2)) * st;
+        box[3] = expf(ldv<T>(row + 3)) * st;
+    } else {                  // eval_yolov5.py:203-205
+        const float aw = k.d.anchors[s][a][0] / st, ah = k.d.anchors[s][a][1] / st;
+        box[0] = (sigm(ldv<T>(row + 0)) * 2.f - 0.5f + (float)x) * st;
+        box[1] = (sigm(ldv<T>(row + 1)) * 2.f - 0.5f + (float)y) * st;
+        const float tw = sigm(ldv<T>(row + 2)) * 2.f, th = sigm(ldv<T>(row + 3)) * 2.f;
+        box[2] = tw * tw * aw * st;
+        box[3] = th * th * ah * st;
+    }
+}
+
+template <typename T>
+__global__ void decode_full_kernel(const DecK k, float* __restrict__ out)
+{
+    const int E = 5 + k.d.num_class;
+    const long tot = (long)k.d.B * k.ntot * E;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < tot; id += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(id % E);
+        const long r = id / E;
+        const int pi = (int)(r % k.ntot);
+        const int b = (int)(r / k.ntot);
+        int s, a, y, x;
+        locate(k, pi, s, a, y, x);
+        const T* row = cell_ptr<T>(k, b, s, a, y, x);
+        float v;
+        if (e < 4) {
+            float box[4];
+            decode_box<T>(k, row, s, a, y, x, box);
+            v = box[e];
+        } else {
+            v = sigm(ldv<T>(row + e));
+        }
+        out[id] = v;
+    }
+}
+
+// One workgroup (1024 threads) per image walks the predictions in order.
+template <typename T>
+__global__ __launch_bounds__(1024) void decode_filter_kernel(const DecK k, float conf_thr, float cls_thr,
+                                                             float* __restrict__ cand, int32_t* __restrict__ ncand, int cap)
+{
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nc = k.d.num_class;
+    if (t == 0) base_s = 0;
+    __syncthreads();
+    float* out = cand + (size_t)b * cap * 6;
+    for (int p0 = 0; p0 < k.ntot; p0 += 1024) {
+        const int pi = p0 + t;
+        bool flag = false;
+        float box[4] = {0, 0, 0, 0}, conf = 0.f;
+        int cls = 0;
+        if (pi < k.ntot) {
+            int s, a, y, x;
+            locate(k, pi, s, a, y, x);
+            const T* row = cell_ptr<T>(k, b, s, a, y, x);
+            const float obj = sigm(ldv<T>(row + 4));
+            bool pass = k.d.yolox ? true : (obj >= conf_thr);                 // eval_yolov5.py:266
+            if (pass) {
+                float best = -INFINITY, best_raw = -INFINITY;
+                for (int c = 0; c < nc; ++c) {
+                    const float pc = sigm(ldv<T>(row + 5 + c));
+                    const float sc = pc * obj;                                // x[:, 5:] *= x[:, 4:5]
+                    if (sc > best) { best = sc; cls = c; }                    // first maximum
+                    if (pc > best_raw) best_raw = pc;
+                }
+                if (k.d.yolox) pass = (obj * best_raw) >= conf_thr && best >= cls_thr;   // eval_yolox.py:206-207,227
+                else           pass = best > cls_thr;                                      // eval_yolov5.py:285
+                if (pass) {
+                    float cb[4];
+                    decode_box<T>(k, row, s, a, y, x, cb);
+                    box[0] = cb[0] - cb[2] / 2.f; box[1] = cb[1] - cb[3] / 2.f;           // numba_xywh2xyxy
+                    box[2] = cb[0] + cb[2] / 2.f; box[3] = cb[1] + cb[3] / 2.f;
+                    conf = best;
+                    flag = true;
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(flag);
+        const int within = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { int c = wave_cnt[w]; if (w < wv) before += c; total += c; }
+        const int base = base_s;
+        if (flag) {
+            const int pos = base + before + within;
+            if (pos < cap) {
+                float* o = out + (size_t)pos * 6;
+                o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3]; o[4] = conf; o[5] = (float)cls;
+            }
+        }
+        __syncthreads();
+        if (t == 0) base_s = base + total;
+        __syncthreads();
+    }
+    if (t == 0) ncand[b] = base_s;
+}
+
+// ---------------------------------------------------------------- NMS
+// numba_iou of one pair (utils/bbox_tools.py:12-35): no eps, 0/0 -> NaN
+__device__ __forceinline__ float pair_iou(const float4 a, const float4 b, float union_clamp) {
+    const float a1 = (a.z - a.x) * (a.w - a.y);
+    const float a2 = (b.z - b.x) * (b.w - b.y);
+    const float w = fmaxf(0.f, fminf(a.z, b.z) - fmaxf(a.x, b.x));
+    const float h = fmaxf(0.f, fminf(a.w, b.w) - fmaxf(a.y, b.y));
+    const float inter = w * h;
+    float den = a1 + a2 - inter;
+    if (union_clamp > 0.f) den = fmaxf(den, union_clamp);
+    return inter / den;
+}
+
+__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ cand, const int32_t* __restrict__ ncand, int cap,
+                                                   float iou_thr, int class_aware, int inclusive, int max_keep, int merge_filter,
+                                                   float* __restrict__ out, int32_t* __restrict__ nkeep, int32_t* __restrict__ keep_idx,
+                                                   float* __restrict__ ws)
+{
+    __shared__ float s_val[16];
+    __shared__ int s_idx[16];
+    __shared__ int s_pick;
+    __shared__ float s_pickval;
+    __shared__ int s_flag[512];
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int n = ncand[b];
+    if (n > cap) n = cap;
+    const float* cb = cand + (size_t)b * cap * 6;
+    float* sc = ws + (size_t)b * cap * 5;                 // scores
+    float4* bx = reinterpret_cast<float4*>(sc + cap);     // offset boxes (cap is a multiple of 4)
+    int32_t* kp = keep_idx + (size_t)b * max_keep;
+    const float uclamp = inclusive ? 0.f : 1e-9f;          // gpu_nms uses gpu_iou (union clamp 1e-9)
+
+    for (int i = t; i < n; i += 1024) {
+        const float* r = cb + (size_t)i * 6;
+        const float off = class_aware ? r[5] * 4096.f : r[5] * 0.f;       // eval_yolov5.py:293-298
+        bx[i] = make_float4(r[0] + off, r[1] + off, r[2] + off, r[3] + off);
+        sc[i] = r[4];
+    }
+    __syncthreads();
+
+    int k = 0;
+    while (k < max_keep) {
+        // arg-max with first index on ties
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = t; i < n; i += 1024) { const float v = sc[i]; if (v > bv) { bv = v; bi = i; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[wv] = bv; s_idx[wv] = bi; }
+        __syncthreads();
+        if (t == 0) {
+            float v = s_val[0]; int ix = s_idx[0];
+            for (int w = 1; w < 16; ++w) if (s_val[w] > v || (s_val[w] == v && s_idx[w] < ix)) { v = s_val[w]; ix = s_idx[w]; }
+            s_pick = ix; s_pickval = v;
+        }
+        __syncthreads();
+        const float pv = s_pickval;
+        const int pi = s_pick;
+        if (!(pv > 0.f)) break;                            // `while score_copy.sum() > 0` on non-negative scores
+        if (t == 0) kp[k] = pi;
+        ++k;
+        const float4 pb = bx[pi];
+        for (int i = t; i < n; i += 1024) {
+            const float iou = pair_iou(pb, bx[i], uclamp);
+            const bool sup = inclusive ? (iou >= iou_thr) : (iou > iou_thr);
+            if (sup || i == pi) sc[i] = 0.f;
+        }
+        __syncthreads();
+    }
+
+    // merge filter: keep i iff more than one candidate overlaps it with iou > thr (eval_yolov5.py:306-315)
+    const bool do_merge = merge_filter && n > 1 && n < 3000;
+    if (do_merge) {
+        for (int r0 = 0; r0 < k; r0 += 16) {
+            const int r = r0 + wv;
+            int cnt = 0;
+            if (r < k) {
+                const float4 pb = bx[kp[r]];
+                for (int i = lane; i < n; i += 64) cnt += (pair_iou(pb, bx[i], 0.f) > iou_thr) ? 1 : 0;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            if (lane == 0 && r < k) s_flag[r] = cnt > 1;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int m = 0;
+            for (int r = 0; r < k; ++r) if (s_flag[r]) kp[m++] = kp[r];
+            s_pick = m;
+        }
+        __syncthreads();
+        k = s_pick;
+    }
+    if (t == 0) nkeep[b] = k;
+    __syncthreads();
+    for (int i = t; i < k * 6; i += 1024) {
+        const int r = i / 6, c = i - r * 6;
+        out[((size_t)b * max_keep + r) * 6 + c] = cb[(size_t)kp[r] * 6 + c];
+    }
+}
+
+int fill_deck(const yh_decode_desc* d, const void* const* preds, DecK* k, const char* who) {
+    YH_CHECK_ARG(d && preds, "%s: null desc", who);
+    YH_CHECK_ARG(d->B > 0 && d->num_class >= 1 && d->num_anchor >= 1 && d->num_anchor <= 3 && d->num_stage >= 1 && d->num_stage <= MAXS, "%s: bad dims", who);
+    k->d = *d;
+    int acc = 0;
+    for (int s = 0; s < MAXS; ++s) {
+        k->start[s] = acc;
+        k->pred[s] = nullptr;
+        if (s < d->num_stage) {
+            YH_CHECK_ARG(preds[s] != nullptr && d->H[s] > 0 && d->W[s] > 0 && d->ldp[s] >= d->num_anchor * (5 + d->num_class), "%s: stage %d invalid", who, s);
+            k->pred[s] = preds[s];
+            acc += d->num_anchor * d->H[s] * d->W[s];
+        }
+    }
+    k->start[MAXS] = acc;
+    k->ntot = acc;
+    return YH_OK;
+}
+
+}  // namespace
+
+extern "C" int yh_decode_full(const yh_decode_desc* d, const void* const* preds, float* out, yh_stream stream)
+{
+    DecK k;
+    int rc = fill_deck(d, preds, &k, "yh_decode_full");
+    if (rc) return rc;
+    YH_CHECK_ARG(out != nullptr, "yh_decode_full: null output");
+    long tot = (long)d->B * k.ntot * (5 + d->num_class);
+    int g = (int)((tot + 255) / 256 > 8192 ? 8192 : (tot + 255) / 256);
+    if (d->pred_is_f32) hipLaunchKernelGGL((decode_full_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, k, out);
+    else                hipLaunchKernelGGL((decode_full_kernel<uint16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, k, out);
+    YH_CHECK_LAUNCH("yh_decode_full");
+    return YH_OK;
+}
+
+extern "C" int yh_decode_filter(const yh_decode_desc* d, const void* const* preds, float conf_thr, float cls_thr,
+                                float* cand, int32_t* ncand, int cap, yh_stream stream)
+{
+    DecK k;
+    int rc = fill_deck(d, preds, &k, "yh_decode_filter");
+    if (rc) return rc;
+    YH_CHECK_ARG(cand && ncand && cap > 0 && cap % 4 == 0, "yh_decode_filter: cand/ncand null or cap not a multiple of 4");
+    if (d->pred_is_f32) hipLaunchKernelGGL((decode_filter_kernel<float>), dim3(d->B), dim3(1024), 0, (hipStream_t)stream, k, conf_thr, cls_thr, cand, ncand, cap);
+    else                hipLaunchKernelGGL((decode_filter_kernel<uint16_t>), dim3(d->B), dim3(1024), 0, (hipStream_t)stream, k, conf_thr, cls_thr, cand, ncand, cap);
+    YH_CHECK_LAUNCH("yh_decode_filter");
+    return YH_OK;
+}
+
+extern "C" size_t yh_nms_ws_bytes(int B, int cap) { return (size_t)B * cap * 5 * sizeof(float); }
+
+extern "C" int yh_nms_batched(const float* cand, const int32_t* ncand, int B, int cap,
+                              float iou_thr, int class_aware, int thr_inclusive, int max_keep, int merge_filter,
+                              float* out, int32_t* nkeep, int32_t* keep_idx, void* ws, yh_stream stream)
+{
+    YH_CHECK_ARG(cand && ncand && out && nkeep && keep_idx && ws, "yh_nms_batched: null pointer");
+    YH_CHECK_ARG(B > 0 && cap > 0 && cap % 4 == 0, "yh_nms_batched: cap must be a positive multiple of 4");
+    YH_CHECK_ARG(max_keep > 0 && max_keep <= 512, "yh_nms_batched: max_keep must be in [1,512]");
+    YH_CHECK_ARG(yh_aligned16(ws), "yh_nms_batched: workspace unaligned");
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, cand, ncand, cap, iou_thr, class_aware,
+                       thr_inclusive, max_keep, merge_filter, out, nkeep, keep_idx, (float*)ws);
+    YH_CHECK_LAUNCH("yh_nms_batched");
+    return YH_OK;
+}

@@ -1,0 +1,62 @@
+"""Synthetic COCO-shaped inputs: the same generator feeds bench.py, the
+tests and tools/gen_golden.py, so that fixtures only need to store seeds.
+numpy.random.RandomState streams are frozen across NumPy versions."""
+import numpy as np
+
+COCO_ANCHORS = np.array([[[10, 13], [16, 30], [33, 23]],
+                         [[30, 61], [62, 45], [59, 119]],
+                         [[116, 90], [156, 198], [373, 326]]], dtype=np.float32)
+
+
+def synth_targets(batch, img_size=640, num_class=80, max_boxes=20, seed=1, min_boxes=1):
+    """(B, maxbox, 6) float32 [xmin,ymin,xmax,ymax,cls,img_idx], padded with -1
+    (the collate format of dataset/data_collater.py:20-64)."""
+    rs = np.random.RandomState(seed)
+    counts = rs.randint(min_boxes, max_boxes + 1, size=batch)
+    mb = int(counts.max()) if batch else 0
+    out = -np.ones((batch, max(mb, 1), 6), dtype=np.float32)
+    for b in range(batch):
+        n = counts[b]
+        cx = rs.uniform(0.1, 0.9, n) * img_size
+        cy = rs.uniform(0.1, 0.9, n) * img_size
+        w = np.exp(rs.uniform(np.log(8), np.log(img_size / 2), n))
+        h = np.exp(rs.uniform(np.log(8), np.log(img_size / 2), n))
+        x1 = np.clip(cx - w / 2, 0, img_size); x2 = np.clip(cx + w / 2, 0, img_size)
+        y1 = np.clip(cy - h / 2, 0, img_size); y2 = np.clip(cy + h / 2, 0, img_size)
+        out[b, :n, 0], out[b, :n, 1], out[b, :n, 2], out[b, :n, 3] = x1, y1, x2, y2
+        out[b, :n, 4] = rs.randint(0, num_class, n)
+        out[b, :n, 5] = b
+    return out
+
+
+def synth_head_outputs(batch, img_size=640, num_class=80, num_anchor=3, seed=3, scale=1.0, strides=(8, 16, 32)):
+    """Random raw head tensors in the reference layout: list of (B, A*(5+nc), h, w) float32."""
+    rs = np.random.RandomState(seed)
+    return [(rs.randn(batch, num_anchor * (5 + num_class), img_size // s, img_size // s) * scale).astype(np.float32)
+            for s in strides]
+
+
+def synth_nms_heads(batch, img_size=640, num_class=80, num_anchor=3, seed=2, frac=0.01, clusters=50, strides=(8, 16, 32)):
+    """Head tensors whose decode yields ~`frac` of the anchors above conf 0.001, grouped in
+    overlapping clusters: objectness logits are shifted far negative except on
+    cells near `clusters` random centres; class logits ~N(0,1) with one boosted class."""
+    rs = np.random.RandomState(seed)
+    E = 5 + num_class
+    outs = []
+    centres = rs.uniform(0.1, 0.9, (batch, clusters, 2)) * img_size
+    ccls = rs.randint(0, num_class, (batch, clusters))
+    for s in strides:
+        h = w = img_size // s
+        t = rs.randn(batch, num_anchor, E, h, w).astype(np.float32)
+        t[:, :, 4] -= 12.0
+        n_pick = max(1, int(frac * num_anchor * h * w / clusters))
+        for b in range(batch):
+            for k in range(clusters):
+                gx = int(np.clip(centres[b, k, 0] / s, 0, w - 1)); gy = int(np.clip(centres[b, k, 1] / s, 0, h - 1))
+                for _ in range(n_pick):
+                    a = rs.randint(num_anchor)
+                    yy = int(np.clip(gy + rs.randint(-1, 2), 0, h - 1)); xx = int(np.clip(gx + rs.randint(-1, 2), 0, w - 1))
+                    t[b, a, 4, yy, xx] = rs.uniform(0.0, 4.0)
+                    t[b, a, 5 + ccls[b, k], yy, xx] += 4.0
+        outs.append(t.reshape(batch, num_anchor * E, h, w))
+    return outs
