@@ -197,6 +197,8 @@ typedef struct yh_v5loss_desc {
     float   iou_scale, cof_scale, cls_scale;
     int32_t pred_is_f32;          /* 0: bf16 predictions, 1: fp32                  */
     int32_t ldp[4];               /* elements per cell of each prediction buffer   */
+    int32_t targets_xywhn;        /* 1: targets already hold (cx,cy,w,h)/img size — the argument
+                                     convention of YOLOV5Loss.match (loss/yolov5_loss.py:142)   */
 } yh_v5loss_desc;
 
 /* workspace sizes in bytes */
@@ -245,6 +247,10 @@ int yh_decode_full(const yh_decode_desc* d, const void* const* preds, float* out
  *  conf_ge: obj >= conf_thr ; cls_gt: cls_conf > cls_thr (v5) / obj*max>=conf & cls>=thr (yolox) */
 int yh_decode_filter(const yh_decode_desc* d, const void* const* preds, float conf_thr, float cls_thr,
                      float* cand, int32_t* ncand, int cap, yh_stream stream);
+/* The same filter applied to an already decoded (B, N, 5+nc) fp32 tensor — the argument of
+ * YOLOV5Evaluator.numba_nms (trainer/eval_yolov5.py:261-286); used after TTA merging.      */
+int yh_filter_decoded(const float* dec, int B, int N, int num_class, float conf_thr, float cls_thr, int yolox,
+                      float* cand, int32_t* ncand, int cap, yh_stream stream);
 /* Greedy NMS per image on candidate lists, selection order = reference order.
  *  class_aware: add cls*4096 to the box before IoU (hyp['agnostic'] == True in the reference)
  *  thr_inclusive: 1 -> suppress when iou >= thr (numba_nms), 0 -> iou > thr (gpu_nms)

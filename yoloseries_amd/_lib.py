@@ -60,6 +60,7 @@ class V5LossDesc(C.Structure):
         ("iou_scale", C.c_float), ("cof_scale", C.c_float), ("cls_scale", C.c_float),
         ("pred_is_f32", C.c_int32),
         ("ldp", C.c_int32 * 4),
+        ("targets_xywhn", C.c_int32),
     ]
 
 
@@ -115,6 +116,7 @@ _SIGS = {
     "yh_iou_pairwise": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "yh_decode_full": (_i32, [C.POINTER(DecodeDesc), C.POINTER(_vp), _vp, _vp]),
     "yh_decode_filter": (_i32, [C.POINTER(DecodeDesc), C.POINTER(_vp), _f32, _f32, _vp, _vp, _i32, _vp]),
+    "yh_filter_decoded": (_i32, [_vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "yh_nms_ws_bytes": (_sz, [_i32, _i32]),
     "yh_nms_batched": (_i32, [_vp, _vp, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
 }

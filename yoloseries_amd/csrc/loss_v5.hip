@@ -94,10 +94,14 @@ __global__ __launch_bounds__(1024) void v5_assign_kernel(const LossK p, const fl
             const float* tg = targets + (size_t)r * 6;      // r = b*MB + j
             const float x1 = tg[0], y1 = tg[1], x2 = tg[2], y2 = tg[3];
             // xyxy2xywhn (utils/bbox_tools.py:103-119), then * fm size (:151-153)
-            const float cxn = ((x1 + x2) / 2.0f) / d.img_size0;
-            const float cyn = ((y1 + y2) / 2.0f) / d.img_size1;
-            const float wn = (x2 - x1) / d.img_size0;
-            const float hn = (y2 - y1) / d.img_size1;
+            float cxn, cyn, wn, hn;
+            if (d.targets_xywhn) { cxn = x1; cyn = y1; wn = x2; hn = y2; }
+            else {
+                cxn = ((x1 + x2) / 2.0f) / d.img_size0;
+                cyn = ((y1 + y2) / 2.0f) / d.img_size1;
+                wn = (x2 - x1) / d.img_size0;
+                hn = (y2 - y1) / d.img_size1;
+            }
             gxf = cxn * fw; gyf = cyn * fh; gw = wn * fw; gh = hn * fh;
             const float aw = d.anchors[s][a][0] / ds, ah = d.anchors[s][a][1] / ds;
             const float rw = gw / aw + 1e-16f, rh = gh / ah + 1e-16f;
@@ -206,13 +210,15 @@ __device__ float ciou_fwd_bwd(const float* b1, const float* b2, float* g /*4 or 
     const float ciou = iou - (ctr / cd + v * alpha);
     if (g) {
         // order of unknowns: x1, y1, x2, y2
-        const float diw[4] = {(iwr >= 0.f && x1 > X1) ? -1.f : 0.f, 0.f, (iwr >= 0.f && x2 < X2) ? 1.f : 0.f, 0.f};
-        const float dih[4] = {0.f, (ihr >= 0.f && y1 > Y1) ? -1.f : 0.f, 0.f, (ihr >= 0.f && y2 < Y2) ? 1.f : 0.f};
-        // ties (x1 == X1 etc.) split the gradient in torch; they have measure zero and take the `<` side here
+        // torch.min/max split the gradient evenly on ties (minimum/maximum backward); clamp(min=0) passes at >= 0
+        auto lt = [](float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); };
+        const float pw_ = (iwr >= 0.f) ? 1.f : 0.f, ph_ = (ihr >= 0.f) ? 1.f : 0.f;
+        const float diw[4] = {-pw_ * lt(X1, x1), 0.f, pw_ * lt(x2, X2), 0.f};
+        const float dih[4] = {0.f, -ph_ * lt(Y1, y1), 0.f, ph_ * lt(y2, Y2)};
         const float dw1[4] = {-1.f, 0.f, 1.f, 0.f};
         const float dh1[4] = {0.f, -1.f, 0.f, 1.f};
-        const float dcw[4] = {(x1 < X1) ? -1.f : 0.f, 0.f, (x2 > X2) ? 1.f : 0.f, 0.f};
-        const float dch[4] = {0.f, (y1 < Y1) ? -1.f : 0.f, 0.f, (y2 > Y2) ? 1.f : 0.f};
+        const float dcw[4] = {-lt(x1, X1), 0.f, lt(X2, x2), 0.f};
+        const float dch[4] = {0.f, -lt(y1, Y1), 0.f, lt(Y2, y2)};
         const float dcx[4] = {0.5f, 0.f, 0.5f, 0.f};
         const float dcy[4] = {0.f, 0.5f, 0.f, 0.5f};
         const float du_dw = 1.f / h1c;

@@ -156,6 +156,70 @@ __global__ __launch_bounds__(1024) void decode_filter_kernel(const DecK k, float
     if (t == 0) ncand[b] = base_s;
 }
 
+
+// Candidate filter on an already decoded (B, N, 5+nc) fp32 tensor (the argument of
+// YOLOV5Evaluator.numba_nms, eval_yolov5.py:261-286), order preserving.
+__global__ __launch_bounds__(1024) void filter_decoded_kernel(const float* __restrict__ dec, int N, int nc, float conf_thr,
+                                                              float cls_thr, int yolox, float* __restrict__ cand,
+                                                              int32_t* __restrict__ ncand, int cap)
+{
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int E = 5 + nc;
+    if (t == 0) base_s = 0;
+    __syncthreads();
+    float* out = cand + (size_t)b * cap * 6;
+    for (int p0 = 0; p0 < N; p0 += 1024) {
+        const int pi = p0 + t;
+        bool flag = false;
+        float box[4] = {0, 0, 0, 0}, conf = 0.f;
+        int cls = 0;
+        if (pi < N) {
+            const float* row = dec + ((size_t)b * N + pi) * E;
+            const float obj = row[4];
+            bool pass = yolox ? true : (obj >= conf_thr);
+            if (pass) {
+                float best = -INFINITY, best_raw = -INFINITY;
+                for (int c = 0; c < nc; ++c) {
+                    const float pc = row[5 + c];
+                    const float sc = pc * obj;
+                    if (sc > best) { best = sc; cls = c; }
+                    if (pc > best_raw) best_raw = pc;
+                }
+                if (yolox) pass = (obj * best_raw) >= conf_thr && best >= cls_thr;
+                else       pass = best > cls_thr;
+                if (pass) {
+                    box[0] = row[0] - row[2] / 2.f; box[1] = row[1] - row[3] / 2.f;
+                    box[2] = row[0] + row[2] / 2.f; box[3] = row[1] + row[3] / 2.f;
+                    conf = best;
+                    flag = true;
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(flag);
+        const int within = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { int c = wave_cnt[w]; if (w < wv) before += c; total += c; }
+        const int base = base_s;
+        if (flag) {
+            const int pos = base + before + within;
+            if (pos < cap) {
+                float* o = out + (size_t)pos * 6;
+                o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3]; o[4] = conf; o[5] = (float)cls;
+            }
+        }
+        __syncthreads();
+        if (t == 0) base_s = base + total;
+        __syncthreads();
+    }
+    if (t == 0) ncand[b] = base_s;
+}
+
 // ---------------------------------------------------------------- NMS
 // numba_iou of one pair (utils/bbox_tools.py:12-35): no eps, 0/0 -> NaN
 __device__ __forceinline__ float pair_iou(const float4 a, const float4 b, float union_clamp) {
@@ -309,6 +373,15 @@ extern "C" int yh_decode_filter(const yh_decode_desc* d, const void* const* pred
     return YH_OK;
 }
 
+extern "C" int yh_filter_decoded(const float* dec, int B, int N, int num_class, float conf_thr, float cls_thr, int yolox,
+                                 float* cand, int32_t* ncand, int cap, yh_stream stream)
+{
+    YH_CHECK_ARG(dec && cand && ncand && B > 0 && N > 0 && num_class >= 1 && cap > 0 && cap % 4 == 0, "yh_filter_decoded: bad args");
+    hipLaunchKernelGGL(filter_decoded_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, dec, N, num_class, conf_thr, cls_thr, yolox, cand, ncand, cap);
+    YH_CHECK_LAUNCH("yh_filter_decoded");
+    return YH_OK;
+}
+
 extern "C" size_t yh_nms_ws_bytes(int B, int cap) { return (size_t)B * cap * 5 * sizeof(float); }
 
 extern "C" int yh_nms_batched(const float* cand, const int32_t* ncand, int B, int cap,
@@ -317,7 +390,7 @@ extern "C" int yh_nms_batched(const float* cand, const int32_t* ncand, int B, in
 {
     YH_CHECK_ARG(cand && ncand && out && nkeep && keep_idx && ws, "yh_nms_batched: null pointer");
     YH_CHECK_ARG(B > 0 && cap > 0 && cap % 4 == 0, "yh_nms_batched: cap must be a positive multiple of 4");
-    YH_CHECK_ARG(max_keep > 0 && max_keep <= 512, "yh_nms_batched: max_keep must be in [1,512]");
+    YH_CHECK_ARG(max_keep > 0 && (max_keep <= 512 || !merge_filter), "yh_nms_batched: max_keep must be in [1,512] when merge_filter is set");
     YH_CHECK_ARG(yh_aligned16(ws), "yh_nms_batched: workspace unaligned");
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, cand, ncand, cap, iou_thr, class_aware,
                        thr_inclusive, max_keep, merge_filter, out, nkeep, keep_idx, (float*)ws);
