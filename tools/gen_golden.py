@@ -316,12 +316,20 @@ def main():
                 outs = m(x)
             for i, o in enumerate(outs):
                 g7[f"s_eval64_out{i}"] = o.numpy()
+            # train mode at 256x256 (>= 128 samples per channel for every BatchNorm; at 64x64 the deepest
+            # stage has 8 samples per channel, which makes bf16-vs-fp32 comparisons ill-conditioned)
             m.train()
-            outs = m(x)
+            x2 = torch.from_numpy(np.random.RandomState(71).rand(2, 3, 256, 256).astype(np.float32))
+            outs = m(x2)
             for i, o in enumerate(outs):
-                g7[f"s_train64_out{i}"] = o.detach().numpy()
-            g7["s_train64_rm_focus"] = m.focus.bn.running_mean.numpy().copy()
-            g7["s_train64_rv_focus"] = m.focus.bn.running_var.numpy().copy()
+                flat = o.detach().numpy().reshape(-1)
+                idx = np.random.RandomState(72 + i).randint(0, flat.size, 4096)
+                g7[f"s_train256_idx{i}"] = idx.astype(np.int64)
+                g7[f"s_train256_val{i}"] = flat[idx]
+                g7[f"s_train256_shape{i}"] = np.array(o.shape)
+            g7["s_train256_rm_focus"] = m.focus.bn.running_mean.numpy().copy()
+            g7["s_train256_rv_focus"] = m.focus.bn.running_var.numpy().copy()
+            g7["s_train256_rv_last"] = m.head_stage4_bscp.cba3.bn.running_var.numpy().copy()
     np.savez_compressed(os.path.join(OUT, "g7_model.npz"), **g7)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden written:", sorted(os.listdir(OUT)), f"{total / 1e6:.2f} MB")

@@ -1,0 +1,662 @@
+"""Host-side executor of the YOLO conv graph on the HIP kernels (include/yolohip.h).
+
+A model (or a single block used stand-alone) describes itself once to a ``Builder`` as a
+list of ops over NHWC bf16 buffers:
+
+  ConvOp  — implicit-GEMM conv over a virtual channel-concat of up to two slices (one may be
+            read through a nearest-2x upsample), followed by training-mode BatchNorm + SiLU
+            (stats from the conv epilogue, finalize, apply) or, for Detect, a bias only.
+            Sibling 1x1 convs that read the same input (C3's cba1/cba2,
+            utils/layer_tools.py:165-168) are one GEMM with stacked output channels.
+  PoolOp  — SPPF 5x5/s1 max-pool writing into a channel slice of the concat buffer.
+
+torch.cat / nn.Upsample / x.clone() of the reference are never materialised: concat and
+upsample are addressing modes of the consumer's loader, residuals are fused into the apply.
+``Program`` holds the pre-built kernel descriptors for one input shape and runs
+forward (train / eval) and backward; ``ParamPack`` keeps the fp32 master parameters in one
+flat arena (the nn.Parameters are views of it, so state_dict/optimizers are unchanged) and
+maps them to the packed bf16 weight images and back (packed fp32 grads -> parameter grads)
+with one index-gather launch each.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import hipk
+from ._lib import (ConvDesc, WgradDesc, YH_ACT_NONE, YH_ACT_SILU, YH_CONV_DGRAD, YH_CONV_FWD, YoloHipError, check, lib)
+from .hipk import Slice
+
+BN_EPS_DEFAULT = 1e-3
+
+
+def _rup(x, m):
+    return ((x + m - 1) // m) * m
+
+
+class TBuf:
+    """An NHWC bf16 activation buffer (allocated per Program)."""
+
+    def __init__(self, name, H, W, Cn, needs_grad=True):
+        self.name, self.H, self.W, self.C = name, H, W, Cn
+        self.needs_grad = needs_grad
+        self.t = None       # (B,H,W,C) bf16
+        self.g = None       # gradient buffer, same shape
+        self.ginit = None   # per-channel "gradient already written" flags while planning the backward
+
+
+class Ref:
+    """Channel slice of a TBuf, optionally read through a 2x nearest upsample."""
+
+    def __init__(self, buf, coff=0, Cn=None, ups=0):
+        self.buf, self.coff, self.C, self.ups = buf, coff, (buf.C - coff if Cn is None else Cn), ups
+
+    def sl(self, grad=False):
+        return Slice(self.buf.g if grad else self.buf.t, self.coff, self.C, self.ups)
+
+
+class ConvOp:
+    def __init__(self, name, segs, parts, k, stride, pad, Hi, Wi, kind, outs, res, focus=False):
+        self.name, self.segs, self.parts = name, segs, parts
+        self.k, self.stride, self.pad, self.Hi, self.Wi = k, stride, pad, Hi, Wi
+        self.Ho = (Hi + 2 * pad - k) // stride + 1
+        self.Wo = (Wi + 2 * pad - k) // stride + 1
+        self.kind, self.outs, self.res, self.focus = kind, outs, res, focus
+        self.Ctot = sum(s.C for s in segs)
+        self.Ktot = k * k * self.Ctot
+        self.part_N = [c.out_channels for c, _ in parts]
+        self.N = sum(self.part_N)
+        self.Npad = _rup(self.N, 128)
+        self.y = None            # raw conv output buffer (cba) / head buffer (plain)
+
+
+class PoolOp:
+    def __init__(self, name, src, dst):
+        self.name, self.src, self.dst = name, src, dst
+        self.idx = None
+
+
+class Builder:
+    """Collects buffers and ops for one batch/input shape."""
+
+    def __init__(self):
+        self.bufs, self.ops = [], []
+
+    def buf(self, name, H, W, Cn, needs_grad=True):
+        if Cn % 8:
+            raise YoloHipError(f"{name}: channel count {Cn} must be a multiple of 8 on the HIP path")
+        b = TBuf(name, H, W, Cn, needs_grad)
+        self.bufs.append(b)
+        return b
+
+    def cba(self, name, mods, segs, dsts=None, res=None, focus=False):
+        """ConvBnAct(s) sharing one input; returns the activation Refs (one per module)."""
+        c0 = mods[0].conv
+        k, s = c0.kernel_size[0], c0.stride[0]
+        p = c0.padding[0]
+        Hi, Wi = segs[0].buf.H << segs[0].ups, segs[0].buf.W << segs[0].ups
+        if focus:                      # 6x6/s2/p2 on the image == 3x3/s1/p1 on the space-to-depth tensor
+            k, s, p = 3, 1, 1
+        for m in mods:
+            if m.conv.groups != 1 or m.conv.bias is not None:
+                raise YoloHipError(f"{name}: grouped / biased ConvBnAct is outside the HIP hot path")
+        op = ConvOp(name, segs, [(m.conv, m.bn) for m in mods], k, s, p, Hi, Wi, 'cba', None, res, focus)
+        op.y = self.buf(name + ".y", op.Ho, op.Wo, op.N)
+        if dsts is None:
+            dsts = [Ref(self.buf(name + f".a{i}" if len(mods) > 1 else name + ".a", op.Ho, op.Wo, n)) for i, n in enumerate(op.part_N)]
+        op.outs = dsts
+        self.ops.append(op)
+        return dsts
+
+    def plain(self, name, conv, seg):
+        """Detect 1x1 conv with bias (utils/layer_tools.py:454-470): output buffer padded to ld 256-multiple."""
+        Hi, Wi = seg.buf.H, seg.buf.W
+        op = ConvOp(name, [seg], [(conv, None)], conv.kernel_size[0], conv.stride[0], conv.padding[0], Hi, Wi, 'plain', None, None)
+        op.y = self.buf(name + ".out", op.Ho, op.Wo, _rup(op.N, 8))
+        op.y.is_head = True
+        self.ops.append(op)
+        return op
+
+    def pool(self, name, src, dst):
+        self.ops.append(PoolOp(name, src, dst))
+
+
+# ------------------------------------------------------------------------------------------
+class ParamPack:
+    """Flat fp32 parameter arena + index maps to/from the packed kernel layouts."""
+
+    def __init__(self, module, ops):
+        params = list(module.parameters())
+        if not params:
+            raise YoloHipError("model has no parameters")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise YoloHipError("yoloseries_amd models run on an MI355X device only (no CPU path in the product); call .to('cuda') first")
+        self.device = dev
+        self.params = params
+        if any(p.dtype != torch.float32 for p in params):
+            raise YoloHipError("master parameters must be float32 (bf16 copies are made by the engine)")
+        sizes = [p.numel() for p in params]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.n = int(offs[-1])
+        flat = torch.empty(self.n, dtype=torch.float32, device=dev)
+        for p, o in zip(params, offs[:-1]):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self.flat = flat
+        self.off = {id(p): int(o) for p, o in zip(params, offs[:-1])}
+        self.sig = self._signature()
+
+        pack_idx, self.wloc = [], {}
+        cur = 0
+        gcur = 0
+        unpack = np.full(self.n, -1, dtype=np.int64)
+        self.gloc, self.bn_g, self.bias_g = {}, {}, {}
+
+        def widx(conv):
+            w = conv.weight
+            return self.off[id(w)] + np.arange(w.numel(), dtype=np.int64).reshape(tuple(w.shape))
+
+        for op in ops:
+            if not isinstance(op, ConvOp):
+                continue
+            Wall = np.concatenate([widx(c) for c, _ in op.parts], axis=0)      # [N, I, kh, kw]
+            N = op.N
+            if op.focus:
+                n_, ci, kh6, kw6 = Wall.shape
+                assert kh6 == 6 and kw6 == 6 and 4 * ci <= 16
+                P = np.full((N, 3, 3, 16), -1, dtype=np.int64)
+                for dy in range(2):
+                    for dx in range(2):
+                        for c in range(ci):
+                            P[:, :, :, (dy * 2 + dx) * ci + c] = Wall[:, c, dy::2, dx::2]
+                P = P.reshape(N, 9 * 16)
+            else:
+                P = Wall.transpose(0, 2, 3, 1).reshape(N, op.Ktot)
+            Pp = np.full((op.Npad, op.Ktot), -1, dtype=np.int64)
+            Pp[:N] = P
+            self.wloc[(op.name, 'fwd')] = (cur, op.Npad, op.Ktot)
+            pack_idx.append(Pp.reshape(-1)); cur += Pp.size
+            # packed gradient image [N][Ktot] and the map back to parameter positions
+            pos = gcur + np.arange(N * op.Ktot, dtype=np.int64).reshape(N, op.Ktot)
+            valid = P >= 0
+            unpack[P[valid]] = pos[valid]
+            self.gloc[op.name] = gcur
+            gcur += _rup(N * op.Ktot, 8)
+            # dgrad images, one per input segment that needs a gradient
+            if not op.focus:
+                Nk = _rup(N, 8)
+                Wk = Wall
+                if Nk != N:
+                    Wk = np.concatenate([Wall, np.full((Nk - N,) + Wall.shape[1:], -1, dtype=np.int64)], axis=0)
+                c0 = 0
+                for si, sg in enumerate(op.segs):
+                    if sg.buf.needs_grad:
+                        D = Wk[:, c0:c0 + sg.C].transpose(1, 2, 3, 0).reshape(sg.C, op.k * op.k * Nk)
+                        Cp = _rup(sg.C, 128)
+                        Dp = np.full((Cp, D.shape[1]), -1, dtype=np.int64)
+                        Dp[:sg.C] = D
+                        self.wloc[(op.name, 'dgrad', si)] = (cur, Cp, D.shape[1])
+                        pack_idx.append(Dp.reshape(-1)); cur += Dp.size
+                    c0 += sg.C
+            # BN affine / bias gradients live in the packed-gradient arena too
+            for pi, (conv, bn) in enumerate(op.parts):
+                if bn is not None:
+                    Cn = bn.weight.numel()
+                    unpack[self.off[id(bn.weight)]:self.off[id(bn.weight)] + Cn] = gcur + np.arange(Cn)
+                    unpack[self.off[id(bn.bias)]:self.off[id(bn.bias)] + Cn] = gcur + Cn + np.arange(Cn)
+                    self.bn_g[(op.name, pi)] = (gcur, gcur + Cn)
+                    gcur += _rup(2 * Cn, 8)
+                if conv.bias is not None:
+                    Cn = conv.bias.numel()
+                    unpack[self.off[id(conv.bias)]:self.off[id(conv.bias)] + Cn] = gcur + np.arange(Cn)
+                    self.bias_g[(op.name, pi)] = gcur
+                    gcur += _rup(Cn, 8)
+        if cur >= 2 ** 31 or gcur >= 2 ** 31:
+            raise YoloHipError("parameter arena too large for int32 index maps")
+        self.pack_idx = torch.from_numpy(np.concatenate(pack_idx).astype(np.int32)).to(dev)
+        self.unpack_idx = torch.from_numpy(unpack.astype(np.int32)).to(dev)
+        self.wpack = torch.zeros(cur, dtype=torch.bfloat16, device=dev)
+        self.gsize = gcur
+        self.gpack = torch.zeros(max(gcur, 8), dtype=torch.float32, device=dev)
+        self.packed_version = -1
+
+    def _signature(self):
+        return (self.params[0].data_ptr(), self.params[-1].data_ptr(), len(self.params))
+
+    def valid_for(self, module):
+        ps = list(module.parameters())
+        return len(ps) == len(self.params) and all(a is b for a, b in zip(ps, self.params)) and \
+            ps[0].data_ptr() == self.flat.data_ptr() and ps[0].device == self.device
+
+    def repack(self):
+        hipk.pack_bf16(self.flat, self.pack_idx, self.wpack)
+
+    def wptr(self, key):
+        off, rows, K = self.wloc[key]
+        return self.wpack.data_ptr() + 2 * off, rows, K
+
+    def grads_to_params(self):
+        """packed fp32 gradients -> one flat gradient in parameter order (fresh tensor per call)."""
+        flat_g = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        hipk.gather_f32(self.gpack, self.unpack_idx, flat_g)
+        outs, o = [], 0
+        for p in self.params:
+            outs.append(flat_g[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        return flat_g, outs
+
+
+# ------------------------------------------------------------------------------------------
+class Program:
+    """Pre-built kernel launches for one (batch, input shape)."""
+
+    def __init__(self, builder, pack, B, outputs, bn_eps_of=None):
+        self.B, self.pack = B, pack
+        self.ops, self.bufs = builder.ops, builder.bufs
+        self.outputs = outputs          # list of ConvOp (plain) or Ref whose buffers are returned
+        dev = pack.device
+        self.dev = dev
+        self.L = lib()
+        for b in self.bufs:
+            b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=dev)
+        self.generation = 0
+        self.bwd_ready = False
+        self._keep = []                 # keeps ctypes structs / tensors alive
+        self._build_forward()
+
+    # -- helpers -------------------------------------------------------------------------
+    def _conv_desc(self, op, train):
+        pk = self.pack
+        wp, npad, K = pk.wptr((op.name, 'fwd'))
+        assert K == op.Ktot
+        d = ConvDesc()
+        for i, sg in enumerate(op.segs):
+            d.seg[i] = hipk.make_seg(sg.sl())
+        d.nseg, d.mode = len(op.segs), YH_CONV_FWD
+        d.B, d.Ho, d.Wo, d.Hi, d.Wi = self.B, op.Ho, op.Wo, op.Hi, op.Wi
+        d.KH = d.KW = op.k
+        d.stride, d.pad = op.stride, op.pad
+        d.w, d.N, d.Npad = wp, op.N, npad
+        return d
+
+    def _build_forward(self):
+        B, pk, L = self.B, self.pack, self.L
+        self.cmd_train, self.cmd_eval = [], []
+        self.op_state = {}
+        for op in self.ops:
+            if isinstance(op, PoolOp):
+                op.idx = torch.zeros(B, op.src.buf.H, op.src.buf.W, op.src.C, dtype=torch.int8, device=self.dev)
+                s, dd = op.src.sl(), op.dst.sl()
+                args = (s.ptr(), s.ld, B, op.src.buf.H, op.src.buf.W, s.C, dd.ptr(), dd.ld, op.idx.data_ptr())
+                self.cmd_train.append((L.yh_maxpool5_fwd, args, op.name))
+                self.cmd_eval.append((L.yh_maxpool5_fwd, args[:-1] + (None,), op.name))
+                continue
+            M = B * op.Ho * op.Wo
+            st = {}
+            self.op_state[op.name] = st
+            if op.kind == 'plain':
+                conv = op.parts[0][0]
+                d = self._conv_desc(op, True)
+                d.bias = conv.bias.data_ptr() if conv.bias is not None else None
+                d.act = YH_ACT_NONE
+                d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
+                st['desc'] = d
+                self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name))
+                self.cmd_eval.append((L.yh_conv_igemm, (C.byref(d),), op.name))
+                continue
+            # ---- ConvBnAct, training: conv(+stats) -> finalize -> apply
+            d = self._conv_desc(op, True)
+            d.act = YH_ACT_NONE
+            d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
+            nblk = L.yh_conv_stat_blocks(C.byref(d))
+            st['stats'] = torch.zeros(nblk, 2, op.Npad, dtype=torch.float32, device=self.dev)
+            d.stats = st['stats'].data_ptr()
+            st['desc_train'] = d
+            self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name))
+            st['ws'] = []
+            c0 = 0
+            for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
+                ws = torch.zeros(4 * n, dtype=torch.float32, device=self.dev)
+                st['ws'].append(ws)
+                mom = bn.momentum if bn.momentum is not None else 0.1
+                self.cmd_train.append((L.yh_bn_finalize, (
+                    st['stats'].data_ptr() + 4 * c0, nblk, op.Npad, n, M, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(),
+                    float(bn.eps), float(mom), ws.data_ptr()), op.name))
+                dst = op.outs[pi].sl()
+                res = op.res.sl() if (op.res is not None and pi == 0) else None
+                self.cmd_train.append((L.yh_bn_silu_apply, (
+                    op.y.t.data_ptr() + 2 * c0, op.y.C, ws.data_ptr(), n, M, dst.ptr(), dst.ld,
+                    res.ptr() if res else None, res.ld if res else 0), op.name))
+                c0 += n
+            # ---- inference: folded BN + SiLU (+ residual) in the conv epilogue
+            de = self._conv_desc(op, False)
+            st['fold'] = torch.zeros(2, op.N, dtype=torch.float32, device=self.dev)
+            c0 = 0
+            for (conv, bn), n in zip(op.parts, op.part_N):
+                self.cmd_eval.append((L.yh_bn_fold, (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                                     bn.running_var.data_ptr(), float(bn.eps), n,
+                                                     st['fold'].data_ptr() + 4 * c0, st['fold'].data_ptr() + 4 * (op.N + c0)), op.name))
+                c0 += n
+            de.scale, de.shift = st['fold'].data_ptr(), st['fold'].data_ptr() + 4 * op.N
+            de.act = YH_ACT_SILU
+            o0 = op.outs[0].sl()
+            de.out0, de.ld0, de.nsplit = o0.ptr(), o0.ld, op.part_N[0] if len(op.outs) > 1 else op.N
+            if len(op.outs) > 1:
+                o1 = op.outs[1].sl()
+                de.out1, de.ld1 = o1.ptr(), o1.ld
+                assert len(op.outs) == 2
+            if op.res is not None:
+                r = op.res.sl()
+                de.res, de.ldr = r.ptr(), r.ld
+            st['desc_eval'] = de
+            self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name))
+
+    # -- forward ---------------------------------------------------------------------------
+    def _run(self, cmds):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for fn, args, name in cmds:
+            rc = fn(*args, st)
+            if rc != 0:
+                check(rc, f"{fn.__name__} [{name}]")
+
+    def forward(self, train):
+        self.generation += 1
+        # fresh head buffers every call: the returned views must not be overwritten by the next forward
+        for o in self.outputs:
+            if isinstance(o, ConvOp):
+                o.y.t = torch.empty(self.B, o.y.H, o.y.W, o.y.C, dtype=torch.bfloat16, device=self.dev)
+                self.op_state[o.name]['desc'].out0 = o.y.t.data_ptr()
+        self._run(self.cmd_train if train else self.cmd_eval)
+        return self.generation
+
+    # -- backward --------------------------------------------------------------------------
+    def _build_backward(self):
+        B, pk, L = self.B, self.pack, self.L
+        cmds = []
+        max_gy = 0
+        for b in self.bufs:
+            b.ginit = np.zeros(b.C, dtype=bool)
+            if b.needs_grad and b.g is None and not b.name.endswith(".y") and not getattr(b, "is_head", False):
+                b.g = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=self.dev)
+        for op in self.ops:
+            if isinstance(op, ConvOp) and op.kind == 'cba':
+                max_gy = max(max_gy, B * op.Ho * op.Wo * op.N)
+        self.gy_scratch = torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev)
+        self.part_scratch = torch.zeros(1024 * 2 * 2048, dtype=torch.float32, device=self.dev)
+        self.coef_scratch = {}
+        self.ups_scratch = {}
+
+        def claim(ref):
+            """returns accumulate flag for a write into grad(ref) and marks it written"""
+            flags = ref.buf.ginit[ref.coff:ref.coff + ref.C]
+            if flags.all():
+                return 1
+            if flags.any():
+                raise YoloHipError(f"partial gradient overlap on {ref.buf.name}")
+            flags[:] = True
+            return 0
+
+        def require(ref, who):
+            if not ref.buf.ginit[ref.coff:ref.coff + ref.C].all():
+                raise YoloHipError(f"{who}: gradient of {ref.buf.name}[{ref.coff}:{ref.coff + ref.C}] is never produced")
+
+        # head outputs receive their gradient from the caller
+        for o in self.outputs:
+            if isinstance(o, ConvOp):
+                o.y.ginit[:] = True
+            else:
+                o.buf.ginit[o.coff:o.coff + o.C] = True
+
+        for op in reversed(self.ops):
+            if isinstance(op, PoolOp):
+                require(op.dst, op.name)
+                acc = claim(op.src)
+                go, gi = op.dst.sl(True), op.src.sl(True)
+                cmds.append((L.yh_maxpool5_bwd, (go.ptr(), go.ld, op.idx.data_ptr(), B, op.src.buf.H, op.src.buf.W, go.C,
+                                                 gi.ptr(), gi.ld, acc), op.name))
+                continue
+            M = B * op.Ho * op.Wo
+            st = self.op_state[op.name]
+            gdw = pk.gpack.data_ptr() + 4 * pk.gloc[op.name]
+            if op.kind == 'plain':
+                # gradient arrives in op.y.g (set per call); bias grad = column sums
+                st['gy_ref'] = 'head'
+                gy_ptr_holder = st
+                conv = op.parts[0][0]
+                cmds.append(('head_colsum', op, pk.bias_g.get((op.name, 0))))
+                gy_ld, gyN = op.y.C, op.N
+                gy_sl = None
+            else:
+                c0 = 0
+                for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
+                    require(op.outs[pi], op.name)
+                    ga = op.outs[pi].sl(True)
+                    ws = st['ws'][pi]
+                    coef = torch.zeros(2 * n, dtype=torch.float32, device=self.dev)
+                    self.coef_scratch[(op.name, pi)] = coef
+                    nblk = L.yh_ew_blocks(M)
+                    ypart = op.y.t.data_ptr() + 2 * c0
+                    cmds.append((L.yh_bn_silu_bwd_reduce, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), n, M,
+                                                           self.part_scratch.data_ptr()), op.name))
+                    goff, boff = pk.bn_g[(op.name, pi)]
+                    cmds.append((L.yh_bn_bwd_finalize, (self.part_scratch.data_ptr(), nblk, n, M,
+                                                        pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
+                                                        coef.data_ptr()), op.name))
+                    gres_ptr, gres_ld, gres_acc = None, 0, 0
+                    if op.res is not None and pi == 0 and op.res.buf.needs_grad:
+                        gres_acc = claim(op.res)
+                        gr = op.res.sl(True)
+                        gres_ptr, gres_ld = gr.ptr(), gr.ld
+                    cmds.append((L.yh_bn_silu_bwd_apply, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), bn.weight.data_ptr(),
+                                                          coef.data_ptr(), n, M, self.gy_scratch.data_ptr() + 2 * c0, op.N,
+                                                          gres_ptr, gres_ld, gres_acc), op.name))
+                    c0 += n
+                gy_ld, gyN = op.N, op.N
+            # wgrad per segment
+            coff_k = 0
+            for si, sg in enumerate(op.segs):
+                wd = WgradDesc()
+                wd.gy = self.gy_scratch.data_ptr() if op.kind == 'cba' else 0
+                wd.ldg, wd.N = gy_ld, gyN
+                wd.seg = hipk.make_seg(sg.sl())
+                wd.coff_k, wd.Ctot = coff_k, op.Ctot
+                wd.B, wd.Ho, wd.Wo, wd.Hi, wd.Wi = B, op.Ho, op.Wo, op.Hi, op.Wi
+                wd.KH = wd.KW = op.k
+                wd.stride, wd.pad = op.stride, op.pad
+                wd.dw = gdw
+                ntile = ((gyN + 63) // 64) * ((sg.C + 63) // 64) * op.k * op.k
+                wd.splits = max(1, min((M + 511) // 512, (1024 + ntile - 1) // ntile))
+                self._keep.append(wd)
+                cmds.append(('wgrad', op, wd))
+                coff_k += sg.C
+            # dgrad per segment
+            for si, sg in enumerate(op.segs):
+                if not sg.buf.needs_grad:
+                    continue
+                wp, cpad, Kd = pk.wptr((op.name, 'dgrad', si))
+                Nk = _rup(op.N, 8)
+                d = ConvDesc()
+                d.seg[0].ptr = self.gy_scratch.data_ptr() if op.kind == 'cba' else 0
+                d.seg[0].ld, d.seg[0].C, d.seg[0].ups = gy_ld, Nk, 0
+                d.nseg, d.mode = 1, YH_CONV_DGRAD
+                d.B, d.Ho, d.Wo, d.Hi, d.Wi = B, op.Hi, op.Wi, op.Ho, op.Wo
+                d.KH = d.KW = op.k
+                d.stride, d.pad = op.stride, op.pad
+                d.w, d.N, d.Npad = wp, sg.C, cpad
+                d.act = YH_ACT_NONE
+                d.nsplit = sg.C
+                if sg.ups:
+                    tmp = torch.zeros(B, op.Hi, op.Wi, sg.C, dtype=torch.bfloat16, device=self.dev)
+                    self.ups_scratch[(op.name, si)] = tmp
+                    d.out0, d.ld0, d.accumulate = tmp.data_ptr(), sg.C, 0
+                    acc = claim(Ref(sg.buf, sg.coff, sg.C))
+                    gl = Slice(sg.buf.g, sg.coff, sg.C)
+                    self._keep.append(d)
+                    cmds.append(('dgrad', op, d))
+                    cmds.append((L.yh_upsample2_bwd, (tmp.data_ptr(), sg.C, B, sg.buf.H, sg.buf.W, sg.C, gl.ptr(), gl.ld, acc), op.name))
+                else:
+                    acc = claim(Ref(sg.buf, sg.coff, sg.C))
+                    gl = Slice(sg.buf.g, sg.coff, sg.C)
+                    d.out0, d.ld0, d.accumulate = gl.ptr(), gl.ld, acc
+                    self._keep.append(d)
+                    cmds.append(('dgrad', op, d))
+        self.cmd_bwd = cmds
+        self.bwd_ready = True
+
+    def backward(self, head_grads):
+        """head_grads: list of [B,h,w,ld] bf16 gradient buffers matching self.outputs (plain ops)."""
+        if not self.bwd_ready:
+            self._build_backward()
+        pk, L = self.pack, self.L
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        hipk.fill_zero(pk.gpack)
+        heads = {}
+        for o, g in zip(self.outputs, head_grads):
+            if isinstance(o, ConvOp):
+                heads[o.name] = g
+            else:
+                o.buf.g[..., o.coff:o.coff + o.C].copy_(g)
+        for cmd in self.cmd_bwd:
+            fn = cmd[0]
+            if fn == 'head_colsum':
+                _, op, boff = cmd
+                g = heads[op.name]
+                if boff is not None:
+                    rc = L.yh_colsum(g.data_ptr(), op.y.C, op.y.C, self.B * op.Ho * op.Wo, self.part_scratch.data_ptr(),
+                                     pk.gpack.data_ptr() + 4 * boff, st)
+                    if rc:
+                        check(rc, "yh_colsum")
+            elif fn == 'wgrad':
+                _, op, wd = cmd
+                if op.kind == 'plain':
+                    wd.gy = heads[op.name].data_ptr()
+                rc = L.yh_conv_wgrad(C.byref(wd), st)
+                if rc:
+                    check(rc, f"yh_conv_wgrad [{op.name}]")
+            elif fn == 'dgrad':
+                _, op, d = cmd
+                if op.kind == 'plain':
+                    d.seg[0].ptr = heads[op.name].data_ptr()
+                rc = L.yh_conv_igemm(C.byref(d), st)
+                if rc:
+                    check(rc, f"yh_conv_igemm dgrad [{op.name}]")
+            else:
+                _, args, name = cmd
+                rc = fn(*args, st)
+                if rc:
+                    check(rc, f"{fn.__name__} bwd [{name}]")
+        return pk.grads_to_params()
+
+
+# ------------------------------------------------------------------------------------------
+class _NetFn(torch.autograd.Function):
+    """One autograd node for the whole conv graph: forward runs the train program, backward
+    returns (a) nothing for the image and (b) per-parameter gradient views of one flat buffer."""
+
+    @staticmethod
+    def forward(ctx, host, prog, x, *params):
+        gen = prog.forward(True)
+        ctx.prog, ctx.gen, ctx.host = prog, gen, host
+        outs = host._yh_outputs(prog)
+        ctx.out_meta = [(o.shape, o.stride()) for o in outs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        prog = ctx.prog
+        if prog.generation != ctx.gen:
+            raise YoloHipError("backward() after another forward() on the same model/shape: activations were overwritten "
+                               "(run forward/backward alternately)")
+        from .layout import is_cell_major
+        head_grads = []
+        for o, g, op in zip(ctx.out_meta, gouts, prog.outputs):
+            shape, stride = o
+            if isinstance(op, ConvOp):
+                Bn, Ct, h, w = shape
+                ld = op.y.C
+                if g is None:
+                    gb = torch.zeros(Bn, h, w, ld, dtype=torch.bfloat16, device=prog.dev)
+                elif g.dtype == torch.bfloat16 and is_cell_major(g) and g.stride(3) == ld:
+                    gb = g.as_strided((Bn, h, w, ld), (h * w * ld, w * ld, ld, 1))
+                else:
+                    gb = torch.zeros(Bn, h, w, ld, dtype=torch.bfloat16, device=prog.dev)
+                    gb[..., :Ct] = g.permute(0, 2, 3, 1)
+                head_grads.append(gb)
+            else:
+                head_grads.append(g.permute(0, 2, 3, 1).to(torch.bfloat16) if g is not None else torch.zeros(
+                    shape[0], shape[2], shape[3], shape[1], dtype=torch.bfloat16, device=prog.dev))
+        flat_g, pgrads = prog.backward(head_grads)
+        ctx.host._yh_last_flat_grad = flat_g
+        hook = getattr(ctx.host, "_yh_grad_hook", None)
+        if hook is not None:
+            hook(flat_g)
+        gx = None
+        if ctx.needs_input_grad[2] and prog.in_buf.needs_grad and prog.in_buf.g is not None:
+            gx = prog.in_buf.g.permute(0, 3, 1, 2).float()
+        return (None, None, gx, *pgrads)
+
+
+class HipModuleMixin:
+    """Mixed into nn.Modules whose forward runs on the engine."""
+
+    def _yh_state(self):
+        st = self.__dict__.get('_yh')
+        if st is None:
+            st = {'pack': None, 'progs': {}}
+            self.__dict__['_yh'] = st
+        return st
+
+    def __getstate__(self):
+        s = dict(self.__dict__)
+        s.pop('_yh', None)
+        s.pop('_yh_last_flat_grad', None)
+        s.pop('_yh_grad_hook', None)
+        return s
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__['_yh'] = None
+
+    def _yh_reset(self):
+        self.__dict__['_yh'] = None
+
+    # subclasses implement:  _yh_build(builder, B, H, W) -> (input_kind, outputs)
+    def _yh_program(self, B, H, W):
+        st = self._yh_state()
+        if st['pack'] is not None and not st['pack'].valid_for(self):
+            st = {'pack': None, 'progs': {}}
+            self.__dict__['_yh'] = st
+        key = (B, H, W)
+        prog = st['progs'].get(key)
+        if prog is None:
+            b = Builder()
+            outputs = self._yh_build(b, B, H, W)
+            if st['pack'] is None:
+                st['pack'] = ParamPack(self, b.ops)
+            prog = Program(b, st['pack'], B, outputs)
+            prog.in_buf = b.bufs[0]
+            st['progs'][key] = prog
+            if len(st['progs']) > 4:      # bound the number of cached shapes
+                st['progs'].pop(next(iter(st['progs'])))
+        return prog
+
+    def _yh_outputs(self, prog):
+        from .layout import cell_major_view
+        outs = []
+        for o in prog.outputs:
+            if isinstance(o, ConvOp):
+                outs.append(cell_major_view(o.y.t, o.N))
+            else:
+                t = o.buf.t[..., o.coff:o.coff + o.C]
+                outs.append(t.permute(0, 3, 1, 2))
+        return outs
+
+    def _yh_forward(self, prog, x):
+        pk = prog.pack
+        pk.repack()
+        if self.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in pk.params)):
+            return _NetFn.apply(self, prog, x, *pk.params)
+        prog.forward(self.training)
+        return tuple(self._yh_outputs(prog))
