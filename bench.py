@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): images/sec of one full YOLOv5s training step at 640x640
+— forward (HIP conv graph, bf16) + YOLOv5 loss + backward + clip + SGD-nesterov + EMA —
+batch 64 per GPU on synthetic COCO-shaped data resident in HBM, random-init weights.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce of the flat gradient)
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     — dominant kernel family, algorithmic conv FLOPs / its measured duration (HIP events on the
+                 launch stream, separate instrumented steps after the timed region)
+  cpu_baseline — the oracle (torch-CPU fp32 port of the same train step) on a bounded sample, rank 0, N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense MFMA peak, MI355X (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+TRAIN_GFLOP_PER_IMG = 49.30    # YOLOv5s@640: 3 x 16.434 GFLOP conv fwd
+
+
+def make_hyp(dev, img, batch):
+    return dict(device=dev, num_class=80, input_img_size=[img, img], batch_size=batch,
+                use_focal_loss=True, focal_loss_gamma=1.5, focal_loss_alpha=0.25,
+                iou_loss_scale=0.05, cls_loss_scale=0.5, cof_loss_scale=1.0, anchor_match_thr=4.0,
+                class_smooth_factor=1.0, cls_pos_weight=1.0, cof_pos_weight=1.0,
+                loss_items_on_device=True)
+
+
+def cpu_baseline(budget_s=20.0, batch=4, img=640):
+    """torch-CPU fp32 port (oracle/) of the same train step on a bounded sample: B=4 (BASELINE config #1)."""
+    from oracle.v5loss import V5LossOracle
+    from oracle.v5net import V5NetOracle
+    from yoloseries_amd import models
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = V5NetOracle(models.YOLOV5Small(3, 80).state_dict(), train=True)
+    hyp = make_hyp("cpu", img, batch)
+    lossf = V5LossOracle(COCO_ANCHORS, hyp)
+    x = torch.rand(batch, 3, img, img, generator=torch.Generator().manual_seed(0))
+    t = synth_targets(batch, img, 80, 20, seed=1)
+    times = []
+    t_begin = time.time()
+    for it in range(4):
+        t0 = time.time()
+        out = lossf(net(x), t)
+        out["tot_loss"].backward()
+        net.sgd_step(0.01)
+        times.append(time.time() - t0)
+        if it >= 1 and time.time() - t_begin > budget_s:
+            break
+    steady = times[1:] if len(times) > 1 else times
+    return {"value": round(batch / float(np.median(steady)), 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{len(steady)} train steps (fwd+loss+bwd+SGD) of YOLOv5s at batch {batch}, {img}x{img}, "
+            f"torch-CPU fp32 oracle, after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--img", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--model", default="small", choices=["small", "middle", "large", "xlarge"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from yoloseries_amd import models
+    from yoloseries_amd.loss import YOLOV5Loss
+    from yoloseries_amd.trainer import ExponentialMovingAverageModel
+    from yoloseries_amd.utils import FlatSGD
+    from yoloseries_amd.utils.dist import DataParallelGrads
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
+
+    B, img = args.batch, args.img
+    torch.manual_seed(0)
+    cls = {"small": models.YOLOV5Small, "middle": models.YOLOV5Middle, "large": models.YOLOV5Large, "xlarge": models.YOLOV5XLarge}[args.model]
+    model = cls(3, 80).to(dev).train()
+    hyp = make_hyp(dev, img, B)
+    lossf = YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), hyp)
+    lr = 0.000625 * B                       # basic_lr_per_img x per-rank batch (train_yolov5.py:184)
+    opt = FlatSGD(model, lr=lr, momentum=0.937, weight_decay=1e-4, nesterov=True)
+    ema = ExponentialMovingAverageModel(model)
+    dp = DataParallelGrads(model) if world > 1 else None
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(rank), dtype=torch.float32).to(dev)
+    t = torch.from_numpy(synth_targets(B, img, 80, 20, seed=1 + rank)).to(dev)
+
+    def step():
+        out = lossf(model(x), t)
+        out["tot_loss"].backward()
+        opt.clip_grad_norm_(10.0)
+        opt.step()
+        opt.zero_grad()
+        ema.update(model)
+        return out
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    loss_val = float(out["tot_loss"].item())
+    ips = world * B * args.steps / dt
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        roof = measure_roofline(model, step, B)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:      # the oracle is test infrastructure; never let it fail the measurement
+            cpu = {"error": repr(e)}
+    if rank == 0:
+        res = {
+            "metric": "images/sec (640x640) YOLOv5s train-step", "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"YOLOv5{args.model[0]} bf16 train step (fwd+loss+bwd+clip+SGD+EMA), batch {B}/GPU x {img}x{img} synthetic COCO-80, "
+                                   f"random-init (BASELINE.json configs[1])", "global_batch": B * world, "parallelism": f"dp{world}"},
+            "train_tflops": round(ips * TRAIN_GFLOP_PER_IMG / 1000.0, 2),
+            "mfma_frac_step": round(ips * TRAIN_GFLOP_PER_IMG / 1000.0 / (MFMA_PEAK_TFLOPS * world), 4),
+            "final_loss": round(loss_val, 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure_roofline(model, step, B, nsteps=3):
+    """HIP-event timing of every engine launch over `nsteps` instrumented steps (events are recorded on the
+    stream the kernels are launched on).  Reports the conv kernel family with the largest total time."""
+    prog = next(iter(model._yh_state()['progs'].values()))
+    prog.profile = {}
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+    prof, prog.profile = prog.profile, None
+    fam = {}
+    for key, recs in prof.items():
+        name, flops = key
+        ms = sum(s.elapsed_time(e) for s, e in recs)
+        f = fam.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        f["ms"] += ms
+        f["flops"] += flops * len(recs)
+        f["launches"] += len(recs)
+    conv = {k: v for k, v in fam.items() if v["flops"] > 0}
+    if not conv:
+        return None
+    dom = max(conv, key=lambda k: conv[k]["ms"])
+    d = conv[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    total_ms = sum(v["ms"] for v in fam.values()) / nsteps
+    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(1000 * d["ms"] / d["launches"], 2), "launches_per_step": d["launches"] // nsteps,
+            "family_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+            "engine_kernel_ms_per_step": round(total_ms, 3)}
+
+
+if __name__ == "__main__":
+    main()

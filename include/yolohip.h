@@ -180,6 +180,8 @@ int yh_sgd_step(float* p, const float* g, float* buf, const uint8_t* group, int6
                 int first_step, const float* grad_scale, yh_stream stream);
 /* sum of squares of a flat fp32 buffer (for clip_grad_norm_, train_yolov5.py:344) */
 int yh_sumsq(const float* x, int64_t n, float* part, float* out, yh_stream stream);
+/* clip coefficient min(1, max_norm/(sqrt(sumsq)+1e-6)) as a device scalar for yh_sgd_step's grad_scale */
+int yh_clip_scale(const float* sumsq, float max_norm, float* out, yh_stream stream);
 /* EMA: e = d*e + (1-d)*p over a flat arena (trainer/ema_model.py:20-28)         */
 int yh_ema_update(float* ema, const float* p, int64_t n, float decay, yh_stream stream);
 

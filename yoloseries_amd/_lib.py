@@ -106,6 +106,7 @@ _SIGS = {
     "yh_gather_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "yh_sgd_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp]),
     "yh_sumsq": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "yh_clip_scale": (_i32, [_vp, _f32, _vp, _vp]),
     "yh_ema_update": (_i32, [_vp, _vp, _i64, _f32, _vp]),
     "yh_v5loss_ws_bytes": (_sz, [C.POINTER(V5LossDesc)]),
     "yh_v5loss_saved_bytes": (_sz, [C.POINTER(V5LossDesc)]),
@@ -142,6 +143,9 @@ def lib():
         raise YoloHipError(
             f"{LIB_PATH} not found: the HIP extension is required (run __graft_entry__.build() or "
             f"`make -C {CSRC_DIR}`); there is no CPU fallback for the product path.")
+    # torch bundles its own libamdhip64: import it first so that this library binds to the SAME HIP
+    # runtime (two runtimes in one process cannot see each other's device context)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     missing = []
     for name, (res, args) in _SIGS.items():

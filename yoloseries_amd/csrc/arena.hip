@@ -70,6 +70,14 @@ __global__ void sum_final_kernel(const float* __restrict__ part, int nb, float* 
         *out = (float)s;
     }
 }
+__global__ void clip_scale_kernel(const float* sumsq, float max_norm, float* out)
+{
+    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float c = max_norm / (sqrtf(*sumsq) + 1e-6f);
+        *out = c < 1.f ? c : 1.f;
+    }
+}
 __global__ void ema_kernel(float* __restrict__ e, const float* __restrict__ p, long n, float decay)
 {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -137,5 +145,13 @@ extern "C" int yh_ema_update(float* ema, const float* p, int64_t n, float decay,
     if (n == 0) return YH_OK;
     hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(TH), 0, (hipStream_t)stream, ema, p, (long)n, decay);
     YH_CHECK_LAUNCH("yh_ema_update");
+    return YH_OK;
+}
+
+extern "C" int yh_clip_scale(const float* sumsq, float max_norm, float* out, yh_stream stream)
+{
+    YH_CHECK_ARG(sumsq && out && max_norm > 0.f, "yh_clip_scale: bad args");
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq, max_norm, out);
+    YH_CHECK_LAUNCH("yh_clip_scale");
     return YH_OK;
 }

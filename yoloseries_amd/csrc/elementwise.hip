@@ -11,21 +11,48 @@ namespace {
 constexpr int EW_THREADS = 256;
 
 // ---------------------------------------------------------------- BN finalize
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int ldstat, int C, double count,
+// Deterministic column sums of a [nblk][nwhich][ld] partial slab: one block = 64 channels (lane = channel,
+// coalesced rows), 16 waves stride over the partial rows, fixed-order combine through LDS in fp64.
+template <int NW>
+__device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int nblk, int ld, int C, int c, double* out /*NW*/)
+{
+    __shared__ double sred[16][NW][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double acc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc[w] = 0.0;
+    if (c < C) {
+        for (int b = wv; b < nblk; b += 16) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc[w] += (double)slab[((size_t)b * NW + w) * ld + c];
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sred[wv][w][lane] = acc[w];
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            double s = 0.0;
+            for (int i = 0; i < 16; ++i) s += sred[i][w][lane];
+            out[w] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int ldstat, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, int64_t* num_batches,
                                    float eps, float momentum, float* ws)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double sq[2];
+    slab_colsum<2>(stats, nblk, ldstat, C, c, sq);
+    if (threadIdx.x >= 64) return;
     if (c == 0 && num_batches) *num_batches += 1;
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)stats[((size_t)b * 2 + 0) * ldstat + c];
-        q += (double)stats[((size_t)b * 2 + 1) * ldstat + c];
-    }
-    double mean = s / count;
-    double var = q / count - mean * mean;
+    double mean = sq[0] / count;
+    double var = sq[1] / count - mean * mean;
     if (var < 0.0) var = 0.0;
     float invstd = (float)(1.0 / sqrt(var + (double)eps));
     float g = gamma[c], bt = beta[c];
@@ -148,28 +175,25 @@ __global__ __launch_bounds__(EW_THREADS) void col_reduce_kernel(const uint16_t* 
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
                                        float* dgamma, float* dbeta, float* coef)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += (double)part[((size_t)b * 2 + 0) * C + c];
-        s2 += (double)part[((size_t)b * 2 + 1) * C + c];
-    }
-    if (dbeta) dbeta[c] = (float)s1;
-    if (dgamma) dgamma[c] = (float)s2;
-    if (coef) { coef[c] = (float)(s1 / M); coef[C + c] = (float)(s2 / M); }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s[2];
+    slab_colsum<2>(part, nblk, C, C, c, s);
+    if (threadIdx.x >= 64 || c >= C) return;
+    if (dbeta) dbeta[c] = (float)s[0];
+    if (dgamma) dgamma[c] = (float)s[1];
+    if (coef) { coef[c] = (float)(s[0] / M); coef[C + c] = (float)(s[1] / M); }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out)
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out)
 {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[((size_t)b * 2 + 0) * C + c];
-    out[c] = (float)s;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s[2];
+    slab_colsum<2>(part, nblk, C, C, c, s);
+    if (threadIdx.x >= 64 || c >= C) return;
+    out[c] = (float)s[0];
 }
 
 __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ldga, const uint16_t* __restrict__ y, int ldy,
@@ -390,7 +414,7 @@ extern "C" int yh_bn_finalize(const float* stats, int nblk, int ldstat, int C, i
                               int64_t* num_batches, float eps, float momentum, float* ws, yh_stream stream)
 {
     YH_CHECK_ARG(stats && gamma && beta && ws && nblk > 0 && C > 0 && count > 0 && ldstat >= C, "yh_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
                        stats, nblk, ldstat, C, (double)count, gamma, beta, running_mean, running_var, num_batches, eps, momentum, ws);
     YH_CHECK_LAUNCH("yh_bn_finalize");
     return YH_OK;
@@ -441,7 +465,7 @@ extern "C" int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M,
                                   float* dgamma, float* dbeta, float* coef, yh_stream stream)
 {
     YH_CHECK_ARG(part && nblk > 0 && C > 0 && M > 0, "yh_bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
                        part, nblk, C, (double)M, dgamma, dbeta, coef);
     YH_CHECK_LAUNCH("yh_bn_bwd_finalize");
     return YH_OK;
@@ -473,7 +497,7 @@ extern "C" int yh_colsum(const yh_bf16* g, int ldg, int C, int64_t M, float* par
     long rpb = (M + nblk - 1) / nblk;
     hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        g, ldg, (const uint16_t*)nullptr, 0, (const float*)nullptr, C, C / 8, (long)M, rpb, part);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, part, nblk, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, nblk, C, out);
     YH_CHECK_LAUNCH("yh_colsum");
     return YH_OK;
 }

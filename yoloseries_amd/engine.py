@@ -34,6 +34,11 @@ def _rup(x, m):
     return ((x + m - 1) // m) * m
 
 
+def _pick_bn(n):
+    """output-channel tile the conv kernel picks (csrc/conv_igemm.hip pick_bn)"""
+    return 32 if n <= 32 else (64 if n <= 64 else 128)
+
+
 class TBuf:
     """An NHWC bf16 activation buffer (allocated per Program)."""
 
@@ -144,6 +149,16 @@ class ParamPack:
             flat[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = flat[o:o + p.numel()].view(p.shape)
         self.flat = flat
+        # float buffers (BatchNorm running statistics) share one arena too: EMA / DP averaging are single launches
+        fbufs = [b for b in module.buffers() if b.dtype == torch.float32]
+        nb = sum(b.numel() for b in fbufs)
+        self.fbuf = torch.empty(max(nb, 1), dtype=torch.float32, device=dev)
+        o = 0
+        for b in fbufs:
+            self.fbuf[o:o + b.numel()].copy_(b.data.reshape(-1))
+            b.data = self.fbuf[o:o + b.numel()].view(b.shape)
+            o += b.numel()
+        self.nbuf = nb
         self.off = {id(p): int(o) for p, o in zip(params, offs[:-1])}
         self.sig = self._signature()
 
@@ -261,6 +276,7 @@ class Program:
         for b in self.bufs:
             b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=dev)
         self.generation = 0
+        self.profile = None             # {(kernel family, algorithmic flops): [(start_event, end_event)]} when profiling
         self.bwd_ready = False
         self._keep = []                 # keeps ctypes structs / tensors alive
         self._build_forward()
@@ -289,8 +305,8 @@ class Program:
                 op.idx = torch.zeros(B, op.src.buf.H, op.src.buf.W, op.src.C, dtype=torch.int8, device=self.dev)
                 s, dd = op.src.sl(), op.dst.sl()
                 args = (s.ptr(), s.ld, B, op.src.buf.H, op.src.buf.W, s.C, dd.ptr(), dd.ld, op.idx.data_ptr())
-                self.cmd_train.append((L.yh_maxpool5_fwd, args, op.name))
-                self.cmd_eval.append((L.yh_maxpool5_fwd, args[:-1] + (None,), op.name))
+                self.cmd_train.append((L.yh_maxpool5_fwd, args, op.name, ('yh_maxpool5_fwd', 0)))
+                self.cmd_eval.append((L.yh_maxpool5_fwd, args[:-1] + (None,), op.name, ('yh_maxpool5_fwd', 0)))
                 continue
             M = B * op.Ho * op.Wo
             st = {}
@@ -302,8 +318,8 @@ class Program:
                 d.act = YH_ACT_NONE
                 d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
                 st['desc'] = d
-                self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name))
-                self.cmd_eval.append((L.yh_conv_igemm, (C.byref(d),), op.name))
+                self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op)))
+                self.cmd_eval.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op)))
                 continue
             # ---- ConvBnAct, training: conv(+stats) -> finalize -> apply
             d = self._conv_desc(op, True)
@@ -313,7 +329,7 @@ class Program:
             st['stats'] = torch.zeros(nblk, 2, op.Npad, dtype=torch.float32, device=self.dev)
             d.stats = st['stats'].data_ptr()
             st['desc_train'] = d
-            self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name))
+            self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op)))
             st['ws'] = []
             c0 = 0
             for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
@@ -323,12 +339,12 @@ class Program:
                 self.cmd_train.append((L.yh_bn_finalize, (
                     st['stats'].data_ptr() + 4 * c0, nblk, op.Npad, n, M, bn.weight.data_ptr(), bn.bias.data_ptr(),
                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(),
-                    float(bn.eps), float(mom), ws.data_ptr()), op.name))
+                    float(bn.eps), float(mom), ws.data_ptr()), op.name, ('yh_bn_finalize', 0)))
                 dst = op.outs[pi].sl()
                 res = op.res.sl() if (op.res is not None and pi == 0) else None
                 self.cmd_train.append((L.yh_bn_silu_apply, (
                     op.y.t.data_ptr() + 2 * c0, op.y.C, ws.data_ptr(), n, M, dst.ptr(), dst.ld,
-                    res.ptr() if res else None, res.ld if res else 0), op.name))
+                    res.ptr() if res else None, res.ld if res else 0), op.name, ('yh_bn_silu_apply', 0)))
                 c0 += n
             # ---- inference: folded BN + SiLU (+ residual) in the conv epilogue
             de = self._conv_desc(op, False)
@@ -337,7 +353,7 @@ class Program:
             for (conv, bn), n in zip(op.parts, op.part_N):
                 self.cmd_eval.append((L.yh_bn_fold, (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                                                      bn.running_var.data_ptr(), float(bn.eps), n,
-                                                     st['fold'].data_ptr() + 4 * c0, st['fold'].data_ptr() + 4 * (op.N + c0)), op.name))
+                                                     st['fold'].data_ptr() + 4 * c0, st['fold'].data_ptr() + 4 * (op.N + c0)), op.name, ('yh_bn_fold', 0)))
                 c0 += n
             de.scale, de.shift = st['fold'].data_ptr(), st['fold'].data_ptr() + 4 * op.N
             de.act = YH_ACT_SILU
@@ -351,15 +367,26 @@ class Program:
                 r = op.res.sl()
                 de.res, de.ldr = r.ptr(), r.ld
             st['desc_eval'] = de
-            self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name))
+            self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name, self._fam_conv(op)))
 
     # -- forward ---------------------------------------------------------------------------
+    def _fam_conv(self, op):
+        M = self.B * op.Ho * op.Wo
+        return (f'conv_igemm_kernel<{_pick_bn(op.N)}>', 2.0 * M * op.N * op.k * op.k * (12 if op.focus else op.Ctot))
+
     def _run(self, cmds):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for fn, args, name in cmds:
+        prof = self.profile
+        for fn, args, name, meta in cmds:
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             rc = fn(*args, st)
             if rc != 0:
                 check(rc, f"{fn.__name__} [{name}]")
+            if prof is not None:
+                e1.record()
+                prof.setdefault(meta, []).append((e0, e1))
 
     def forward(self, train):
         self.generation += 1
@@ -415,7 +442,7 @@ class Program:
                 acc = claim(op.src)
                 go, gi = op.dst.sl(True), op.src.sl(True)
                 cmds.append((L.yh_maxpool5_bwd, (go.ptr(), go.ld, op.idx.data_ptr(), B, op.src.buf.H, op.src.buf.W, go.C,
-                                                 gi.ptr(), gi.ld, acc), op.name))
+                                                 gi.ptr(), gi.ld, acc), op.name, ('yh_maxpool5_bwd', 0)))
                 continue
             M = B * op.Ho * op.Wo
             st = self.op_state[op.name]
@@ -425,7 +452,7 @@ class Program:
                 st['gy_ref'] = 'head'
                 gy_ptr_holder = st
                 conv = op.parts[0][0]
-                cmds.append(('head_colsum', op, pk.bias_g.get((op.name, 0))))
+                cmds.append(('head_colsum', op, pk.bias_g.get((op.name, 0)), ('yh_colsum', 0)))
                 gy_ld, gyN = op.y.C, op.N
                 gy_sl = None
             else:
@@ -439,11 +466,11 @@ class Program:
                     nblk = L.yh_ew_blocks(M)
                     ypart = op.y.t.data_ptr() + 2 * c0
                     cmds.append((L.yh_bn_silu_bwd_reduce, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), n, M,
-                                                           self.part_scratch.data_ptr()), op.name))
+                                                           self.part_scratch.data_ptr()), op.name, ('yh_bn_silu_bwd_reduce', 0)))
                     goff, boff = pk.bn_g[(op.name, pi)]
                     cmds.append((L.yh_bn_bwd_finalize, (self.part_scratch.data_ptr(), nblk, n, M,
                                                         pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
-                                                        coef.data_ptr()), op.name))
+                                                        coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0)))
                     gres_ptr, gres_ld, gres_acc = None, 0, 0
                     if op.res is not None and pi == 0 and op.res.buf.needs_grad:
                         gres_acc = claim(op.res)
@@ -451,7 +478,7 @@ class Program:
                         gres_ptr, gres_ld = gr.ptr(), gr.ld
                     cmds.append((L.yh_bn_silu_bwd_apply, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), bn.weight.data_ptr(),
                                                           coef.data_ptr(), n, M, self.gy_scratch.data_ptr() + 2 * c0, op.N,
-                                                          gres_ptr, gres_ld, gres_acc), op.name))
+                                                          gres_ptr, gres_ld, gres_acc), op.name, ('yh_bn_silu_bwd_apply', 0)))
                     c0 += n
                 gy_ld, gyN = op.N, op.N
             # wgrad per segment
@@ -469,7 +496,7 @@ class Program:
                 ntile = ((gyN + 63) // 64) * ((sg.C + 63) // 64) * op.k * op.k
                 wd.splits = max(1, min((M + 511) // 512, (1024 + ntile - 1) // ntile))
                 self._keep.append(wd)
-                cmds.append(('wgrad', op, wd))
+                cmds.append(('wgrad', op, wd, ('conv_wgrad_kernel', 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
                 coff_k += sg.C
             # dgrad per segment
             for si, sg in enumerate(op.segs):
@@ -494,14 +521,14 @@ class Program:
                     acc = claim(Ref(sg.buf, sg.coff, sg.C))
                     gl = Slice(sg.buf.g, sg.coff, sg.C)
                     self._keep.append(d)
-                    cmds.append(('dgrad', op, d))
-                    cmds.append((L.yh_upsample2_bwd, (tmp.data_ptr(), sg.C, B, sg.buf.H, sg.buf.W, sg.C, gl.ptr(), gl.ld, acc), op.name))
+                    cmds.append(('dgrad', op, d, (f'conv_igemm_kernel<{_pick_bn(sg.C)}>', 2.0 * M * op.N * op.k * op.k * sg.C)))
+                    cmds.append((L.yh_upsample2_bwd, (tmp.data_ptr(), sg.C, B, sg.buf.H, sg.buf.W, sg.C, gl.ptr(), gl.ld, acc), op.name, ('yh_upsample2_bwd', 0)))
                 else:
                     acc = claim(Ref(sg.buf, sg.coff, sg.C))
                     gl = Slice(sg.buf.g, sg.coff, sg.C)
                     d.out0, d.ld0, d.accumulate = gl.ptr(), gl.ld, acc
                     self._keep.append(d)
-                    cmds.append(('dgrad', op, d))
+                    cmds.append(('dgrad', op, d, (f'conv_igemm_kernel<{_pick_bn(sg.C)}>', 2.0 * M * op.N * op.k * op.k * sg.C)))
         self.cmd_bwd = cmds
         self.bwd_ready = True
 
@@ -518,10 +545,14 @@ class Program:
                 heads[o.name] = g
             else:
                 o.buf.g[..., o.coff:o.coff + o.C].copy_(g)
+        prof = self.profile
         for cmd in self.cmd_bwd:
             fn = cmd[0]
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if fn == 'head_colsum':
-                _, op, boff = cmd
+                _, op, boff, _m = cmd
                 g = heads[op.name]
                 if boff is not None:
                     rc = L.yh_colsum(g.data_ptr(), op.y.C, op.y.C, self.B * op.Ho * op.Wo, self.part_scratch.data_ptr(),
@@ -529,24 +560,27 @@ class Program:
                     if rc:
                         check(rc, "yh_colsum")
             elif fn == 'wgrad':
-                _, op, wd = cmd
+                _, op, wd, _m = cmd
                 if op.kind == 'plain':
                     wd.gy = heads[op.name].data_ptr()
                 rc = L.yh_conv_wgrad(C.byref(wd), st)
                 if rc:
                     check(rc, f"yh_conv_wgrad [{op.name}]")
             elif fn == 'dgrad':
-                _, op, d = cmd
+                _, op, d, _m = cmd
                 if op.kind == 'plain':
                     d.seg[0].ptr = heads[op.name].data_ptr()
                 rc = L.yh_conv_igemm(C.byref(d), st)
                 if rc:
                     check(rc, f"yh_conv_igemm dgrad [{op.name}]")
             else:
-                _, args, name = cmd
+                _, args, name, _m = cmd
                 rc = fn(*args, st)
                 if rc:
                     check(rc, f"{fn.__name__} bwd [{name}]")
+            if prof is not None:
+                e1.record()
+                prof.setdefault(cmd[3], []).append((e0, e1))
         return pk.grads_to_params()
 
 
@@ -589,9 +623,15 @@ class _NetFn(torch.autograd.Function):
                     shape[0], shape[2], shape[3], shape[1], dtype=torch.bfloat16, device=prog.dev))
         flat_g, pgrads = prog.backward(head_grads)
         ctx.host._yh_last_flat_grad = flat_g
-        hook = getattr(ctx.host, "_yh_grad_hook", None)
+        hook = getattr(ctx.host, "_yh_grad_hook", None)        # data-parallel all-reduce (utils/dist.py)
         if hook is not None:
             hook(flat_g)
+        hook = getattr(ctx.host, "_yh_grad_hook_opt", None)    # flat-arena optimizer
+        if hook is not None:
+            hook(flat_g)
+        if getattr(ctx.host, "flat_grads_only", False):
+            # the flat-arena optimizer (utils/optim.py FlatSGD) consumes flat_g directly; skip 177 AccumulateGrad nodes
+            pgrads = [None] * len(pgrads)
         gx = None
         if ctx.needs_input_grad[2] and prog.in_buf.needs_grad and prog.in_buf.g is not None:
             gx = prog.in_buf.g.permute(0, 3, 1, 2).float()
@@ -613,6 +653,8 @@ class HipModuleMixin:
         s.pop('_yh', None)
         s.pop('_yh_last_flat_grad', None)
         s.pop('_yh_grad_hook', None)
+        s.pop('_yh_grad_hook_opt', None)
+        s.pop('flat_grads_only', None)
         return s
 
     def __setstate__(self, state):

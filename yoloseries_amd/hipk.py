@@ -197,3 +197,7 @@ def sumsq(x, part, out):
 
 def ema_update(ema, p, decay):
     check(lib().yh_ema_update(_p(ema), _p(p), p.numel(), decay, _st()), "yh_ema_update")
+
+
+def clip_scale(sumsq_t, max_norm, out):
+    check(lib().yh_clip_scale(_p(sumsq_t), float(max_norm), _p(out), _st()), "yh_clip_scale")

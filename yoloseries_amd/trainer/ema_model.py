@@ -1,6 +1,7 @@
 """ExponentialMovingAverageModel — mirror of trainer/ema_model.py:7-28.
 decay = decay_ratio * (1 - exp(-n/2000)); every floating tensor of the state_dict follows
-e = d*e + (1-d)*p.  On a model with a flat parameter arena the update is one HIP launch."""
+e = d*e + (1-d)*p.  When the source model keeps its parameters / BatchNorm statistics in the
+engine's flat arenas, the whole update is two HIP launches (parameters, float buffers)."""
 import math
 from copy import deepcopy
 
@@ -9,26 +10,60 @@ import torch
 __all__ = ['ExponentialMovingAverageModel']
 
 
+def _unwrap(model):
+    return model.module if hasattr(model, 'module') and isinstance(model.module, torch.nn.Module) else model
+
+
 class ExponentialMovingAverageModel:
 
     def __init__(self, model, decay_ratio=0.9999, update_num=0):
-        self.ema = deepcopy(model.module if hasattr(model, 'module') and isinstance(model.module, torch.nn.Module) else model).eval()
+        self.ema = deepcopy(_unwrap(model)).eval()
         self.update_num = update_num
         self.get_decay_weight = lambda x: decay_ratio * (1 - math.exp(-x / 2000))
         for parm in self.ema.parameters():
             parm.requires_grad_(False)
+        self._flat = None
+
+    def _flat_views(self, src_pack):
+        """(re)alias the EMA module's parameters / float buffers onto two flat tensors laid out like the source arenas"""
+        ps = list(self.ema.parameters())
+        ok = self._flat is not None and ps[0].data_ptr() == self._flat[0].data_ptr() and self._flat[0].numel() == src_pack.n
+        if not ok:
+            fp = torch.empty(src_pack.n, dtype=torch.float32, device=src_pack.device)
+            o = 0
+            for p in ps:
+                fp[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = fp[o:o + p.numel()].view(p.shape)
+                o += p.numel()
+            fb = torch.empty(max(src_pack.nbuf, 1), dtype=torch.float32, device=src_pack.device)
+            o = 0
+            for b in self.ema.buffers():
+                if b.dtype == torch.float32:
+                    fb[o:o + b.numel()].copy_(b.data.reshape(-1))
+                    b.data = fb[o:o + b.numel()].view(b.shape)
+                    o += b.numel()
+            self._flat = (fp, fb)
+            if hasattr(self.ema, "_yh_reset"):
+                self.ema._yh_reset()
+        return self._flat
 
     def update(self, model):
         with torch.no_grad():
             self.update_num += 1
             decay_weight = self.get_decay_weight(self.update_num)
-            src = model.module if hasattr(model, 'module') and isinstance(model.module, torch.nn.Module) else model
+            src = _unwrap(model)
+            st = src.__dict__.get('_yh')
+            pack = st['pack'] if st else None
+            if pack is not None and pack.valid_for(src):
+                from .. import hipk
+                fp, fb = self._flat_views(pack)
+                hipk.ema_update(fp, pack.flat, decay_weight)
+                if pack.nbuf:
+                    hipk.ema_update(fb, pack.fbuf, decay_weight)
+                # integer buffers (num_batches_tracked) are not averaged by the reference either
+                return
             state = src.state_dict()
             for k, v in self.ema.state_dict().items():
                 if v.dtype.is_floating_point:
-                    if v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and state[k].is_contiguous():
-                        from .. import hipk
-                        hipk.ema_update(v, state[k].detach(), decay_weight)
-                    else:
-                        v *= decay_weight
-                        v += (1. - decay_weight) * state[k].detach()
+                    v *= decay_weight
+                    v += (1. - decay_weight) * state[k].detach()

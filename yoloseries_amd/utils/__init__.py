@@ -2,3 +2,5 @@ from .synth import COCO_ANCHORS, synth_head_outputs, synth_nms_heads, synth_targ
 from .bbox_tools import *  # noqa: F401,F403
 from .nms import *  # noqa: F401,F403
 from .layer_tools import *  # noqa: F401,F403
+from .optim import *  # noqa: F401,F403
+from .dist import *  # noqa: F401,F403

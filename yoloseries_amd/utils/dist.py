@@ -1,0 +1,117 @@
+"""Distributed helpers — mirror of the reference's utils/dist.py / utils/allreduce_norm.py surface that the
+drivers import (get_rank, get_world_size, get_local_rank, synchronize, all_reduce_norm, get_num_devices),
+ROCm/CPU safe (no nvidia-smi), plus the data-parallel gradient exchange of the HIP models.
+
+One process per GPU; torch.distributed backend "nccl" is RCCL on ROCm (xGMI inside a node); the CPU tests
+use "gloo".  The reference wraps the model in DDP (train_yolov5.py:219-220): gradients are AVERAGED over
+ranks, BatchNorm statistics stay per-rank during training and are averaged only before evaluation
+(utils/allreduce_norm.py:56-98).  Here the engine hands over ONE flat fp32 gradient buffer per backward,
+so the exchange is a single (optionally chunked) all-reduce instead of DDP's per-bucket hooks.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+__all__ = ['get_rank', 'get_world_size', 'get_local_rank', 'get_num_devices', 'synchronize', 'is_main_process',
+           'all_reduce_norm', 'DataParallelGrads', 'allreduce_flat_mean']
+
+
+def _on():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if _on() else 1
+
+
+def get_rank():
+    return dist.get_rank() if _on() else 0
+
+
+def get_local_rank():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def get_num_devices():
+    """utils/dist.py:34-41 without nvidia-smi: visible devices from the environment or the runtime"""
+    vis = os.environ.get("CUDA_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES")
+    if vis:
+        return len([v for v in vis.split(",") if v != ""])
+    return torch.cuda.device_count()
+
+
+def synchronize():
+    """barrier across ranks (utils/dist.py:66-79)"""
+    if _on() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def allreduce_flat_mean(flat, group=None, chunks=1):
+    """in-place mean over ranks of one flat tensor; `chunks` > 1 issues several async collectives so that
+    the tail of the buffer can overlap with whatever the caller still computes"""
+    world = dist.get_world_size(group) if _on() else 1
+    if world == 1:
+        return []
+    n = flat.numel()
+    step = (n + chunks - 1) // chunks
+    works = []
+    for o in range(0, n, step):
+        part = flat[o:o + step]
+        works.append((dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group, async_op=True), part))
+    for w, part in works:
+        w.wait()
+        part.div_(world)
+    return works
+
+
+class DataParallelGrads:
+    """Averages the engine's flat gradient over the ranks right after each backward (DDP semantics:
+    mean of per-rank gradients; no_sync() skips the exchange on accumulation steps, train_yolov5.py:327)."""
+
+    def __init__(self, model, group=None, chunks=2):
+        self.model, self.group, self.chunks = model, group, chunks
+        self.enabled = True
+        model._yh_grad_hook = self._hook
+
+    def _hook(self, flat_g):
+        if self.enabled:
+            allreduce_flat_mean(flat_g, self.group, self.chunks)
+
+    class _NoSync:
+        def __init__(self, dp):
+            self.dp = dp
+
+        def __enter__(self):
+            self.prev, self.dp.enabled = self.dp.enabled, False
+
+        def __exit__(self, *a):
+            self.dp.enabled = self.prev
+
+    def no_sync(self):
+        return DataParallelGrads._NoSync(self)
+
+
+def all_reduce_norm(module):
+    """average every BatchNorm state (weight, bias, running_mean, running_var) over the ranks before
+    evaluation — utils/allreduce_norm.py:56-98.  With the engine's arenas this is one collective on the
+    float-buffer arena plus one on the gathered affine parameters."""
+    if get_world_size() == 1:
+        return
+    states = []
+    for m in module.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.InstanceNorm2d)):
+            states += [m.weight.data, m.bias.data, m.running_mean.data, m.running_var.data]
+    if not states:
+        return
+    flat = torch.cat([s.reshape(-1).float() for s in states])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= get_world_size()
+    o = 0
+    for s in states:
+        s.copy_(flat[o:o + s.numel()].view(s.shape))
+        o += s.numel()

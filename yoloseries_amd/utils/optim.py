@@ -1,0 +1,115 @@
+"""Flat-arena SGD for the HIP models: the three parameter groups of the reference's
+``_init_optimizer`` (train_yolov5.py:258-280 — BN weights | conv weights + weight decay | biases),
+torch.optim.SGD(nesterov) semantics, clip_grad_norm_(10) (:344) and zero_grad in three launches
+over the model's flat parameter arena instead of ~3x177 per-tensor kernels.
+
+``param_groups`` is a list of dicts with 'lr' / 'initial_lr' / 'momentum' / 'weight_decay', so the
+reference's warm-up code (train_yolov5.py:437-456) can mutate it unchanged."""
+import torch
+from torch import nn
+
+from .. import hipk
+from .._lib import YoloHipError
+
+__all__ = ['FlatSGD']
+
+
+class FlatSGD:
+
+    def __init__(self, model, lr, momentum=0.937, weight_decay=1e-4, nesterov=True):
+        self.model = model
+        model.flat_grads_only = True
+        self.nesterov = nesterov
+        self.param_groups = [
+            {"name": "bn_weight", "lr": lr, "initial_lr": lr, "momentum": momentum, "weight_decay": 0.0},
+            {"name": "weight", "lr": lr, "initial_lr": lr, "momentum": momentum, "weight_decay": weight_decay},
+            {"name": "bias", "lr": lr, "initial_lr": lr, "momentum": momentum, "weight_decay": 0.0},
+        ]
+        self._built_for = None
+        self.steps = 0
+        self._gacc = None
+        self._nacc = 0
+        model._yh_grad_hook_opt = self._on_grad
+
+    def _build(self, pack):
+        gid = {}
+        for m in self.model.modules():
+            if hasattr(m, "bias") and isinstance(m.bias, nn.Parameter):
+                gid[id(m.bias)] = 2
+            if isinstance(m, nn.BatchNorm2d):
+                gid[id(m.weight)] = 0
+            elif hasattr(m, 'weight') and isinstance(m.weight, nn.Parameter):
+                gid[id(m.weight)] = 1
+        dev = pack.device
+        group = torch.empty(pack.n, dtype=torch.uint8, device=dev)
+        o = 0
+        for p in pack.params:
+            group[o:o + p.numel()] = gid.get(id(p), 1)
+            o += p.numel()
+        self.group = group
+        self.buf = torch.zeros(pack.n, dtype=torch.float32, device=dev)
+        self.lr_t = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.wd_t = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.part = torch.zeros(4096, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.scale = torch.ones(1, dtype=torch.float32, device=dev)
+        self._lr_host = None
+        self._built_for = pack
+        self._use_scale = False
+
+    def _pack(self):
+        st = self.model.__dict__.get('_yh')
+        if not st or st['pack'] is None:
+            raise YoloHipError("FlatSGD: run a forward pass first (the parameter arena is created lazily)")
+        if self._built_for is not st['pack']:
+            self._build(st['pack'])
+        return st['pack']
+
+    def _on_grad(self, flat_g):
+        # gradient accumulation over several backward() calls (train_yolov5.py:327-337)
+        if self._nacc == 0:
+            self._gacc = flat_g
+        else:
+            self._gacc = self._gacc + flat_g
+        self._nacc += 1
+
+    def _grad(self):
+        g = self._gacc if self._gacc is not None else getattr(self.model, "_yh_last_flat_grad", None)
+        if g is None:
+            raise YoloHipError("FlatSGD.step(): no gradient (call backward() first)")
+        return g
+
+    def clip_grad_norm_(self, max_norm):
+        self._pack()
+        g = self._grad()
+        hipk.sumsq(g, self.part, self.sumsq)
+        hipk.clip_scale(self.sumsq, max_norm, self.scale)
+        self._use_scale = True
+        return self.sumsq          # device scalar: total_norm ** 2 (no host sync)
+
+    def step(self):
+        pack = self._pack()
+        g = self._grad()
+        lrs = tuple(float(pg["lr"]) for pg in self.param_groups) + tuple(float(pg["weight_decay"]) for pg in self.param_groups)
+        if lrs != self._lr_host:
+            self.lr_t.copy_(torch.tensor(lrs[:3], dtype=torch.float32))
+            self.wd_t.copy_(torch.tensor(lrs[3:], dtype=torch.float32))
+            self._lr_host = lrs
+        hipk.sgd_step(pack.flat, g, self.buf, self.group, self.lr_t, self.wd_t, float(self.param_groups[0]["momentum"]),
+                      self.nesterov, self.steps == 0, self.scale if self._use_scale else None)
+        self.steps += 1
+        self._use_scale = False
+
+    def zero_grad(self, set_to_none=True):
+        self._gacc, self._nacc = None, 0
+        self.model._yh_last_flat_grad = None
+
+    def state_dict(self):
+        return {"momentum_buffer": self.buf if self._built_for is not None else None, "steps": self.steps,
+                "param_groups": [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.param_groups = [dict(g) for g in sd["param_groups"]]
+        self.steps = sd["steps"]
+        if sd.get("momentum_buffer") is not None and self._built_for is not None:
+            self.buf.copy_(sd["momentum_buffer"])
