@@ -174,13 +174,18 @@ def measure_roofline(model, step, B, nsteps=3):
     torch.cuda.synchronize()
     prof, prog.profile = prog.profile, None
     fam = {}
+    per_op = []
     for key, recs in prof.items():
-        name, flops = key
+        name, flops, opname = key
         ms = sum(s.elapsed_time(e) for s, e in recs)
+        per_op.append((ms / nsteps, name, opname, flops))
         f = fam.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
         f["ms"] += ms
         f["flops"] += flops * len(recs)
         f["launches"] += len(recs)
+    if os.environ.get("YH_BENCH_LAYERS"):
+        for ms, name, opname, flops in sorted(per_op, reverse=True)[:int(os.environ["YH_BENCH_LAYERS"])]:
+            print(f"# {ms:8.3f} ms/step  {name:28s} {opname:40s} {flops / 1e9 / max(ms, 1e-9):9.1f} TFLOP/s", file=sys.stderr)
     conv = {k: v for k, v in fam.items() if v["flops"] > 0}
     if not conv:
         return None

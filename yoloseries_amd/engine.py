@@ -386,7 +386,7 @@ class Program:
                 check(rc, f"{fn.__name__} [{name}]")
             if prof is not None:
                 e1.record()
-                prof.setdefault(meta, []).append((e0, e1))
+                prof.setdefault(meta + (name,), []).append((e0, e1))
 
     def forward(self, train):
         self.generation += 1
@@ -493,8 +493,12 @@ class Program:
                 wd.KH = wd.KW = op.k
                 wd.stride, wd.pad = op.stride, op.pad
                 wd.dw = gdw
-                ntile = ((gyN + 63) // 64) * ((sg.C + 63) // 64) * op.k * op.k
-                wd.splits = max(1, min((M + 511) // 512, (1024 + ntile - 1) // ntile))
+                kseg = op.k * op.k * sg.C
+                if kseg <= 384:          # "wide" tiling of csrc/conv_wgrad.hip: one block covers every im2col column
+                    ntile = (gyN + 31) // 32 if gyN <= 32 else (gyN + 63) // 64
+                else:
+                    ntile = ((gyN + 63) // 64) * ((kseg + 63) // 64)
+                wd.splits = max(1, min((M + 255) // 256, (1024 + ntile - 1) // ntile))
                 self._keep.append(wd)
                 cmds.append(('wgrad', op, wd, ('conv_wgrad_kernel', 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
                 coff_k += sg.C
@@ -580,7 +584,7 @@ class Program:
                     check(rc, f"{fn.__name__} bwd [{name}]")
             if prof is not None:
                 e1.record()
-                prof.setdefault(cmd[3], []).append((e0, e1))
+                prof.setdefault(cmd[3] + (cmd[1].name if hasattr(cmd[1], 'name') else cmd[2],), []).append((e0, e1))
         return pk.grads_to_params()
 
 
