@@ -62,13 +62,15 @@ __global__ __launch_bounds__(TH) void sumsq_part_kernel(const float* __restrict_
         part[blockIdx.x] = (float)tsum;
     }
 }
-__global__ void sum_final_kernel(const float* __restrict__ part, int nb, float* out)
+__global__ __launch_bounds__(256) void sum_final_kernel(const float* __restrict__ part, int nb, float* out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nb; ++i) s += (double)part[i];
-        *out = (float)s;
-    }
+    __shared__ double sw[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += (double)part[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (float)(sw[0] + sw[1] + sw[2] + sw[3]);
 }
 __global__ void clip_scale_kernel(const float* sumsq, float max_norm, float* out)
 {
@@ -135,7 +137,7 @@ extern "C" int yh_sumsq(const float* x, int64_t n, float* part, float* out, yh_s
     YH_CHECK_ARG(x && part && out && n > 0, "yh_sumsq: bad args (part needs 4096 floats)");
     int nb = grid_for(n);
     hipLaunchKernelGGL(sumsq_part_kernel, dim3(nb), dim3(TH), 0, (hipStream_t)stream, x, (long)n, part);
-    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, nb, out);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb, out);
     YH_CHECK_LAUNCH("yh_sumsq");
     return YH_OK;
 }

@@ -27,10 +27,14 @@ struct ConvK {
     yh_conv_desc d;
     int M, Ctot, Ktot, nkt, mtiles;
     int sa, sb, sc, sdshift;
+    // stride-2 data gradient: the output pixels are processed in 4 parity classes (blockIdx.z); a class only
+    // touches the taps whose parity matches, so no MFMA work is spent on structurally-zero taps
+    int cls, Hc, Wc;
+    int fast;      // every input segment has a multiple of 32 channels: tap-major incremental loader
 };
 
-template <int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
+template <int BN, int WM, int WN, bool FAST, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
 {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
@@ -43,6 +47,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
     uint16_t* sB = sA + 2 * BM * LDSP;                            // [2][BN][LDSP]
     uint16_t* sC = reinterpret_cast<uint16_t*>(smem);            // [BM][CP] (aliases sA/sB)
     float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);  // [WM][2][BN]
+    int* sPix = reinterpret_cast<int*>(smem + MAIN_BYTES + WM * 2 * BN * 4);   // [BM] output pixel of each tile row (cls mode)
 
     const yh_conv_desc& d = p.d;
     const int t = threadIdx.x;
@@ -55,6 +60,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
     const int n0 = blockIdx.y * BN;
     const int HoWo = d.Ho * d.Wo;
     const int sdmask = (1 << p.sdshift) - 1;
+    // parity class of this block (cls mode): output pixels (2i+ph, 2j+pw); taps kh = kh0 + 2a, kw = kw0 + 2b
+    const int ph = p.cls ? (blockIdx.z >> 1) : 0, pw = p.cls ? (blockIdx.z & 1) : 0;
+    const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
+    const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
+    const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
+    const int Keff = nkh * nkw * p.Ctot;
+    const int nkt = p.cls ? (Keff + BK - 1) / BK : p.nkt;
+    const int HcWc = p.Hc * p.Wc;
 
     float run_s = 0.f, run_q = 0.f;
 
@@ -65,11 +78,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
         for (int i = 0; i < 2; ++i) {
             int m = m0 + rowA + 64 * i;
             if (m < p.M) {
-                int im = m / HoWo;
-                int rem = m - im * HoWo;
-                int ho = rem / d.Wo;
-                int wo = rem - ho * d.Wo;
+                int im, ho, wo;
+                if (p.cls) {
+                    im = m / HcWc;
+                    int rem = m - im * HcWc;
+                    int ii = rem / p.Wc;
+                    ho = 2 * ii + ph; wo = 2 * (rem - ii * p.Wc) + pw;
+                } else {
+                    im = m / HoWo;
+                    int rem = m - im * HoWo;
+                    ho = rem / d.Wo;
+                    wo = rem - ho * d.Wo;
+                }
                 img[i] = im; hb[i] = ho * p.sa + p.sc; wb[i] = wo * p.sa + p.sc;
+                if (p.cls && kc == 0) sPix[rowA + 64 * i] = (im * d.Ho + ho) * d.Wo + wo;
             } else {
                 img[i] = 0; hb[i] = -(1 << 28); wb[i] = -(1 << 28);
             }
@@ -85,13 +107,64 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
 
         uint4 ra[2], rb[NBL];
 
-        auto load_tile = [&](int kt) {
+        // ---- loader state: k-tiles are walked tap-major.  On the fast path (every segment a multiple of 32
+        // channels) a k-tile never straddles a tap or a segment, so the per-row pixel offsets and validity are
+        // recomputed only when the tap changes and a k-tile costs a pointer increment.
+        int ld_tap = 0, ld_cb = 0;
+        int pix0[2] = {0, 0}, pix1[2] = {0, 0};
+        bool okr[2] = {false, false};
+        int kcol_base = 0;
+        const int ncb = p.Ctot >> 5;
+        auto tap_setup = [&](int tapl) {
+            int kh = tapl / nkw;
+            int kw = tapl - kh * nkw;
+            if (p.cls) { kh = kh0 + 2 * kh; kw = kw0 + 2 * kw; }
+            kcol_base = (kh * d.KW + kw) * p.Ctot;
+            const int u0 = d.seg[0].ups, u1 = d.seg[1].ups;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hn = hb[i] + kh * p.sb;
+                const int wn_ = wb[i] + kw * p.sb;
+                bool ok = hn >= 0 && wn_ >= 0 && (((hn | wn_) & sdmask) == 0);
+                const int hs = hn >> p.sdshift, ws = wn_ >> p.sdshift;
+                ok = ok && hs < d.Hi && ws < d.Wi;
+                okr[i] = ok;
+                pix0[i] = (img[i] * (d.Hi >> u0) + (hs >> u0)) * (d.Wi >> u0) + (ws >> u0);
+                pix1[i] = (img[i] * (d.Hi >> u1) + (hs >> u1)) * (d.Wi >> u1) + (ws >> u1);
+            }
+        };
+        auto load_fast = [&]() {
+            if (ld_cb == 0) tap_setup(ld_tap);
+            const int c = ld_cb * 32 + kc * 8;
+            const bool s1 = d.nseg > 1 && c >= d.seg[0].C;
+            const uint16_t* sp = s1 ? d.seg[1].ptr : d.seg[0].ptr;
+            const int sld = s1 ? d.seg[1].ld : d.seg[0].ld;
+            const int cc = s1 ? c - d.seg[0].C : c;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (okr[i]) v = *reinterpret_cast<const uint4*>(sp + (size_t)(s1 ? pix1[i] : pix0[i]) * sld + cc);
+                ra[i] = v;
+            }
+            const uint16_t* wp = d.w + (size_t)n0 * p.Ktot + kcol_base + c;
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                const int id = t + i * 256;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (id < BN * 4) v = *reinterpret_cast<const uint4*>(wp + (size_t)(id >> 2) * p.Ktot);
+                rb[i] = v;
+            }
+            if (++ld_cb == ncb) { ld_cb = 0; ++ld_tap; }
+        };
+        auto load_generic = [&](int kt) {
             const int k = kt * BK + kc * 8;
-            const bool kvalid = k < p.Ktot;
+            const bool kvalid = k < Keff;
             int tap = 0, c = 0;
             if (kvalid) { tap = k / p.Ctot; c = k - tap * p.Ctot; }
-            const int kh = tap / d.KW;
-            const int kw = tap - kh * d.KW;
+            int kh = tap / nkw;
+            int kw = tap - kh * nkw;
+            if (p.cls) { kh = kh0 + 2 * kh; kw = kw0 + 2 * kw; }
+            const int kcol = (kh * d.KW + kw) * p.Ctot + c;      // column in the packed weight rows
             const int sidx = (d.nseg > 1 && c >= d.seg[0].C) ? 1 : 0;
             const yh_seg& sg = d.seg[sidx];
             const int cc = c - (sidx ? d.seg[0].C : 0);
@@ -118,10 +191,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (id < BN * 4 && kvalid) {
                     int n = id >> 2;
-                    v = *reinterpret_cast<const uint4*>(d.w + (size_t)(n0 + n) * p.Ktot + k);
+                    v = *reinterpret_cast<const uint4*>(d.w + (size_t)(n0 + n) * p.Ktot + kcol);
                 }
                 rb[i] = v;
             }
+        };
+        auto load_tile = [&](int kt) {
+            if constexpr (FAST) load_fast(); else load_generic(kt);
         };
         auto store_tile = [&](int buf) {
             uint16_t* a = sA + buf * BM * LDSP;
@@ -140,9 +216,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
         store_tile(0);
         __syncthreads();
 
-        for (int kt = 0; kt < p.nkt; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             const int buf = kt & 1;
-            const bool more = (kt + 1) < p.nkt;
+            const bool more = (kt + 1) < nkt;
             if (more) load_tile(kt + 1);
             const uint16_t* a = sA + buf * BM * LDSP;
             const uint16_t* b = sB + buf * BN * LDSP;
@@ -220,14 +296,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p)
                 uint4 v = *reinterpret_cast<const uint4*>(sC + row * CP + cch * 8);
                 uint16_t* dst;
                 bool first = n < d.nsplit;
-                if (first) dst = d.out0 + (size_t)m * d.ld0 + n;
-                else       dst = d.out1 + (size_t)m * d.ld1 + (n - d.nsplit);
+                const size_t orow = p.cls ? (size_t)sPix[row] : (size_t)m;
+                if (first) dst = d.out0 + orow * d.ld0 + n;
+                else       dst = d.out1 + orow * d.ld1 + (n - d.nsplit);
                 const bool addres = (d.res != nullptr) && first;
                 if (addres || d.accumulate) {
                     float f[8];
                     unpack8(v, f);
                     if (addres) {
-                        uint4 rv = *reinterpret_cast<const uint4*>(d.res + (size_t)m * d.ldr + n);
+                        uint4 rv = *reinterpret_cast<const uint4*>(d.res + orow * d.ldr + n);
                         float g[8]; unpack8(rv, g);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] += g[e];
@@ -263,7 +340,7 @@ template <int BN, int WM, int WN>
 constexpr size_t conv_smem_bytes() {
     size_t a = 2 * (BM + BN) * LDSP * 2;
     size_t c = BM * (BN + 8) * 2;
-    return (a > c ? a : c) + WM * 2 * BN * 4;
+    return (a > c ? a : c) + WM * 2 * BN * 4 + BM * 4;
 }
 
 int pick_bn(int N) { return N <= 32 ? 32 : (N <= 64 ? 64 : 128); }
@@ -273,7 +350,7 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
     int mtiles = (int)((M + BM - 1) / BM);
     int b = pick_bn(d->N);
     int nt = (d->N + b - 1) / b;
-    int cap = 2048 / nt;
+    int cap = 1024 / nt;     // also bounds the number of BatchNorm partial-sum rows the finalize kernel reduces
     cap = (cap / 8) * 8;
     if (cap < 8) cap = 8;
     int g = mtiles < cap ? mtiles : cap;
@@ -332,22 +409,43 @@ extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream)
     if (d->mode == YH_CONV_FWD) { k.sa = d->stride; k.sb = 1; k.sc = -d->pad; k.sdshift = 0; }
     else { k.sa = 1; k.sb = -1; k.sc = d->pad; k.sdshift = d->stride == 2 ? 1 : 0; }
     if (k.d.nsplit > k.d.N) k.d.nsplit = k.d.N + 8;   // everything goes to out0
+    k.fast = 1;
+    for (int s2 = 0; s2 < d->nseg; ++s2) if (d->seg[s2].C % 32) k.fast = 0;
+    if ((long)d->B * d->Hi * d->Wi >= (1L << 31)) k.fast = 0;
+    k.cls = 0; k.Hc = d->Ho; k.Wc = d->Wo;
+    if (d->mode == YH_CONV_DGRAD && d->stride == 2 && d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->KH >= 2 && d->KW >= 2 && !d->stats) {
+        k.cls = 1; k.Hc = d->Ho / 2; k.Wc = d->Wo / 2;
+        k.M = (int)(M / 4);
+        k.mtiles = (k.M + BM - 1) / BM;
+    }
 
     int gx, gy, bn;
     conv_grid(d, &gx, &gy, &bn);
     YH_CHECK_ARG(gy * bn <= d->Npad, "yh_conv_igemm: Npad too small for tile");
-    dim3 grid(gx, gy), block(256);
+    if (k.cls) { gx = (gx + 3) / 4; if (gx > k.mtiles) gx = k.mtiles; }
+    dim3 grid(gx, gy, k.cls ? 4 : 1), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (bn == 32) {
-        const size_t sm = conv_smem_bytes<32, 4, 1>();
-        conv_igemm_kernel<32, 4, 1><<<grid, block, sm, st>>>(k);
-    } else if (bn == 64) {
-        const size_t sm = conv_smem_bytes<64, 4, 1>();
-        conv_igemm_kernel<64, 4, 1><<<grid, block, sm, st>>>(k);
-    } else {
-        const size_t sm = conv_smem_bytes<128, 2, 2>();
-        conv_igemm_kernel<128, 2, 2><<<grid, block, sm, st>>>(k);
-    }
+#define YH_LAUNCH_CONV(BN_, WM_, WN_, MINW_)                                                                  \
+    do {                                                                                                      \
+        const size_t sm = conv_smem_bytes<BN_, WM_, WN_>();                                                   \
+        if (k.fast) conv_igemm_kernel<BN_, WM_, WN_, true, MINW_><<<grid, block, sm, st>>>(k);                \
+        else        conv_igemm_kernel<BN_, WM_, WN_, false, MINW_><<<grid, block, sm, st>>>(k);               \
+    } while (0)
+    if (bn == 32) YH_LAUNCH_CONV(32, 4, 1, 4);
+    else if (bn == 64) YH_LAUNCH_CONV(64, 4, 1, 3);
+    else YH_LAUNCH_CONV(128, 2, 2, 2);
+#undef YH_LAUNCH_CONV
     YH_CHECK_LAUNCH("yh_conv_igemm");
     return YH_OK;
+}
+
+// diagnostics: resident blocks per CU the runtime predicts for each instantiation (bn = 32/64/128)
+extern "C" int yh_debug_conv_occupancy(int bn)
+{
+    int nb = -1;
+    hipError_t e;
+    if (bn == 32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_igemm_kernel<32, 4, 1, true, 4>, 256, conv_smem_bytes<32, 4, 1>());
+    else if (bn == 64) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_igemm_kernel<64, 4, 1, true, 3>, 256, conv_smem_bytes<64, 4, 1>());
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_igemm_kernel<128, 2, 2, true, 2>, 256, conv_smem_bytes<128, 2, 2>());
+    return e == hipSuccess ? nb : -(int)e;
 }

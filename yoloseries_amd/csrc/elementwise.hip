@@ -22,7 +22,19 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
 #pragma unroll
     for (int w = 0; w < NW; ++w) acc[w] = 0.0;
     if (c < C) {
-        for (int b = wv; b < nblk; b += 16) {
+        int b = wv;
+        for (; b + 48 < nblk; b += 64) {      // 4 independent row loads in flight per lane
+            float v[4][NW];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v[u][w] = slab[((size_t)(b + 16 * u) * NW + w) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc[w] += (double)v[u][w];
+        }
+        for (; b < nblk; b += 16) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) acc[w] += (double)slab[((size_t)b * NW + w) * ld + c];
         }
@@ -404,7 +416,7 @@ inline int ew_grid(long nthreads) {
 
 extern "C" int yh_ew_blocks(int64_t M) {
     long b = (M + 255) / 256;
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;
     if (b < 1) b = 1;
     return (int)b;
 }

@@ -381,19 +381,31 @@ __global__ __launch_bounds__(256) void v5_obj_fwd_kernel(const LossK p, const St
 }
 
 // ---------------------------------------------------------------- finalize
-__global__ void v5_finalize_kernel(const LossK p, const int32_t* __restrict__ count, const double* __restrict__ part,
+__global__ __launch_bounds__(1024) void v5_finalize_kernel(const LossK p, const int32_t* __restrict__ count, const double* __restrict__ part,
                                    int nb_pos, int nb_obj, double* balances, double* bal_used, float* result)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // deterministic tree: thread t sums the strided partials of (stage, kind) = t / 64; lanes combine in fixed order
+    __shared__ double ssum[MAXS * 3];
     const yh_v5loss_desc& d = p.d;
     const int S = d.num_stage;
+    {
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (wv < S * 3) {
+            const int kind = wv % 3;
+            const int n = kind == 2 ? nb_obj : nb_pos;
+            double a = 0.0;
+            for (int i = lane; i < n; i += 64) a += part[(size_t)wv * PART_BLOCKS + i];
+            a = wave_sum_d(a);
+            if (lane == 0) ssum[wv] = a;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     const double s3 = 3.0 / S;
     double iou_loss = 0.0, cof_loss = 0.0, cls_loss = 0.0;
     long tar = 0;
     for (int s = 0; s < S; ++s) {
-        double a = 0.0, b = 0.0, c = 0.0;
-        for (int i = 0; i < nb_pos; ++i) { a += part[((size_t)s * 3 + 0) * PART_BLOCKS + i]; b += part[((size_t)s * 3 + 1) * PART_BLOCKS + i]; }
-        for (int i = 0; i < nb_obj; ++i) c += part[((size_t)s * 3 + 2) * PART_BLOCKS + i];
+        const double a = ssum[s * 3 + 0], b = ssum[s * 3 + 1], c = ssum[s * 3 + 2];
         const int N = count[s];
         tar += N;
         if (d.num_class > 1) cls_loss += (double)(float)(b / ((double)N * d.num_class));   // mean of an empty tensor is NaN, as in the reference
@@ -614,7 +626,7 @@ extern "C" int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds,
             hipLaunchKernelGGL((v5_obj_fwd_kernel<uint16_t>), dim3(nb_obj), dim3(256), 0, st, k, sg, ciou, next, head, part);
         }
     }
-    hipLaunchKernelGGL(v5_finalize_kernel, dim3(1), dim3(64), 0, st, k, count, part, nb_pos, nb_obj, balances, bal_used, result);
+    hipLaunchKernelGGL(v5_finalize_kernel, dim3(1), dim3(1024), 0, st, k, count, part, nb_pos, nb_obj, balances, bal_used, result);
     YH_CHECK_LAUNCH("yh_v5_loss_fwd");
     return YH_OK;
 }
