@@ -1,4 +1,4 @@
-from .synth import COCO_ANCHORS, synth_head_outputs, synth_nms_heads, synth_targets  # noqa: F401
+from .synth import COCO_ANCHORS, synth_head_outputs, synth_nms_heads, synth_targets, synth_yolox_heads  # noqa: F401
 from .bbox_tools import *  # noqa: F401,F403
 from .nms import *  # noqa: F401,F403
 from .layer_tools import *  # noqa: F401,F403

@@ -60,3 +60,18 @@ def synth_nms_heads(batch, img_size=640, num_class=80, num_anchor=3, seed=2, fra
                     t[b, a, 5 + ccls[b, k], yy, xx] += 4.0
         outs.append(t.reshape(batch, num_anchor * E, h, w))
     return outs
+
+
+def synth_yolox_heads(batch, img_size=640, num_class=80, seed=5, scale=1.0, strides=(8, 16, 32)):
+    """Random YOLOX head tensors in the reference layout: OrderedDict pred_s/m/l of (B, 1, 5+nc, h, w) float32.
+    Box logits are kept small (xy ~ N(0.5, 0.5) cells, wh ~ N(log 3, 0.5)) so that IoUs with the targets are non-trivial."""
+    from collections import OrderedDict
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    for name, s in zip(("pred_s", "pred_m", "pred_l"), strides):
+        h = w = img_size // s
+        t = (rs.randn(batch, 1, 5 + num_class, h, w) * scale).astype(np.float32)
+        t[:, :, 0:2] = (0.5 + 0.5 * rs.randn(batch, 1, 2, h, w)).astype(np.float32)
+        t[:, :, 2:4] = (np.log(3.0) + 0.5 * rs.randn(batch, 1, 2, h, w)).astype(np.float32)
+        out[name] = t
+    return out
