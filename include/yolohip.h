@@ -225,6 +225,32 @@ int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds, const floa
 int yh_v5_loss_bwd(const yh_v5loss_desc* d, const void* const* preds, const float* gout,
                    const void* saved, void* const* gpreds, void* ws, yh_stream stream);
 
+/* ------------------------------------------------------------------------ *
+ * YOLOX loss with SimOTA assignment (loss/yolox_loss.py:11-458)
+ * ------------------------------------------------------------------------ */
+typedef struct yh_yolox_desc {
+    int32_t B, maxbox, num_class, num_stage;
+    int32_t H[4], W[4], ldp[4];   /* per stage: feature map size, elements per cell ([x,y,w,h,obj,cls...] order) */
+    int32_t pred_is_f32;
+    float   img_size0;            /* hyp['input_img_size'][0]; stride = img_size0 / H                          */
+    int32_t use_focal; float focal_gamma, focal_alpha;
+    int32_t use_l1;
+    float   iou_scale, cls_scale, cof_scale, l1_scale;
+    float   cls_smooth, cls_pos_weight, cof_pos_weight;
+    int32_t iou_type;             /* 0 iou, 1 giou, 2 ciou (YOLOXLoss.iou_loss :378-415)                        */
+    int32_t topk; float center_radius;
+    float   cls_cost_const;       /* class part of the SimOTA cost: constant in the reference (:111-147)        */
+} yh_yolox_desc;
+size_t yh_yolox_saved_bytes(const yh_yolox_desc* d);
+size_t yh_yolox_ws_bytes(const yh_yolox_desc* d);
+int yh_yolox_layout(const yh_yolox_desc* d, int64_t* out8);
+/* targets_xywh: [B][maxbox][6] (cx,cy,w,h,cls,img) pixels, padding rows cls < 0 (the reference converts the
+ * caller's xyxy tensor in place, :42).  result fp32[8]: tot, iou, l1, cls, cof, fg_nums, tar_nums, 0           */
+int yh_yolox_loss_fwd(const yh_yolox_desc* d, const void* const* preds, const float* targets_xywh,
+                      double* balances, float* result, void* saved, void* ws, yh_stream stream);
+int yh_yolox_loss_bwd(const yh_yolox_desc* d, const void* const* preds, const float* targets_xywh, const float* gout,
+                      const void* saved, void* const* gpreds, yh_stream stream);
+
 /* Box utilities (utils/bbox_tools.py:164-339) fp32 */
 int yh_iou_matrix(const float* b1, int n1, const float* b2, int n2, float eps_clamp, float* out, yh_stream stream);
 /* kind: 0 giou 1 diou 2 ciou ; pairwise (N,) ; grad (optional) d out/d b1 [N][4] */

@@ -35,7 +35,11 @@ def _gpu_iou(b1, b2):
 
 
 class YOLOXLossOracle:
-    def __init__(self, hyp):
+    def __init__(self, hyp, stable_ties=False):
+        # stable_ties: resolve exact cost ties towards the lower candidate index (what the HIP kernel does); the
+        # reference's torch.topk leaves the choice among EQUAL costs to libstdc++'s introselect, which is not part
+        # of the contract — golden inputs are chosen such that both variants agree (tools/gen_golden.py)
+        self.stable_ties = stable_ties
         self.hyp = hyp
         self.nc = hyp['num_class']
         self.A = hyp['num_anchors']
@@ -73,7 +77,10 @@ class YOLOXLossOracle:
         topk_iou = torch.topk(iou, k, dim=1)[0]
         dyn_k = torch.clamp(topk_iou.sum(1).int(), 1, cost.size(1)).tolist()
         for i in range(cost.size(0)):
-            pos = torch.topk(cost[i], k=dyn_k[i], largest=False)[1]
+            if self.stable_ties:
+                pos = torch.sort(cost[i], stable=True)[1][:dyn_k[i]]
+            else:
+                pos = torch.topk(cost[i], k=dyn_k[i], largest=False)[1]
             mm[i][pos] = 1
         allm = mm.sum(0)
         if allm.max() > 1:

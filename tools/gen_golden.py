@@ -349,7 +349,17 @@ def main():
                 lx_probe({k: torch.from_numpy(v) for k, v in synth_yolox_heads(2, 128, 80, seed=seed + 10 + call).items()},
                          torch.from_numpy(synth_targets(2, 128, 80, 5, seed=seed + call, min_boxes=2)))
             torch.randperm = _orig_randperm
-            if not hits:
+            # also skip inputs where an exact tie in the SimOTA cost (e.g. a gt with zero IoU to every candidate)
+            # decides the assignment: torch.topk's choice among equal costs is an implementation accident
+            from oracle.yoloxloss import YOLOXLossOracle
+            tie_free = not hits
+            for call in range(2 if not hits else 0):
+                o1, o2 = YOLOXLossOracle(dict(hx)), YOLOXLossOracle(dict(hx), stable_ties=True)
+                for o in (o1, o2):
+                    o({k: torch.from_numpy(v) for k, v in synth_yolox_heads(2, 128, 80, seed=seed + 10 + call).items()},
+                      torch.from_numpy(synth_targets(2, 128, 80, 5, seed=seed + call, min_boxes=2)))
+                tie_free &= all(bool((a == b).all()) for a, b in zip(o1.last_fg, o2.last_fg))
+            if not hits and tie_free:
                 break
             seed += 100
         lx = ref_loss.YOLOXLoss(hx)

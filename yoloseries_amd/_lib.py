@@ -64,6 +64,19 @@ class V5LossDesc(C.Structure):
     ]
 
 
+class YoloxDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("maxbox", C.c_int32), ("num_class", C.c_int32), ("num_stage", C.c_int32),
+        ("H", C.c_int32 * 4), ("W", C.c_int32 * 4), ("ldp", C.c_int32 * 4),
+        ("pred_is_f32", C.c_int32), ("img_size0", C.c_float),
+        ("use_focal", C.c_int32), ("focal_gamma", C.c_float), ("focal_alpha", C.c_float),
+        ("use_l1", C.c_int32),
+        ("iou_scale", C.c_float), ("cls_scale", C.c_float), ("cof_scale", C.c_float), ("l1_scale", C.c_float),
+        ("cls_smooth", C.c_float), ("cls_pos_weight", C.c_float), ("cof_pos_weight", C.c_float),
+        ("iou_type", C.c_int32), ("topk", C.c_int32), ("center_radius", C.c_float), ("cls_cost_const", C.c_float),
+    ]
+
+
 class DecodeDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("num_class", C.c_int32), ("num_anchor", C.c_int32), ("num_stage", C.c_int32),
@@ -113,6 +126,11 @@ _SIGS = {
     "yh_v5_assign": (_i32, [C.POINTER(V5LossDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "yh_v5_loss_fwd": (_i32, [C.POINTER(V5LossDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp]),
     "yh_v5_loss_bwd": (_i32, [C.POINTER(V5LossDesc), C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), _vp, _vp]),
+    "yh_yolox_saved_bytes": (_sz, [C.POINTER(YoloxDesc)]),
+    "yh_yolox_ws_bytes": (_sz, [C.POINTER(YoloxDesc)]),
+    "yh_yolox_layout": (_i32, [C.POINTER(YoloxDesc), _vp]),
+    "yh_yolox_loss_fwd": (_i32, [C.POINTER(YoloxDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "yh_yolox_loss_bwd": (_i32, [C.POINTER(YoloxDesc), C.POINTER(_vp), _vp, _vp, _vp, C.POINTER(_vp), _vp]),
     "yh_iou_matrix": (_i32, [_vp, _i32, _vp, _i32, _f32, _vp, _vp]),
     "yh_iou_pairwise": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "yh_decode_full": (_i32, [C.POINTER(DecodeDesc), C.POINTER(_vp), _vp, _vp]),

@@ -122,6 +122,19 @@ class Builder:
         self.ops.append(op)
         return op
 
+    def plain_multi(self, name, parts, segs):
+        """Several biased 1x1 convs with DIFFERENT inputs evaluated as one block-diagonal GEMM whose output
+        columns are the concatenation of the convs' outputs (YOLOX head: reg | cof | cls, yolox_s.py:128-137).
+        parts: list of (conv, index of its input segment in `segs`)."""
+        Hi, Wi = segs[0].buf.H, segs[0].buf.W
+        c0 = parts[0][0]
+        op = ConvOp(name, segs, [(c, None) for c, _ in parts], c0.kernel_size[0], c0.stride[0], c0.padding[0], Hi, Wi, 'plain', None, None)
+        op.part_seg = [si for _, si in parts]
+        op.y = self.buf(name + ".out", op.Ho, op.Wo, _rup(op.N, 8))
+        op.y.is_head = True
+        self.ops.append(op)
+        return op
+
     def pool(self, name, src, dst):
         self.ops.append(PoolOp(name, src, dst))
 
@@ -163,6 +176,8 @@ class ParamPack:
         self.sig = self._signature()
 
         pack_idx, self.wloc = [], {}
+        fpack_idx, self.bias_loc = [], {}
+        fcur = 0
         cur = 0
         gcur = 0
         unpack = np.full(self.n, -1, dtype=np.int64)
@@ -175,7 +190,17 @@ class ParamPack:
         for op in ops:
             if not isinstance(op, ConvOp):
                 continue
-            Wall = np.concatenate([widx(c) for c, _ in op.parts], axis=0)      # [N, I, kh, kw]
+            part_seg = getattr(op, "part_seg", None)
+            if part_seg is None:
+                Wall = np.concatenate([widx(c) for c, _ in op.parts], axis=0)      # [N, I, kh, kw]
+            else:       # block-diagonal: every part only sees the channels of its own input segment
+                Wall = np.full((op.N, op.Ctot, op.k, op.k), -1, dtype=np.int64)
+                seg_c0 = np.concatenate([[0], np.cumsum([sg.C for sg in op.segs])])
+                r = 0
+                for (conv, _), si in zip(op.parts, part_seg):
+                    o = conv.out_channels
+                    Wall[r:r + o, seg_c0[si]:seg_c0[si + 1]] = widx(conv)
+                    r += o
             N = op.N
             if op.focus:
                 n_, ci, kh6, kw6 = Wall.shape
@@ -215,23 +240,35 @@ class ParamPack:
                         pack_idx.append(Dp.reshape(-1)); cur += Dp.size
                     c0 += sg.C
             # BN affine / bias gradients live in the packed-gradient arena too
+            if op.kind == 'plain':
+                # biases of all parts gathered into one fp32 vector (output-column order), gradient = column sums
+                brow = np.full(_rup(N, 8), -1, dtype=np.int64)
+                r = 0
+                for conv, _ in op.parts:
+                    if conv.bias is not None:
+                        brow[r:r + conv.out_channels] = self.off[id(conv.bias)] + np.arange(conv.out_channels)
+                        unpack[self.off[id(conv.bias)]:self.off[id(conv.bias)] + conv.out_channels] = gcur + r + np.arange(conv.out_channels)
+                    r += conv.out_channels
+                self.bias_loc[op.name] = fcur
+                fpack_idx.append(brow); fcur += len(brow)
+                self.bias_g[(op.name, 0)] = gcur
+                gcur += _rup(N, 8)
             for pi, (conv, bn) in enumerate(op.parts):
+                if op.kind == 'plain':
+                    break
                 if bn is not None:
                     Cn = bn.weight.numel()
                     unpack[self.off[id(bn.weight)]:self.off[id(bn.weight)] + Cn] = gcur + np.arange(Cn)
                     unpack[self.off[id(bn.bias)]:self.off[id(bn.bias)] + Cn] = gcur + Cn + np.arange(Cn)
                     self.bn_g[(op.name, pi)] = (gcur, gcur + Cn)
                     gcur += _rup(2 * Cn, 8)
-                if conv.bias is not None:
-                    Cn = conv.bias.numel()
-                    unpack[self.off[id(conv.bias)]:self.off[id(conv.bias)] + Cn] = gcur + np.arange(Cn)
-                    self.bias_g[(op.name, pi)] = gcur
-                    gcur += _rup(Cn, 8)
         if cur >= 2 ** 31 or gcur >= 2 ** 31:
             raise YoloHipError("parameter arena too large for int32 index maps")
         self.pack_idx = torch.from_numpy(np.concatenate(pack_idx).astype(np.int32)).to(dev)
         self.unpack_idx = torch.from_numpy(unpack.astype(np.int32)).to(dev)
         self.wpack = torch.zeros(cur, dtype=torch.bfloat16, device=dev)
+        self.fpack_idx = torch.from_numpy(np.concatenate(fpack_idx).astype(np.int32)).to(dev) if fpack_idx else None
+        self.fpack = torch.zeros(max(fcur, 8), dtype=torch.float32, device=dev)
         self.gsize = gcur
         self.gpack = torch.zeros(max(gcur, 8), dtype=torch.float32, device=dev)
         self.packed_version = -1
@@ -246,6 +283,8 @@ class ParamPack:
 
     def repack(self):
         hipk.pack_bf16(self.flat, self.pack_idx, self.wpack)
+        if self.fpack_idx is not None:
+            hipk.gather_f32(self.flat, self.fpack_idx, self.fpack)
 
     def wptr(self, key):
         off, rows, K = self.wloc[key]
@@ -312,9 +351,8 @@ class Program:
             st = {}
             self.op_state[op.name] = st
             if op.kind == 'plain':
-                conv = op.parts[0][0]
                 d = self._conv_desc(op, True)
-                d.bias = conv.bias.data_ptr() if conv.bias is not None else None
+                d.bias = pk.fpack.data_ptr() + 4 * pk.bias_loc[op.name]
                 d.act = YH_ACT_NONE
                 d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
                 st['desc'] = d
@@ -612,7 +650,9 @@ class _NetFn(torch.autograd.Function):
         for o, g, op in zip(ctx.out_meta, gouts, prog.outputs):
             shape, stride = o
             if isinstance(op, ConvOp):
-                Bn, Ct, h, w = shape
+                Bn, Ct, h, w = prog.B, op.N, op.Ho, op.Wo
+                if g is not None and g.dim() == 5:          # (B, anchors=1, C, h, w) views of the YOLOX head
+                    g = g[:, 0]
                 ld = op.y.C
                 if g is None:
                     gb = torch.zeros(Bn, h, w, ld, dtype=torch.bfloat16, device=prog.dev)
