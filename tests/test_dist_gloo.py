@@ -1,0 +1,62 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel exchange used by bench.py --gpus N: the flat gradient is
+averaged over ranks (DDP semantics, train_yolov5.py:219-220), no_sync skips it, BN states are averaged before eval."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yoloseries_amd.utils.dist import DataParallelGrads, all_reduce_norm, allreduce_flat_mean, get_rank, get_world_size, synchronize
+    assert get_rank() == rank and get_world_size() == world
+    res = {}
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    allreduce_flat_mean(g, chunks=3)
+    res["mean_ok"] = bool(torch.allclose(g, torch.arange(1000, dtype=torch.float32) * 1.5))
+
+    class Fake:          # stands in for a HIP model: the engine calls model._yh_grad_hook(flat_grad) after backward
+        pass
+    fm = Fake()
+    dp = DataParallelGrads(fm, chunks=2)
+    g2 = torch.full((257,), float(rank))
+    fm._yh_grad_hook(g2)
+    res["hook_ok"] = bool(torch.allclose(g2, torch.full((257,), 0.5)))
+    g3 = torch.full((5,), float(rank))
+    with dp.no_sync():
+        fm._yh_grad_hook(g3)
+    res["nosync_ok"] = bool(torch.allclose(g3, torch.full((5,), float(rank))))
+    bn = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+    with torch.no_grad():
+        bn[1].running_mean.fill_(float(rank)); bn[1].weight.fill_(1.0 + rank)
+    all_reduce_norm(bn)
+    res["bn_ok"] = bool(torch.allclose(bn[1].running_mean, torch.full((4,), 0.5)) and torch.allclose(bn[1].weight, torch.full((4,), 1.5)))
+    synchronize()
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_exchange_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in out:
+        assert all(res.values()), (rank, res)

@@ -143,12 +143,13 @@ class Builder:
 class ParamPack:
     """Flat fp32 parameter arena + index maps to/from the packed kernel layouts."""
 
-    def __init__(self, module, ops):
+    def __init__(self, module, ops, host_only=False):
+        """host_only=True builds only the (NumPy) index maps — used by the CPU tests of the packing logic."""
         params = list(module.parameters())
         if not params:
             raise YoloHipError("model has no parameters")
         dev = params[0].device
-        if dev.type != "cuda":
+        if dev.type != "cuda" and not host_only:
             raise YoloHipError("yoloseries_amd models run on an MI355X device only (no CPU path in the product); call .to('cuda') first")
         self.device = dev
         self.params = params
@@ -157,24 +158,24 @@ class ParamPack:
         sizes = [p.numel() for p in params]
         offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         self.n = int(offs[-1])
-        flat = torch.empty(self.n, dtype=torch.float32, device=dev)
-        for p, o in zip(params, offs[:-1]):
-            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
-            p.data = flat[o:o + p.numel()].view(p.shape)
-        self.flat = flat
-        # float buffers (BatchNorm running statistics) share one arena too: EMA / DP averaging are single launches
         fbufs = [b for b in module.buffers() if b.dtype == torch.float32]
         nb = sum(b.numel() for b in fbufs)
-        self.fbuf = torch.empty(max(nb, 1), dtype=torch.float32, device=dev)
-        o = 0
-        for b in fbufs:
-            self.fbuf[o:o + b.numel()].copy_(b.data.reshape(-1))
-            b.data = self.fbuf[o:o + b.numel()].view(b.shape)
-            o += b.numel()
         self.nbuf = nb
+        self.flat = self.fbuf = None
+        if not host_only:
+            flat = torch.empty(self.n, dtype=torch.float32, device=dev)
+            for p, o in zip(params, offs[:-1]):
+                flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = flat[o:o + p.numel()].view(p.shape)
+            self.flat = flat
+            # float buffers (BatchNorm running statistics) share one arena too: EMA / DP averaging are single launches
+            self.fbuf = torch.empty(max(nb, 1), dtype=torch.float32, device=dev)
+            o = 0
+            for b in fbufs:
+                self.fbuf[o:o + b.numel()].copy_(b.data.reshape(-1))
+                b.data = self.fbuf[o:o + b.numel()].view(b.shape)
+                o += b.numel()
         self.off = {id(p): int(o) for p, o in zip(params, offs[:-1])}
-        self.sig = self._signature()
-
         pack_idx, self.wloc = [], {}
         fpack_idx, self.bias_loc = [], {}
         fcur = 0
@@ -264,17 +265,20 @@ class ParamPack:
                     gcur += _rup(2 * Cn, 8)
         if cur >= 2 ** 31 or gcur >= 2 ** 31:
             raise YoloHipError("parameter arena too large for int32 index maps")
-        self.pack_idx = torch.from_numpy(np.concatenate(pack_idx).astype(np.int32)).to(dev)
-        self.unpack_idx = torch.from_numpy(unpack.astype(np.int32)).to(dev)
+        self.pack_idx_np = np.concatenate(pack_idx).astype(np.int32)
+        self.unpack_idx_np = unpack.astype(np.int32)
+        self.fpack_idx_np = np.concatenate(fpack_idx).astype(np.int32) if fpack_idx else None
+        self.gsize = gcur
+        if host_only:
+            return
+        self.pack_idx = torch.from_numpy(self.pack_idx_np).to(dev)
+        self.unpack_idx = torch.from_numpy(self.unpack_idx_np).to(dev)
         self.wpack = torch.zeros(cur, dtype=torch.bfloat16, device=dev)
-        self.fpack_idx = torch.from_numpy(np.concatenate(fpack_idx).astype(np.int32)).to(dev) if fpack_idx else None
+        self.fpack_idx = torch.from_numpy(self.fpack_idx_np).to(dev) if fpack_idx else None
         self.fpack = torch.zeros(max(fcur, 8), dtype=torch.float32, device=dev)
         self.gsize = gcur
         self.gpack = torch.zeros(max(gcur, 8), dtype=torch.float32, device=dev)
         self.packed_version = -1
-
-    def _signature(self):
-        return (self.params[0].data_ptr(), self.params[-1].data_ptr(), len(self.params))
 
     def valid_for(self, module):
         ps = list(module.parameters())
