@@ -185,3 +185,19 @@ def test_g8_yolox_decode_and_nms():
     for i, o in enumerate(outs):
         if o is not None:
             np.testing.assert_array_equal(o, g[f"nms_out{i}"])
+
+
+def test_g9_map_v2():
+    """host-side metric mirror (yoloseries_amd/utils/mAP.py) against the reference's mAP_v2 on identical detections"""
+    from yoloseries_amd.utils.mAP import mAP_v2
+    g = load("g9_map.npz")
+    n = int(g["n"])
+    gts = [g[f"gt{i}"] for i in range(n)]
+    preds = [g[f"pred{i}"] for i in range(n)]
+    m = mAP_v2(gts, preds).compute_ap_per_class()
+    np.testing.assert_array_equal(m["unique_cls"], g["unique_cls"])
+    np.testing.assert_allclose(m["ap"], g["ap"], rtol=1e-12, atol=1e-12)
+    for k in ("precision", "recall", "f1"):
+        np.testing.assert_allclose(m[k], g[k], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(mAP_v2(gts, preds).get_mean_metrics(), g["mean"], rtol=1e-12)
+    assert g["mean"][1] > 0.1

@@ -425,6 +425,34 @@ def main():
             g8[f"nms_out{i}"] = np.asarray(r, np.float32)
     np.savez_compressed(os.path.join(OUT, "g8_yolox.npz"), **g8)
 
+    # ------------------------------------------------------------------ G9 mAP_v2
+    import tempfile
+    from utils.mAP import mAP_v2 as ref_map
+    rs9 = np.random.RandomState(97)
+    gts, preds = [], []
+    for i in range(12):
+        n = rs9.randint(0, 7)
+        c = rs9.uniform(50, 590, (n, 2)); wh = rs9.uniform(20, 200, (n, 2))
+        gt = np.concatenate([c - wh / 2, c + wh / 2, rs9.randint(0, 5, (n, 1))], 1).astype(np.float32)
+        pr = []
+        for row in gt:          # detections: jittered copies (some with wrong class) + false positives
+            for _ in range(rs9.randint(0, 3)):
+                box = row[:4] + rs9.uniform(-15, 15, 4)
+                pr.append(np.concatenate([box, [rs9.uniform(0.05, 1.0)], [row[4] if rs9.rand() < 0.8 else rs9.randint(0, 5)]]))
+        for _ in range(rs9.randint(0, 4)):
+            c2 = rs9.uniform(50, 590, 2); w2 = rs9.uniform(20, 120, 2)
+            pr.append(np.concatenate([c2 - w2 / 2, c2 + w2 / 2, [rs9.uniform(0.05, 0.6)], [rs9.randint(0, 5)]]))
+        gts.append(gt); preds.append(np.array(pr, np.float32).reshape(-1, 6))
+    with tempfile.TemporaryDirectory() as td:
+        mm = ref_map(gts, preds, td)
+        met = mm.compute_ap_per_class()
+        mean = ref_map(gts, preds, td).get_mean_metrics()
+    g9 = {"n": np.array(len(gts)), "ap": met["ap"], "precision": met["precision"], "recall": met["recall"], "f1": met["f1"],
+          "unique_cls": met["unique_cls"], "mean": np.array(mean, np.float64)}
+    for i, (a, b) in enumerate(zip(gts, preds)):
+        g9[f"gt{i}"] = a; g9[f"pred{i}"] = b
+    np.savez_compressed(os.path.join(OUT, "g9_map.npz"), **g9)
+
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden written:", sorted(os.listdir(OUT)), f"{total / 1e6:.2f} MB")
 

@@ -4,3 +4,4 @@ from .nms import *  # noqa: F401,F403
 from .layer_tools import *  # noqa: F401,F403
 from .optim import *  # noqa: F401,F403
 from .dist import *  # noqa: F401,F403
+from .mAP import mAP_v2  # noqa: F401
