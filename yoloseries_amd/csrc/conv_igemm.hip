@@ -16,6 +16,7 @@
 // so every global store is a 16-byte row chunk, and optionally emits per-channel
 // sum / sum-of-squares partials (training-mode BatchNorm statistics) per block.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,6 +32,10 @@ struct ConvK {
     // touches the taps whose parity matches, so no MFMA work is spent on structurally-zero taps
     int cls, Hc, Wc;
     int fast;      // every input segment has a multiple of 32 channels: tap-major incremental loader
+    int v2;        // lean buffer-load kernel eligible
+    unsigned segbytes[2], wbytes;   // addressable bytes from seg[i].ptr / w (hardware range check zero-fills beyond)
+    int pointwise; // 1x1 / stride 1 / no upsample: input pixel == output pixel
+    int dbg;       // YH_CONV_DBG ablation bits (timing experiments only): 1 skip A loads, 2 skip sC writes, 4 skip MFMA, 8 skip B loads
 };
 
 template <int BN, int WM, int WN, bool FAST, int MINW>
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (okr[i]) v = *reinterpret_cast<const uint4*>(sp + (size_t)(s1 ? pix1[i] : pix0[i]) * sld + cc);
+                if (okr[i] && !(p.dbg & 1)) v = *reinterpret_cast<const uint4*>(sp + (size_t)(s1 ? pix1[i] : pix0[i]) * sld + cc);
                 ra[i] = v;
             }
             const uint16_t* wp = d.w + (size_t)n0 * p.Ktot + kcol_base + c;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
             for (int i = 0; i < NBL; ++i) {
                 const int id = t + i * 256;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (id < BN * 4) v = *reinterpret_cast<const uint4*>(wp + (size_t)(id >> 2) * p.Ktot);
+                if (id < BN * 4 && !(p.dbg & 8)) v = *reinterpret_cast<const uint4*>(wp + (size_t)(id >> 2) * p.Ktot);
                 rb[i] = v;
             }
             if (++ld_cb == ncb) { ld_cb = 0; ++ld_tap; }
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        if (!(p.dbg & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
             if (more) store_tile(buf ^ 1);
             __syncthreads();
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
                     v = v * scl + sft;
                     if (d.act == YH_ACT_SILU) v = siluf_(v);
                     uint16_t hb16 = f2bf(v);
-                    sC[row * CP + c] = hb16;
+                    if (!(p.dbg & 2)) sC[row * CP + c] = hb16;
                     float vr = (m0 + row < p.M) ? bf2f(hb16) : 0.f;   // rows past M carry only the bias
                     s += vr; q += vr * vr;
                 }
@@ -336,6 +341,284 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: the same tiling, written for a minimal instruction count per k-tile.  Operands are fetched with raw
+// buffer loads: the per-lane byte offset of a tile row is computed once per TAP (not per k-tile), padding taps
+// and rows past M simply carry an out-of-range offset (the hardware range check returns zeros, no branches),
+// and the walk along the channels / along K is a SCALAR offset.  Eligible when every segment has a multiple
+// of 32 channels and every operand is smaller than 2 GiB (host check).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+template <int BN, int WM, int WN, int MINW, int EPI>   // EPI 0: plain store, 1: + BatchNorm partial sums, 2: generic epilogue
+__global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
+{
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr int NBL = (BN * 4 + 255) / 256;
+    constexpr int CP = BN + 8;
+    constexpr int MAIN_BYTES = (2 * (BM + BN) * LDSP * 2) > (BM * CP * 2) ? (2 * (BM + BN) * LDSP * 2) : (BM * CP * 2);
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* sA = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* sB = sA + 2 * BM * LDSP;
+    uint16_t* sC = reinterpret_cast<uint16_t*>(smem);
+    float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    int* sPix = reinterpret_cast<int*>(smem + MAIN_BYTES + WM * 2 * BN * 4);
+
+    const yh_conv_desc& d = p.d;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int kc = t & 3;
+    const int rowA = t >> 2;
+    const int n0 = blockIdx.y * BN;
+    const int HoWo = d.Ho * d.Wo;
+    const int sdmask = (1 << p.sdshift) - 1;
+    const int ph = p.cls ? (blockIdx.z >> 1) : 0, pw = p.cls ? (blockIdx.z & 1) : 0;
+    const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
+    const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
+    const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
+    const int ncb = p.Ctot >> 5;
+    const int nkt = nkh * nkw * ncb;
+    const int HcWc = p.Hc * p.Wc;
+    const int C0 = d.seg[0].C;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg[0].ptr, 0, p.segbytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d.nseg > 1 ? d.seg[1].ptr : d.seg[0].ptr), 0,
+                                                                          d.nseg > 1 ? p.segbytes[1] : p.segbytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, p.wbytes, 0x00020000);
+
+    // per-thread constants: weight row offsets, LDS addresses
+    unsigned voffB[NBL];
+#pragma unroll
+    for (int j = 0; j < NBL; ++j) {
+        const int id = t + j * 256;
+        voffB[j] = id < BN * 4 ? (unsigned)(((n0 + (id >> 2)) * p.Ktot + kc * 8) * 2) : OOB;
+    }
+    const int ldsA0 = rowA * LDSP + kc * 8;          // + 64*LDSP for the second row
+    const int ldsB0 = rowA * LDSP + kc * 8;          // row id>>2 == rowA (+64 per extra chunk)
+
+    float run_s = 0.f, run_q = 0.f;
+
+    for (int mt = blockIdx.x; mt < p.mtiles; mt += gridDim.x) {
+        const int m0 = mt * BM;
+        int hb[2], wb[2], img[2];
+        unsigned voff0[2], voff1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + rowA + 64 * i;
+            voff0[i] = OOB; voff1[i] = OOB;
+            img[i] = 0; hb[i] = -(1 << 28); wb[i] = -(1 << 28);
+            if (m < p.M) {
+                if (p.pointwise) {
+                    voff0[i] = (unsigned)m * (unsigned)(d.seg[0].ld * 2) + kc * 16;
+                    voff1[i] = (unsigned)m * (unsigned)(d.seg[1].ld * 2) + kc * 16;
+                } else {
+                    int im, ho, wo;
+                    if (p.cls) {
+                        im = m / HcWc;
+                        const int rem = m - im * HcWc;
+                        const int ii = rem / p.Wc;
+                        ho = 2 * ii + ph; wo = 2 * (rem - ii * p.Wc) + pw;
+                    } else {
+                        im = m / HoWo;
+                        const int rem = m - im * HoWo;
+                        ho = rem / d.Wo;
+                        wo = rem - ho * d.Wo;
+                    }
+                    img[i] = im; hb[i] = ho * p.sa + p.sc; wb[i] = wo * p.sa + p.sc;
+                    if (p.cls && kc == 0) sPix[rowA + 64 * i] = (im * d.Ho + ho) * d.Wo + wo;
+                }
+            }
+        }
+
+        f32x16_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        u32x4_t ra[2], rb[NBL];
+        int ld_tap = 0, ld_cb = 0, kcol_base = 0;
+
+        auto tap_setup = [&](int tapl) {
+            int kh = tapl / nkw;
+            int kw = tapl - kh * nkw;
+            if (p.cls) { kh = kh0 + 2 * kh; kw = kw0 + 2 * kw; }
+            kcol_base = (kh * d.KW + kw) * p.Ctot;
+            if (p.pointwise) return;
+            const int u0 = d.seg[0].ups, u1 = d.seg[1].ups;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hn = hb[i] + kh * p.sb;
+                const int wn_ = wb[i] + kw * p.sb;
+                bool ok = hn >= 0 && wn_ >= 0 && (((hn | wn_) & sdmask) == 0);
+                const int hs = hn >> p.sdshift, ws = wn_ >> p.sdshift;
+                ok = ok && hs < d.Hi && ws < d.Wi;
+                const unsigned pix0 = (unsigned)((img[i] * (d.Hi >> u0) + (hs >> u0)) * (d.Wi >> u0) + (ws >> u0));
+                const unsigned pix1 = (unsigned)((img[i] * (d.Hi >> u1) + (hs >> u1)) * (d.Wi >> u1) + (ws >> u1));
+                voff0[i] = ok ? pix0 * (unsigned)(d.seg[0].ld * 2) + kc * 16 : OOB;
+                voff1[i] = ok ? pix1 * (unsigned)(d.seg[1].ld * 2) + kc * 16 : OOB;
+            }
+        };
+        auto load_tile = [&]() {
+            if (ld_cb == 0) tap_setup(ld_tap);
+            const int c = ld_cb * 32;
+            const bool s1 = d.nseg > 1 && c >= C0;           // wave-uniform
+            if (s1) {
+                const int so = (c - C0) * 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs1, voff1[i], so, 0);
+            } else {
+                const int so = c * 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, voff0[i], so, 0);
+            }
+            const int sw = (kcol_base + c) * 2;
+#pragma unroll
+            for (int j = 0; j < NBL; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffB[j], sw, 0);
+            if (++ld_cb == ncb) { ld_cb = 0; ++ld_tap; }
+        };
+        auto store_tile = [&](int buf) {
+            uint16_t* a = sA + buf * BM * LDSP + ldsA0;
+            uint16_t* b = sB + buf * BN * LDSP + ldsB0;
+            *reinterpret_cast<u32x4_t*>(a) = ra[0];
+            *reinterpret_cast<u32x4_t*>(a + 64 * LDSP) = ra[1];
+#pragma unroll
+            for (int j = 0; j < NBL; ++j)
+                if (t + j * 256 < BN * 4) *reinterpret_cast<u32x4_t*>(b + j * 64 * LDSP) = rb[j];
+        };
+
+        load_tile();
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            const bool more = (kt + 1) < nkt;
+            if (more) load_tile();
+            const uint16_t* a = sA + buf * BM * LDSP;
+            const uint16_t* b = sB + buf * BN * LDSP;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t af[TM], bfr[TN];
+                const int koff = (ks * 2 + (lane >> 5)) * 8;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + (wm * (TM * 32) + i * 32 + (lane & 31)) * LDSP + koff));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + (wn * (TN * 32) + j * 32 + (lane & 31)) * LDSP + koff));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+
+        // ---- epilogue
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = wn * (TN * 32) + j * 32 + (lane & 31);
+            float bs = 0.f, scl = 1.f, sft = 0.f;
+            if (EPI == 2) {
+                const int n = n0 + c;
+                const bool nv = n < d.N;
+                bs = (d.bias && nv) ? d.bias[n] : 0.f;
+                scl = (d.scale && nv) ? d.scale[n] : 1.f;
+                sft = (d.shift && nv) ? d.shift[n] : 0.f;
+            }
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                uint16_t* dst = sC + (wm * (TM * 32) + i * 32 + 4 * (lane >> 5)) * CP + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (EPI == 2) {
+                        v = (v + bs) * scl + sft;
+                        if (d.act == YH_ACT_SILU) v = siluf_(v);
+                    }
+                    dst[((r & 3) + 8 * (r >> 2)) * CP] = f2bf(v);
+                    if (EPI == 1) { s += v; q += v * v; }      // rows past M and padded channels are exact zeros
+                }
+            }
+            if (EPI == 1) {
+                s += __shfl_xor(s, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (lane < 32) {
+                    sStat[(wm * 2 + 0) * BN + c] = s;
+                    sStat[(wm * 2 + 1) * BN + c] = q;
+                }
+            }
+        }
+        __syncthreads();
+
+        constexpr int CPR = BN / 8;
+        constexpr int NCH = BM * CPR / 256;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = t + i * 256;
+            const int row = id / CPR;
+            const int cch = id - row * CPR;
+            const int m = m0 + row;
+            const int n = n0 + cch * 8;
+            if (m < p.M && n < d.N) {
+                uint4 v = *reinterpret_cast<const uint4*>(sC + row * CP + cch * 8);
+                const size_t orow = p.cls ? (size_t)sPix[row] : (size_t)m;
+                if (EPI == 2) {
+                    uint16_t* dst;
+                    const bool first = n < d.nsplit;
+                    if (first) dst = d.out0 + orow * d.ld0 + n;
+                    else       dst = d.out1 + orow * d.ld1 + (n - d.nsplit);
+                    const bool addres = (d.res != nullptr) && first;
+                    if (addres || d.accumulate) {
+                        float f[8];
+                        unpack8(v, f);
+                        if (addres) {
+                            uint4 rv = *reinterpret_cast<const uint4*>(d.res + orow * d.ldr + n);
+                            float g[8]; unpack8(rv, g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        }
+                        if (d.accumulate) {
+                            uint4 ov = *reinterpret_cast<const uint4*>(dst);
+                            float g[8]; unpack8(ov, g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        }
+                        v = pack8(f);
+                    }
+                    *reinterpret_cast<uint4*>(dst) = v;
+                } else {
+                    *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
+                }
+            }
+        }
+        if (EPI == 1 && t < BN) {
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                run_s += sStat[(w * 2 + 0) * BN + t];
+                run_q += sStat[(w * 2 + 1) * BN + t];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (EPI == 1 && t < BN) {
+        d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
+        d.stats[((size_t)blockIdx.x * 2 + 1) * d.Npad + n0 + t] = run_q;
+    }
+}
+
 template <int BN, int WM, int WN>
 constexpr size_t conv_smem_bytes() {
     size_t a = 2 * (BM + BN) * LDSP * 2;
@@ -350,7 +633,10 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
     int mtiles = (int)((M + BM - 1) / BM);
     int b = pick_bn(d->N);
     int nt = (d->N + b - 1) / b;
-    int cap = 1024 / nt;     // also bounds the number of BatchNorm partial-sum rows the finalize kernel reduces
+    // persistent blocks: exactly one resident wave of blocks (256 CUs x blocks/CU of this instantiation), so there is
+    // no partially filled second round; also bounds the BatchNorm partial-sum rows the finalize kernel reduces
+    const int occ = b == 32 ? 4 : (b == 64 ? 3 : 2);
+    int cap = (256 * occ) / nt;
     cap = (cap / 8) * 8;
     if (cap < 8) cap = 8;
     int g = mtiles < cap ? mtiles : cap;
@@ -410,6 +696,7 @@ extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream)
     else { k.sa = 1; k.sb = -1; k.sc = d->pad; k.sdshift = d->stride == 2 ? 1 : 0; }
     if (k.d.nsplit > k.d.N) k.d.nsplit = k.d.N + 8;   // everything goes to out0
     k.fast = 1;
+    { const char* e = getenv("YH_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
     for (int s2 = 0; s2 < d->nseg; ++s2) if (d->seg[s2].C % 32) k.fast = 0;
     if ((long)d->B * d->Hi * d->Wi >= (1L << 31)) k.fast = 0;
     k.cls = 0; k.Hc = d->Ho; k.Wc = d->Wo;
@@ -424,6 +711,50 @@ extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream)
     YH_CHECK_ARG(gy * bn <= d->Npad, "yh_conv_igemm: Npad too small for tile");
     if (k.cls) { gx = (gx + 3) / 4; if (gx > k.mtiles) gx = k.mtiles; }
     dim3 grid(gx, gy, k.cls ? 4 : 1), block(256);
+    // ---- lean buffer-load kernel
+    k.v2 = k.fast && !(k.dbg & 16);
+    k.pointwise = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !k.cls) ? 1 : 0;
+    for (int s2 = 0; s2 < 2; ++s2) {
+        k.segbytes[s2] = 0;
+        if (s2 < d->nseg) {
+            const yh_seg& g = d->seg[s2];
+            if (g.ups) k.pointwise = 0;
+            const unsigned long npix = (unsigned long)d->B * (d->Hi >> g.ups) * (d->Wi >> g.ups);
+            const unsigned long bytes = ((npix - 1) * g.ld + g.C) * 2;
+            if (bytes >= (1ul << 31)) k.v2 = 0;
+            k.segbytes[s2] = (unsigned)bytes;
+        }
+    }
+    {
+        const unsigned long wb = (unsigned long)d->Npad * k.Ktot * 2;
+        if (wb >= (1ul << 31)) k.v2 = 0;
+        k.wbytes = (unsigned)wb;
+    }
+    if (d->nseg == 1) { k.d.seg[1] = k.d.seg[0]; }
+    if (k.v2) {
+        hipStream_t st2 = (hipStream_t)stream;
+        const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || k.d.nsplit < d->N;
+        const int epi = generic ? 2 : (d->stats ? 1 : 0);
+        if (generic && d->stats) k.v2 = 0;        // statistics of an affine/activated output: generic kernel only
+    }
+    if (k.v2) {
+        hipStream_t st2 = (hipStream_t)stream;
+        const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || k.d.nsplit < d->N;
+        const int epi = generic ? 2 : (d->stats ? 1 : 0);
+#define YH_LAUNCH_V2(BN_, WM_, WN_, MINW_)                                                                     \
+        do {                                                                                                   \
+            const size_t sm = conv_smem_bytes<BN_, WM_, WN_>();                                                \
+            if (epi == 2)      conv_v2_kernel<BN_, WM_, WN_, MINW_, 2><<<grid, block, sm, st2>>>(k);           \
+            else if (epi == 1) conv_v2_kernel<BN_, WM_, WN_, MINW_, 1><<<grid, block, sm, st2>>>(k);           \
+            else               conv_v2_kernel<BN_, WM_, WN_, MINW_, 0><<<grid, block, sm, st2>>>(k);           \
+        } while (0)
+        if (bn == 32) YH_LAUNCH_V2(32, 4, 1, 4);
+        else if (bn == 64) YH_LAUNCH_V2(64, 4, 1, 3);
+        else YH_LAUNCH_V2(128, 2, 2, 2);
+#undef YH_LAUNCH_V2
+        YH_CHECK_LAUNCH("yh_conv_igemm(v2)");
+        return YH_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
 #define YH_LAUNCH_CONV(BN_, WM_, WN_, MINW_)                                                                  \
     do {                                                                                                      \
