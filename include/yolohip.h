@@ -111,6 +111,9 @@ typedef struct yh_wgrad_desc {
     int32_t  splits;                  /* split of the M (pixel) reduction, >=1      */
 } yh_wgrad_desc;
 int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
+/* number of (out-channel x im2col-column) tiles the kernel uses for a layer; callers size `splits` so that
+ * tiles*splits is about one resident wave of blocks */
+int yh_conv_wgrad_tiles(int N, int Kseg);
 
 /* ------------------------------------------------------------------------ *
  * BatchNorm (training statistics) + SiLU, forward and backward

@@ -102,6 +102,7 @@ _SIGS = {
     "yh_conv_stat_blocks": (_i32, [C.POINTER(ConvDesc)]),
     "yh_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp]),
     "yh_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
+    "yh_conv_wgrad_tiles": (_i32, [_i32, _i32]),
     "yh_bn_finalize": (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
     "yh_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
     "yh_bn_silu_apply": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),

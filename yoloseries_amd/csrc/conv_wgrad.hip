@@ -4,24 +4,29 @@
 //
 // i.e. the GEMM  gy^T (N x M)  *  im2col(X) (M x K): both operands have the reduction index m
 // (output pixel) as their slow memory axis.  Tiles are staged in their natural [pixel][channel]
-// layout with 16-byte ds_write_b128 (row pitch == 64 B mod 256 B) and the MFMA fragments — which
+// layout with 16-byte ds_write_b128 (row pitch == 64/192 B mod 256 B) and the MFMA fragments — which
 // need 8 consecutive PIXELS per lane — are formed by ds_read_b64_tr_b16 (the CDNA4 transposing LDS
-// read), so no element-wise transposition is ever executed.  The pixel reduction is split over
-// blockIdx.y; partial tiles are added with fp32 atomics (two 128-byte row segments per wave
-// instruction).  Two tilings:
+// read), so no element-wise transposition is ever executed.  Operands are fetched with raw buffer
+// loads: per-lane offsets are fixed per thread, the walk along the pixels is a scalar offset, rows past
+// the split and padding taps carry an out-of-range offset (hardware zero fill, no branches).
+// The pixel reduction is split over blockIdx.y; partial tiles are added with fp32 atomics (two
+// 128-byte row segments per wave instruction).  Tilings:
 //   wide    (K <= 384: stem, 3x3x32 and most 1x1 layers) one block covers ALL im2col columns, so gy
 //           is read once and the 9 taps of a pixel are gathered by the same block (L1/L2 hits);
-//   general 64 x 64 tiles, 64 pixels per k-step.
+//   general 128 x 128 (or 64 x 128) tiles, 64 pixels per k-step, one column tile per block.
 // Replaces autograd's conv weight gradient (train_yolov5.py:337).
 #include "common.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short v4s;
+typedef __attribute__((ext_vector_type(8))) short v8s;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 struct WgK {
     yh_wgrad_desc d;
-    int M, Ktot, Kseg, rows_per_split, ctiles;
+    int M, Ktot, Kseg, rows_per_split, ctiles, pointwise;
+    unsigned gybytes, xbytes;
 };
 
 // transposing read: 16-lane group reads a 4(row) x 16(col) block of 16-bit elements; lane i of the group gets
@@ -33,8 +38,8 @@ __device__ __forceinline__ v4s tr_read(const uint16_t* p) {
 constexpr int wg_pitch(int cols) { return (cols % 64 == 32) ? cols : cols + 32; }
 
 // WN x WC waves, each wave computes (TNW*32) x (TCW*32); TK pixels per k-step
-template <int WN, int WC, int TNW, int TCW, int TK>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p)
+template <int WN, int WC, int TNW, int TCW, int TK, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_wgrad_kernel(const WgK p)
 {
     constexpr int TN = WN * TNW * 32;             // out-channel rows of the tile
     constexpr int TCOLS = WC * TCW * 32;          // im2col columns of the tile
@@ -47,6 +52,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p)
     constexpr int ACH = (TN / 8 + TPR - 1) / TPR; // A chunks per thread
     constexpr int BCH = (TCOLS / 8) / TPR;        // B chunks per thread
     static_assert((TCOLS / 8) % TPR == 0, "column chunks must divide over the row's threads");
+    constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* sA = reinterpret_cast<uint16_t*>(smem);           // [2][TK][PA]
@@ -72,17 +78,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p)
     const int Hs = d.Hi >> ups, Ws = d.Wi >> ups;
     const int C = d.seg.C;
 
-    // per-thread column chunks: (tap, channel) is fixed for the whole reduction
-    int bkh[BCH], bkw[BCH], bc[BCH];
-    bool bok[BCH];
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)d.gy, 0, p.gybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg.ptr, 0, p.xbytes, 0x00020000);
+
+    // per-thread constants
+    unsigned voffA[ACH];
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+        const int ch = (sub + TPR * j) * 8;
+        voffA[j] = (ch < TN && n0 + ch < d.N) ? (unsigned)((row * d.ldg + n0 + ch) * 2) : OOB;
+    }
+    int bkh[BCH], bkw[BCH];
+    unsigned bcoff[BCH];              // byte offset of the chunk's channel inside a pixel (OOB when the column is padding)
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
         const int col = col0 + (sub + TPR * j) * 8;
-        bok[j] = col < p.Kseg;
-        const int tap = bok[j] ? col / C : 0;
-        bc[j] = col - tap * C;
+        const bool ok = col < p.Kseg;
+        const int tap = ok ? col / C : 0;
+        bcoff[j] = ok ? (unsigned)((col - tap * C) * 2) : OOB;
         bkh[j] = tap / d.KW;
         bkw[j] = tap - bkh[j] * d.KW;
+        if (p.pointwise && ok) bcoff[j] += (unsigned)(row * d.seg.ld * 2);
     }
 
     f32x16_t acc[TNW][TCW];
@@ -93,46 +109,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[ACH], rb[BCH];
+    u32x4_t ra[ACH], rb[BCH];
     auto load_tile = [&](int kt) {
-        const int m = mbeg + kt * TK + row;
-        const bool mv = m < mend;
+        const int mb = mbeg + kt * TK;             // scalar
+        const bool mv = mb + row < mend;
+        const unsigned sg = (unsigned)mb * (unsigned)(d.ldg * 2);
 #pragma unroll
-        for (int j = 0; j < ACH; ++j) {
-            const int ch = (sub + TPR * j) * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (mv && ch < TN && n0 + ch < d.N) v = *reinterpret_cast<const uint4*>(d.gy + (size_t)m * d.ldg + n0 + ch);
-            ra[j] = v;
-        }
-        int im = 0, hb = 0, wb = 0;
-        if (mv) {
-            im = m / HoWo;
-            const int rem = m - im * HoWo;
-            const int ho = rem / d.Wo;
-            hb = ho * d.stride - d.pad;
-            wb = (rem - ho * d.Wo) * d.stride - d.pad;
-        }
+        for (int j = 0; j < ACH; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsg, mv ? voffA[j] : OOB, sg, 0);
+        if (p.pointwise) {
+            const unsigned sx = (unsigned)mb * (unsigned)(d.seg.ld * 2);
 #pragma unroll
-        for (int j = 0; j < BCH; ++j) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int hi = hb + bkh[j], wi = wb + bkw[j];
-            if (mv && bok[j] && hi >= 0 && wi >= 0 && hi < d.Hi && wi < d.Wi) {
-                const size_t pix = ((size_t)im * Hs + (hi >> ups)) * Ws + (wi >> ups);
-                v = *reinterpret_cast<const uint4*>(d.seg.ptr + pix * d.seg.ld + bc[j]);
+            for (int j = 0; j < BCH; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsx, mv ? bcoff[j] : OOB, sx, 0);
+        } else {
+            const int m = mb + row;
+            int im = 0, hb = -(1 << 28), wb = -(1 << 28);
+            if (mv) {
+                im = m / HoWo;
+                const int rem = m - im * HoWo;
+                const int ho = rem / d.Wo;
+                hb = ho * d.stride - d.pad;
+                wb = (rem - ho * d.Wo) * d.stride - d.pad;
             }
-            rb[j] = v;
+#pragma unroll
+            for (int j = 0; j < BCH; ++j) {
+                const int hi = hb + bkh[j], wi = wb + bkw[j];
+                const bool ok = hi >= 0 && wi >= 0 && hi < d.Hi && wi < d.Wi && bcoff[j] != OOB;
+                const unsigned pix = (unsigned)((im * Hs + (hi >> ups)) * Ws + (wi >> ups));
+                rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? pix * (unsigned)(d.seg.ld * 2) + bcoff[j] : OOB, 0, 0);
+            }
         }
     };
+    uint16_t* const stA = sA + row * PA + sub * 8;
+    uint16_t* const stB = sB + row * PB + sub * 8;
     auto store_tile = [&](int buf) {
-        uint16_t* a = sA + buf * TK * PA + row * PA;
-        uint16_t* b = sB + buf * TK * PB + row * PB;
 #pragma unroll
-        for (int j = 0; j < ACH; ++j) {
-            const int ch = (sub + TPR * j) * 8;
-            if (ch < TN) *reinterpret_cast<uint4*>(a + ch) = ra[j];
-        }
+        for (int j = 0; j < ACH; ++j)
+            if ((sub + TPR * j) * 8 < TN) *reinterpret_cast<u32x4_t*>(stA + buf * TK * PA + TPR * j * 8) = ra[j];
 #pragma unroll
-        for (int j = 0; j < BCH; ++j) *reinterpret_cast<uint4*>(b + (sub + TPR * j) * 8) = rb[j];
+        for (int j = 0; j < BCH; ++j) *reinterpret_cast<u32x4_t*>(stB + buf * TK * PB + TPR * j * 8) = rb[j];
     };
 
     // fragment addressing for the transposing reads (see tr_read)
@@ -140,6 +154,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p)
     const int q = i16 >> 2, pp = i16 & 3;
     const int frag_row = 8 * (g16 >> 1) + q;               // + 16*ks + 4*r
     const int frag_col = 16 * (g16 & 1) + 4 * pp;          // + 32*tile
+    const uint16_t* const fa = sA + frag_row * PA + wn * TNW * 32 + frag_col;
+    const uint16_t* const fb = sB + frag_row * PB + wc * TCW * 32 + frag_col;
 
     load_tile(0);
     store_tile(0);
@@ -148,28 +164,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgK p)
         const int buf = kt & 1;
         const bool more = (kt + 1) < nkt;
         if (more) load_tile(kt + 1);
-        const uint16_t* a = sA + buf * TK * PA;
-        const uint16_t* b = sB + buf * TK * PB;
+        const uint16_t* a = fa + buf * TK * PA;
+        const uint16_t* b = fb + buf * TK * PB;
 #pragma unroll
         for (int ks = 0; ks < TK / 16; ++ks) {
             bf16x8_t af[TNW], bfr[TCW];
-            const int r0 = ks * 16 + frag_row;
 #pragma unroll
             for (int i = 0; i < TNW; ++i) {
-                const uint16_t* base = a + r0 * PA + (wn * TNW + i) * 32 + frag_col;
-                v4s lo = tr_read(base);
-                v4s hi = tr_read(base + 4 * PA);
-                typedef __attribute__((ext_vector_type(8))) short v8s;
-                v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const uint16_t* base = a + ks * 16 * PA + i * 32;
+                const v4s lo = tr_read(base);
+                const v4s hi = tr_read(base + 4 * PA);
+                const v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 af[i] = __builtin_bit_cast(bf16x8_t, v);
             }
 #pragma unroll
             for (int j = 0; j < TCW; ++j) {
-                const uint16_t* base = b + r0 * PB + (wc * TCW + j) * 32 + frag_col;
-                v4s lo = tr_read(base);
-                v4s hi = tr_read(base + 4 * PB);
-                typedef __attribute__((ext_vector_type(8))) short v8s;
-                v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const uint16_t* base = b + ks * 16 * PB + j * 32;
+                const v4s lo = tr_read(base);
+                const v4s hi = tr_read(base + 4 * PB);
+                const v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 bfr[j] = __builtin_bit_cast(bf16x8_t, v);
             }
 #pragma unroll
@@ -208,6 +221,14 @@ constexpr size_t wg_smem() {
 
 }  // namespace
 
+/* tile the kernel will use for a layer: rows (out channels) x im2col columns per block; used by the host to size `splits` */
+extern "C" int yh_conv_wgrad_tiles(int N, int Kseg)
+{
+    if (Kseg <= 384) return N <= 32 ? (N + 31) / 32 : (N + 63) / 64;
+    const int tn = N <= 64 ? 64 : 128;
+    return ((N + tn - 1) / tn) * ((Kseg + 127) / 128);
+}
+
 extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
 {
     YH_CHECK_ARG(d != nullptr, "yh_conv_wgrad: null desc");
@@ -228,6 +249,13 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     k.M = (int)M;
     k.Ktot = d->KH * d->KW * d->Ctot;
     k.Kseg = d->KH * d->KW * d->seg.C;          // im2col columns of THIS segment
+    const unsigned long gyb = ((unsigned long)(M - 1) * d->ldg + ((d->N + 7) / 8) * 8) * 2;
+    const unsigned long npix = (unsigned long)d->B * (d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups);
+    const unsigned long xb = ((npix - 1) * d->seg.ld + d->seg.C) * 2;
+    YH_CHECK_ARG(gyb < (1ul << 31) && xb < (1ul << 31), "yh_conv_wgrad: operands of 2 GiB or more are not supported");
+    k.gybytes = (unsigned)gyb;
+    k.xbytes = (unsigned)xb;
+    k.pointwise = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->seg.ups) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = k.Kseg <= 384;
     const int TK = wide ? 32 : 64;
@@ -237,33 +265,24 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     k.rows_per_split = rps;
     splits = (int)((M + rps - 1) / rps);
     YH_CHECK_ARG(splits <= 65535, "yh_conv_wgrad: too many splits");
+#define YH_WG(WN_, WC_, TNW_, TCW_, TK_, MINW_, NT_)                                                            \
+    do {                                                                                                        \
+        dim3 grid((NT_) * k.ctiles, splits);                                                                    \
+        conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_><<<grid, dim3(256), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
+    } while (0)
     if (wide) {
-        if (d->N <= 32 && k.Kseg <= 256) {
-            k.ctiles = 1;
-            dim3 grid(((d->N + 31) / 32) * k.ctiles, splits);
-            conv_wgrad_kernel<1, 4, 1, 2, 32><<<grid, dim3(256), wg_smem<1, 4, 1, 2, 32>(), st>>>(k);
-        } else if (d->N <= 32) {
-            k.ctiles = 1;
-            dim3 grid(((d->N + 31) / 32) * k.ctiles, splits);
-            conv_wgrad_kernel<1, 4, 1, 3, 32><<<grid, dim3(256), wg_smem<1, 4, 1, 3, 32>(), st>>>(k);
-        } else if (k.Kseg <= 128) {
-            k.ctiles = 1;
-            dim3 grid(((d->N + 63) / 64) * k.ctiles, splits);
-            conv_wgrad_kernel<1, 4, 2, 1, 32><<<grid, dim3(256), wg_smem<1, 4, 2, 1, 32>(), st>>>(k);
-        } else if (k.Kseg <= 256) {
-            k.ctiles = 1;
-            dim3 grid(((d->N + 63) / 64) * k.ctiles, splits);
-            conv_wgrad_kernel<1, 4, 2, 2, 32><<<grid, dim3(256), wg_smem<1, 4, 2, 2, 32>(), st>>>(k);
-        } else {
-            k.ctiles = 1;
-            dim3 grid(((d->N + 63) / 64) * k.ctiles, splits);
-            conv_wgrad_kernel<1, 4, 2, 3, 32><<<grid, dim3(256), wg_smem<1, 4, 2, 3, 32>(), st>>>(k);
-        }
+        k.ctiles = 1;
+        if (d->N <= 32 && k.Kseg <= 256) YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32);
+        else if (d->N <= 32)             YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32);
+        else if (k.Kseg <= 128)          YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64);
+        else if (k.Kseg <= 256)          YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64);
+        else                             YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64);
     } else {
-        k.ctiles = (k.Kseg + 63) / 64;
-        dim3 grid(((d->N + 63) / 64) * k.ctiles, splits);
-        conv_wgrad_kernel<2, 2, 1, 1, 64><<<grid, dim3(256), wg_smem<2, 2, 1, 1, 64>(), st>>>(k);
+        k.ctiles = (k.Kseg + 127) / 128;
+        if (d->N <= 64) YH_WG(2, 2, 1, 2, 64, 3, (d->N + 63) / 64);
+        else            YH_WG(2, 2, 2, 2, 64, 2, (d->N + 127) / 128);
     }
+#undef YH_WG
     YH_CHECK_LAUNCH("yh_conv_wgrad");
     return YH_OK;
 }

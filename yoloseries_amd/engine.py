@@ -535,12 +535,8 @@ class Program:
                 wd.KH = wd.KW = op.k
                 wd.stride, wd.pad = op.stride, op.pad
                 wd.dw = gdw
-                kseg = op.k * op.k * sg.C
-                if kseg <= 384:          # "wide" tiling of csrc/conv_wgrad.hip: one block covers every im2col column
-                    ntile = (gyN + 31) // 32 if gyN <= 32 else (gyN + 63) // 64
-                else:
-                    ntile = ((gyN + 63) // 64) * ((kseg + 63) // 64)
-                wd.splits = max(1, min((M + 255) // 256, (1024 + ntile - 1) // ntile))
+                ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
+                wd.splits = max(1, min((M + 255) // 256, (768 + ntile - 1) // ntile))
                 self._keep.append(wd)
                 cmds.append(('wgrad', op, wd, ('conv_wgrad_kernel', 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
                 coff_k += sg.C
