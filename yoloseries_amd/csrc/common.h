@@ -26,17 +26,29 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
     f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
     f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
+// two floats -> packed bf16 pair (lo in bits 0..15), one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    f32x2_t v = {lo, hi};
+    bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, b);
+}
 __device__ __forceinline__ uint4 pack8(const float* f) {
     uint4 v;
-    v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-    v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-    v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-    v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    v.x = pack2(f[0], f[1]);
+    v.y = pack2(f[2], f[3]);
+    v.z = pack2(f[4], f[5]);
+    v.w = pack2(f[6], f[7]);
     return v;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+// approximate-reciprocal variants (v_exp_f32 + v_rcp_f32, ~1 ulp each) for the bf16 activation path;
+// the loss / assignment kernels keep the IEEE-division forms above
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_fast(float x) { return x * sigmoid_fast(x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
                     int row = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     float v = acc[i][j][r] + bs;
                     v = v * scl + sft;
-                    if (d.act == YH_ACT_SILU) v = siluf_(v);
+                    if (d.act == YH_ACT_SILU) v = silu_fast(v);
                     uint16_t hb16 = f2bf(v);
                     if (!(p.dbg & 2)) sC[row * CP + c] = hb16;
                     float vr = (m0 + row < p.M) ? bf2f(hb16) : 0.f;   // rows past M carry only the bias
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
                     float v = acc[i][j][r];
                     if (EPI == 2) {
                         v = (v + bs) * scl + sft;
-                        if (d.act == YH_ACT_SILU) v = siluf_(v);
+                        if (d.act == YH_ACT_SILU) v = silu_fast(v);
                     }
                     dst[((r & 3) + 8 * (r >> 2)) * CP] = f2bf(v);
                     if (EPI == 1) { s += v; q += v * v; }      // rows past M and padded channels are exact zeros
@@ -731,15 +731,10 @@ extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream)
         k.wbytes = (unsigned)wb;
     }
     if (d->nseg == 1) { k.d.seg[1] = k.d.seg[0]; }
+    const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || k.d.nsplit < d->N;
+    if (generic && d->stats) k.v2 = 0;            // statistics of an affine/activated output: generic kernel only
     if (k.v2) {
         hipStream_t st2 = (hipStream_t)stream;
-        const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || k.d.nsplit < d->N;
-        const int epi = generic ? 2 : (d->stats ? 1 : 0);
-        if (generic && d->stats) k.v2 = 0;        // statistics of an affine/activated output: generic kernel only
-    }
-    if (k.v2) {
-        hipStream_t st2 = (hipStream_t)stream;
-        const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || k.d.nsplit < d->N;
         const int epi = generic ? 2 : (d->stats ? 1 : 0);
 #define YH_LAUNCH_V2(BN_, WM_, WN_, MINW_)                                                                     \
         do {                                                                                                   \

@@ -91,24 +91,27 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
 }
 
 // ---------------------------------------------------------------- BN+SiLU apply
+// Grid-stride over 16-byte chunks with a stride that is a multiple of the chunks per row, so a thread
+// keeps its 8 channels for the whole pass and the per-channel constants live in registers.
 __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, const float* __restrict__ ws, int C, int cpr,
-                                     long nchunks, uint16_t* __restrict__ out, int ldo,
+                                     long M, uint16_t* __restrict__ out, int ldo,
                                      const uint16_t* __restrict__ res, int ldr)
 {
-    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < nchunks; id += (long)gridDim.x * blockDim.x) {
-        long m = id / cpr;
-        int c = (int)(id - m * cpr) * 8;
+    const long T = (long)gridDim.x * blockDim.x;
+    const long rstep = T / cpr;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rstep * cpr) return;
+    long m = gid / cpr;
+    const int c = (int)(gid - m * cpr) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = ws[c + e]; sh[e] = ws[C + c + e]; }
+    for (; m < M; m += rstep) {
         uint4 v = *reinterpret_cast<const uint4*>(y + m * ldy + c);
         float f[8];
         unpack8(v, f);
-        const float4 s0 = *reinterpret_cast<const float4*>(ws + c);
-        const float4 s1 = *reinterpret_cast<const float4*>(ws + c + 4);
-        const float4 h0 = *reinterpret_cast<const float4*>(ws + C + c);
-        const float4 h1 = *reinterpret_cast<const float4*>(ws + C + c + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = siluf_(f[e] * sc[e] + sh[e]);
+        for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e] * sc[e] + sh[e]);
         if (res) {
             uint4 rv = *reinterpret_cast<const uint4*>(res + m * ldr + c);
             float g[8];
@@ -124,15 +127,17 @@ __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, co
 // ---------------------------------------------------------------- column reductions
 // Block b owns rows [b*rpb, (b+1)*rpb).  Thread (rg, cch) accumulates 8 channels over
 // rows rg, rg+RG, ...; row groups are combined through LDS.
+constexpr int RED_THREADS = 512;
+
 template <int MODE>   // 0: BN+SiLU backward sums (gz, gz*xhat) ; 1: plain column sum of g
-__global__ __launch_bounds__(EW_THREADS) void col_reduce_kernel(const uint16_t* __restrict__ ga, int ldga,
-                                                                const uint16_t* __restrict__ y, int ldy,
-                                                                const float* __restrict__ ws, int C, int cpr,
-                                                                long M, long rpb, float* __restrict__ part)
+__global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const uint16_t* __restrict__ ga, int ldga,
+                                                                 const uint16_t* __restrict__ y, int ldy,
+                                                                 const float* __restrict__ ws, int C, int cpr,
+                                                                 long M, long rpb, float* __restrict__ part)
 {
-    __shared__ float sP[EW_THREADS * 16];
+    __shared__ float sP[RED_THREADS * 16];
     const int t = threadIdx.x;
-    const int RG = EW_THREADS / cpr;
+    const int RG = RED_THREADS / cpr;
     const int rg = t / cpr;
     const int cch = t - rg * cpr;
     const int c = cch * 8;
@@ -140,36 +145,55 @@ __global__ __launch_bounds__(EW_THREADS) void col_reduce_kernel(const uint16_t* 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
     if (rg < RG) {
-        float sc[8], sh[8], mu[8], is[8];
+        // z = y*sc + sh ; xhat = y*is - mu*is
+        float sc[8], sh[8], is[8], mi[8];
         if (MODE == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { sc[e] = ws[c + e]; sh[e] = ws[C + c + e]; mu[e] = ws[2 * C + c + e]; is[e] = ws[3 * C + c + e]; }
+            for (int e = 0; e < 8; ++e) {
+                sc[e] = ws[c + e]; sh[e] = ws[C + c + e]; is[e] = ws[3 * C + c + e]; mi[e] = ws[2 * C + c + e] * is[e];
+            }
         }
-        long r0 = (long)blockIdx.x * rpb;
-        long r1 = min(M, r0 + rpb);
-        for (long m = r0 + rg; m < r1; m += RG) {
-            uint4 gv = *reinterpret_cast<const uint4*>(ga + m * ldga + c);
+        const long r0 = (long)blockIdx.x * rpb;
+        const long r1 = min(M, r0 + rpb);
+        auto accum = [&](const uint4& gv, const uint4& yv) {
             float g[8];
             unpack8(gv, g);
             if (MODE == 0) {
-                uint4 yv = *reinterpret_cast<const uint4*>(y + m * ldy + c);
                 float yy[8];
                 unpack8(yv, yy);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float z = yy[e] * sc[e] + sh[e];
-                    float sg = sigmoidf_(z);
+                    float sg = sigmoid_fast(z);
                     float gz = g[e] * (sg * (1.f + z * (1.f - sg)));
-                    float xh = (yy[e] - mu[e]) * is[e];
+                    float xh = yy[e] * is[e] - mi[e];
                     a1[e] += gz; a2[e] += gz * xh;
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a1[e] += g[e];
             }
+        };
+        long m = r0 + rg;
+        // four rows in flight per thread: the pass is latency-bound otherwise
+        for (; m + 3L * RG < r1; m += 4L * RG) {
+            uint4 gv[4], yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gv[u] = *reinterpret_cast<const uint4*>(ga + (m + (long)u * RG) * ldga + c);
+                if (MODE == 0) yv[u] = *reinterpret_cast<const uint4*>(y + (m + (long)u * RG) * ldy + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(gv[u], yv[u]);
+        }
+        for (; m < r1; m += RG) {
+            uint4 gv = *reinterpret_cast<const uint4*>(ga + m * ldga + c);
+            uint4 yv = gv;
+            if (MODE == 0) yv = *reinterpret_cast<const uint4*>(y + m * ldy + c);
+            accum(gv, yv);
         }
     }
-    // sP layout [rg][2][C]  (RG*2*C = 256/cpr*2*cpr*8 <= 4096 floats)
+    // sP layout [rg][2][C]  (RG*2*C = RED_THREADS/cpr*2*cpr*8 <= RED_THREADS*16 floats)
     if (rg < RG) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(EW_THREADS) void col_reduce_kernel(const uint16_t* 
         }
     }
     __syncthreads();
-    for (int i = t; i < 2 * C; i += EW_THREADS) {
+    for (int i = t; i < 2 * C; i += RED_THREADS) {
         int which = i / C;
         int cc = i - which * C;
         float s = 0.f;
@@ -208,14 +232,31 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
     out[c] = (float)s[0];
 }
 
+// gz = gamma*is*(dz - c1 - xhat*c2) with dz = g*silu'(z), xhat = (y-mu)*is, written per channel as
+// gz = A*dz + Bc*y + D (constants in registers, see bn_silu_apply_kernel for the striding).
 __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ldga, const uint16_t* __restrict__ y, int ldy,
                                          const float* __restrict__ ws, const float* __restrict__ gamma,
-                                         const float* __restrict__ coef, int C, int cpr, long nchunks,
+                                         const float* __restrict__ coef, int C, int cpr, long M,
                                          uint16_t* __restrict__ gy, int ldgy, uint16_t* gres, int ldgres, int gres_acc)
 {
-    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < nchunks; id += (long)gridDim.x * blockDim.x) {
-        long m = id / cpr;
-        int c = (int)(id - m * cpr) * 8;
+    const long T = (long)gridDim.x * blockDim.x;
+    const long rstep = T / cpr;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rstep * cpr) return;
+    long m = gid / cpr;
+    const int c = (int)(gid - m * cpr) * 8;
+    float sc[8], sh[8], A[8], Bc[8], D[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = ws[c + e]; sh[e] = ws[C + c + e];
+        const float mu = ws[2 * C + c + e], is = ws[3 * C + c + e];
+        const float gi = gamma[c + e] * is;
+        const float c1 = coef[c + e], c2 = coef[C + c + e];
+        A[e] = gi;
+        Bc[e] = -gi * is * c2;
+        D[e] = gi * (mu * is * c2 - c1);
+    }
+    for (; m < M; m += rstep) {
         uint4 gv = *reinterpret_cast<const uint4*>(ga + m * ldga + c);
         uint4 yv = *reinterpret_cast<const uint4*>(y + m * ldy + c);
         float g[8], yy[8], o[8];
@@ -223,12 +264,10 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
         unpack8(yv, yy);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float sc = ws[c + e], sh = ws[C + c + e], mu = ws[2 * C + c + e], is = ws[3 * C + c + e];
-            float z = yy[e] * sc + sh;
-            float sg = sigmoidf_(z);
-            float gz = g[e] * (sg * (1.f + z * (1.f - sg)));
-            float xh = (yy[e] - mu) * is;
-            o[e] = gamma[c + e] * is * (gz - coef[c + e] - xh * coef[C + c + e]);
+            float z = yy[e] * sc[e] + sh[e];
+            float sg = sigmoid_fast(z);
+            float dz = g[e] * (sg * (1.f + z * (1.f - sg)));
+            o[e] = A[e] * dz + (Bc[e] * yy[e] + D[e]);
         }
         *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
         if (gres) {
@@ -447,14 +486,14 @@ extern "C" int yh_bn_fold(const float* gamma, const float* beta, const float* rm
 extern "C" int yh_bn_silu_apply(const yh_bf16* y, int ldy, const float* ws, int C, int64_t M,
                                 yh_bf16* out, int ldo, const yh_bf16* res, int ldr, yh_stream stream)
 {
-    YH_CHECK_ARG(C > 0 && C % 8 == 0 && M > 0 && ws && yh_aligned16(ws), "yh_bn_silu_apply: bad C/M/ws");
+    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && ws && yh_aligned16(ws), "yh_bn_silu_apply: bad C/M/ws");
     YH_CHECK_SLICE("yh_bn_silu_apply", y, ldy, C);
     YH_CHECK_SLICE("yh_bn_silu_apply", out, ldo, C);
     if (res) YH_CHECK_SLICE("yh_bn_silu_apply", res, ldr, C);
     int cpr = C / 8;
     long nch = (long)M * cpr;
     hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       y, ldy, ws, C, cpr, nch, out, ldo, res, ldr);
+                       y, ldy, ws, C, cpr, (long)M, out, ldo, res, ldr);
     YH_CHECK_LAUNCH("yh_bn_silu_apply");
     return YH_OK;
 }
@@ -467,7 +506,7 @@ extern "C" int yh_bn_silu_bwd_reduce(const yh_bf16* ga, int ldga, const yh_bf16*
     YH_CHECK_SLICE("yh_bn_silu_bwd_reduce", y, ldy, C);
     int nblk = yh_ew_blocks(M);
     long rpb = (M + nblk - 1) / nblk;
-    hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk), dim3(EW_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
                        ga, ldga, y, ldy, ws, C, C / 8, (long)M, rpb, part);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_reduce");
     return YH_OK;
@@ -488,7 +527,7 @@ extern "C" int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* 
                                     int C, int64_t M, yh_bf16* gy, int ldgy,
                                     yh_bf16* gres, int ldgres, int gres_accumulate, yh_stream stream)
 {
-    YH_CHECK_ARG(C > 0 && C % 8 == 0 && M > 0 && ws && gamma && coef, "yh_bn_silu_bwd_apply: bad args");
+    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && ws && gamma && coef, "yh_bn_silu_bwd_apply: bad args");
     YH_CHECK_SLICE("yh_bn_silu_bwd_apply", ga, ldga, C);
     YH_CHECK_SLICE("yh_bn_silu_bwd_apply", y, ldy, C);
     YH_CHECK_SLICE("yh_bn_silu_bwd_apply", gy, ldgy, C);
@@ -496,7 +535,7 @@ extern "C" int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* 
     int cpr = C / 8;
     long nch = (long)M * cpr;
     hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       ga, ldga, y, ldy, ws, gamma, coef, C, cpr, nch, gy, ldgy, gres, ldgres, gres_accumulate);
+                       ga, ldga, y, ldy, ws, gamma, coef, C, cpr, (long)M, gy, ldgy, gres, ldgres, gres_accumulate);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply");
     return YH_OK;
 }
@@ -507,7 +546,7 @@ extern "C" int yh_colsum(const yh_bf16* g, int ldg, int C, int64_t M, float* par
     YH_CHECK_SLICE("yh_colsum", g, ldg, C);
     int nblk = yh_ew_blocks(M);
     long rpb = (M + nblk - 1) / nblk;
-    hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk), dim3(EW_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
                        g, ldg, (const uint16_t*)nullptr, 0, (const float*)nullptr, C, C / 8, (long)M, rpb, part);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, nblk, C, out);
     YH_CHECK_LAUNCH("yh_colsum");

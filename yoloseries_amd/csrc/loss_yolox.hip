@@ -101,7 +101,6 @@ __global__ __launch_bounds__(1024) void yolox_assign_kernel(const XK p, const St
     __shared__ int s_near[MAXG];
     __shared__ int s_cnt[16];
     __shared__ int s_misc[8];
-    __shared__ float s_valf[16];
     __shared__ int s_vali[16];
     const yh_yolox_desc& d = p.d;
     const int b = blockIdx.x, s = st.s;
