@@ -132,14 +132,14 @@ int yh_bn_fold(const float* gamma, const float* beta, const float* rm, const flo
 /* out = silu(y*scale+shift) (+res) ; all bf16 NHWC slices                      */
 int yh_bn_silu_apply(const yh_bf16* y, int ldy, const float* ws, int C, int64_t M,
                      yh_bf16* out, int ldo, const yh_bf16* res, int ldr, yh_stream stream);
-/* pass 1 of the backward: partial sums of gz and gz*xhat per channel
+/* pass 1 of the backward: partial sums of gz and gz*y per channel (gz = ga*silu'(bn(y)))
  * part layout: [nblk][2][C], nblk = yh_ew_blocks(M)                            */
 int yh_ew_blocks(int64_t M);
 int yh_bn_silu_bwd_reduce(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy,
                           const float* ws, int C, int64_t M, float* part, yh_stream stream);
-/* combine partials -> dgamma, dbeta (+= into grads) and coefficients
- * coef layout (fp32, 2*C): mean(gz) | mean(gz*xhat)                            */
-int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M,
+/* combine partials (fp64): sum(gz*xhat) = invstd*(sum(gz*y) - mean*sum(gz)) with mean/invstd from ws
+ * -> dgamma, dbeta and coefficients; coef layout (fp32, 2*C): mean(gz) | mean(gz*xhat) */
+int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M, const float* ws,
                        float* dgamma, float* dbeta, float* coef, yh_stream stream);
 /* pass 2: gy = gamma*invstd*(gz - c1 - xhat*c2); optional residual pass-through
  * gres (op)= ga                                                                */

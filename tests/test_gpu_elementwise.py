@@ -65,7 +65,7 @@ def test_bn_silu_fwd_bwd(dev, C, M):
     part = torch.zeros(nblk, 2, C, device=dev)
     hipk.bn_silu_bwd_reduce(hipk.full(ga), y, ws, M, part)
     dgamma, dbeta, coef = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(2 * C, device=dev)
-    hipk.bn_bwd_finalize(part, nblk, C, M, dgamma, dbeta, coef)
+    hipk.bn_bwd_finalize(part, nblk, C, M, ws, dgamma, dbeta, coef)
     gy = torch.zeros(M, C, dtype=torch.bfloat16, device=dev)
     gres = _rand_bf16((M, C), dev, 4)
     gres0 = gres.clone()

@@ -108,7 +108,7 @@ _SIGS = {
     "yh_bn_silu_apply": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
     "yh_ew_blocks": (_i32, [_i64]),
     "yh_bn_silu_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp]),
-    "yh_bn_bwd_finalize": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "yh_bn_bwd_finalize": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "yh_bn_silu_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _vp]),
     "yh_colsum": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp]),
     "yh_maxpool5_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),

@@ -130,7 +130,7 @@ __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, co
 constexpr int RED_THREADS = 512;
 
 template <int MODE>   // 0: BN+SiLU backward sums (gz, gz*xhat) ; 1: plain column sum of g
-__global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const uint16_t* __restrict__ ga, int ldga,
+__global__ __launch_bounds__(RED_THREADS, 4) void col_reduce_kernel(const uint16_t* __restrict__ ga, int ldga,
                                                                  const uint16_t* __restrict__ y, int ldy,
                                                                  const float* __restrict__ ws, int C, int cpr,
                                                                  long M, long rpb, float* __restrict__ part)
@@ -145,16 +145,12 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const uint16_t*
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
     if (rg < RG) {
-        // z = y*sc + sh ; xhat = y*is - mu*is
-        float sc[8], sh[8], is[8], mi[8];
+        // accumulates sum(dz) and sum(dz*y); the finalize turns the second into sum(dz*xhat) = is*(sum(dz*y) - mu*sum(dz))
+        float sc[8], sh[8];
         if (MODE == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sc[e] = ws[c + e]; sh[e] = ws[C + c + e]; is[e] = ws[3 * C + c + e]; mi[e] = ws[2 * C + c + e] * is[e];
-            }
+            for (int e = 0; e < 8; ++e) { sc[e] = ws[c + e]; sh[e] = ws[C + c + e]; }
         }
-        const long r0 = (long)blockIdx.x * rpb;
-        const long r1 = min(M, r0 + rpb);
         auto accum = [&](const uint4& gv, const uint4& yv) {
             float g[8];
             unpack8(gv, g);
@@ -166,31 +162,35 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const uint16_t*
                     float z = yy[e] * sc[e] + sh[e];
                     float sg = sigmoid_fast(z);
                     float gz = g[e] * (sg * (1.f + z * (1.f - sg)));
-                    float xh = yy[e] * is[e] - mi[e];
-                    a1[e] += gz; a2[e] += gz * xh;
+                    a1[e] += gz; a2[e] += gz * yy[e];
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a1[e] += g[e];
             }
         };
-        long m = r0 + rg;
-        // four rows in flight per thread: the pass is latency-bound otherwise
-        for (; m + 3L * RG < r1; m += 4L * RG) {
-            uint4 gv[4], yv[4];
+        // Blocks sweep the tensor together (block b takes row chunks b, b+grid, ...: the chip reads one moving
+        // window, like the apply passes); four rows in flight per thread.  The assignment is fixed -> deterministic.
+        const long CH = 4L * RG;
+        for (long base = (long)blockIdx.x * CH; base < M; base += (long)gridDim.x * CH) {
+            const long m = base + rg;
+            if (base + CH <= M) {
+                uint4 gv[4], yv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                gv[u] = *reinterpret_cast<const uint4*>(ga + (m + (long)u * RG) * ldga + c);
-                if (MODE == 0) yv[u] = *reinterpret_cast<const uint4*>(y + (m + (long)u * RG) * ldy + c);
+                for (int u = 0; u < 4; ++u) {
+                    gv[u] = *reinterpret_cast<const uint4*>(ga + (m + (long)u * RG) * ldga + c);
+                    if (MODE == 0) yv[u] = *reinterpret_cast<const uint4*>(y + (m + (long)u * RG) * ldy + c);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) accum(gv[u], yv[u]);
+            } else {
+                for (long mm = m; mm < M; mm += RG) {
+                    uint4 gv = *reinterpret_cast<const uint4*>(ga + mm * ldga + c);
+                    uint4 yv = gv;
+                    if (MODE == 0) yv = *reinterpret_cast<const uint4*>(y + mm * ldy + c);
+                    accum(gv, yv);
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) accum(gv[u], yv[u]);
-        }
-        for (; m < r1; m += RG) {
-            uint4 gv = *reinterpret_cast<const uint4*>(ga + m * ldga + c);
-            uint4 yv = gv;
-            if (MODE == 0) yv = *reinterpret_cast<const uint4*>(y + m * ldy + c);
-            accum(gv, yv);
         }
     }
     // sP layout [rg][2][C]  (RG*2*C = RED_THREADS/cpr*2*cpr*8 <= RED_THREADS*16 floats)
@@ -212,12 +212,13 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const uint16_t*
 }
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
-                                       float* dgamma, float* dbeta, float* coef)
+                                       const float* __restrict__ ws, float* dgamma, float* dbeta, float* coef)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     double s[2];
     slab_colsum<2>(part, nblk, C, C, c, s);
     if (threadIdx.x >= 64 || c >= C) return;
+    s[1] = (double)ws[3 * C + c] * (s[1] - (double)ws[2 * C + c] * s[0]);      // sum(dz*y) -> sum(dz*xhat)
     if (dbeta) dbeta[c] = (float)s[0];
     if (dgamma) dgamma[c] = (float)s[1];
     if (coef) { coef[c] = (float)(s[0] / M); coef[C + c] = (float)(s[1] / M); }
@@ -512,12 +513,12 @@ extern "C" int yh_bn_silu_bwd_reduce(const yh_bf16* ga, int ldga, const yh_bf16*
     return YH_OK;
 }
 
-extern "C" int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M,
+extern "C" int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M, const float* ws,
                                   float* dgamma, float* dbeta, float* coef, yh_stream stream)
 {
-    YH_CHECK_ARG(part && nblk > 0 && C > 0 && M > 0, "yh_bn_bwd_finalize: bad args");
+    YH_CHECK_ARG(part && ws && nblk > 0 && C > 0 && M > 0, "yh_bn_bwd_finalize: bad args");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
-                       part, nblk, C, (double)M, dgamma, dbeta, coef);
+                       part, nblk, C, (double)M, ws, dgamma, dbeta, coef);
     YH_CHECK_LAUNCH("yh_bn_bwd_finalize");
     return YH_OK;
 }

@@ -510,7 +510,7 @@ class Program:
                     cmds.append((L.yh_bn_silu_bwd_reduce, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), n, M,
                                                            self.part_scratch.data_ptr()), op.name, ('yh_bn_silu_bwd_reduce', 0)))
                     goff, boff = pk.bn_g[(op.name, pi)]
-                    cmds.append((L.yh_bn_bwd_finalize, (self.part_scratch.data_ptr(), nblk, n, M,
+                    cmds.append((L.yh_bn_bwd_finalize, (self.part_scratch.data_ptr(), nblk, n, M, ws.data_ptr(),
                                                         pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
                                                         coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0)))
                     gres_ptr, gres_ld, gres_acc = None, 0, 0

@@ -139,8 +139,8 @@ def bn_silu_bwd_reduce(ga: Slice, y: Slice, ws, M, part):
           "yh_bn_silu_bwd_reduce")
 
 
-def bn_bwd_finalize(part, nblk, Cn, M, dgamma, dbeta, coef):
-    check(lib().yh_bn_bwd_finalize(_p(part), nblk, Cn, M, _p(dgamma), _p(dbeta), _p(coef), _st()), "yh_bn_bwd_finalize")
+def bn_bwd_finalize(part, nblk, Cn, M, ws, dgamma, dbeta, coef):
+    check(lib().yh_bn_bwd_finalize(_p(part), nblk, Cn, M, _p(ws), _p(dgamma), _p(dbeta), _p(coef), _st()), "yh_bn_bwd_finalize")
 
 
 def bn_silu_bwd_apply(ga: Slice, y: Slice, ws, gamma, coef, M, gy: Slice, gres: Slice = None, gres_acc=0):
