@@ -19,6 +19,7 @@ maps them to the packed bf16 weight images and back (packed fp32 grads -> parame
 with one index-gather launch each.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -456,6 +457,7 @@ class Program:
         self.part_scratch = torch.zeros(1024 * 2 * 2048, dtype=torch.float32, device=self.dev)
         self.coef_scratch = {}
         self.ups_scratch = {}
+        self.wgrad_tuned = {}
 
         def claim(ref):
             """returns accumulate flag for a write into grad(ref) and marks it written"""
@@ -536,7 +538,7 @@ class Program:
                 wd.stride, wd.pad = op.stride, op.pad
                 wd.dw = gdw
                 ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
-                wd.splits = max(1, min((M + 255) // 256, (768 + ntile - 1) // ntile))
+                wd.splits = self._tune_wgrad_splits(wd, M, ntile, op)
                 self._keep.append(wd)
                 cmds.append(('wgrad', op, wd, ('conv_wgrad_kernel', 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
                 coff_k += sg.C
@@ -573,6 +575,38 @@ class Program:
                     cmds.append(('dgrad', op, d, (f'conv_igemm_kernel<{_pick_bn(sg.C)}>', 2.0 * M * op.N * op.k * op.k * sg.C)))
         self.cmd_bwd = cmds
         self.bwd_ready = True
+
+    def _tune_wgrad_splits(self, wd, M, ntile, op):
+        """Split-M factor of one weight-gradient launch.  The best total block count depends on the tile
+        configuration's residency and on how the atomics of the epilogue amortise (measured 256..1024 blocks,
+        up to 1.6x apart), so it is timed once per layer when the backward program is built
+        (YH_WGRAD_TUNE=0: fixed 512-block rule)."""
+        def splits_for(total):
+            return max(1, min((M + 255) // 256, (total + ntile - 1) // ntile))
+        if os.environ.get("YH_WGRAD_TUNE", "1") == "0":
+            return splits_for(512)
+        gy_saved = wd.gy
+        if not wd.gy:                      # head gradient arrives at run time: time against the scratch buffer
+            if self.gy_scratch.numel() < M * wd.ldg:
+                return splits_for(512)
+            wd.gy = self.gy_scratch.data_ptr()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        best, best_ms = None, None
+        for sp in sorted({splits_for(t) for t in (256, 512, 768, 1024, 1536)}):
+            wd.splits = sp
+            check(self.L.yh_conv_wgrad(C.byref(wd), st), f"yh_conv_wgrad tune [{op.name}]")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                self.L.yh_conv_wgrad(C.byref(wd), st)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if best_ms is None or ms < best_ms:
+                best, best_ms = sp, ms
+        wd.gy = gy_saved
+        self.wgrad_tuned[(op.name, wd.coff_k)] = (best, best_ms / 3)
+        return best
 
     def backward(self, head_grads):
         """head_grads: list of [B,h,w,ld] bf16 gradient buffers matching self.outputs (plain ops)."""
