@@ -193,8 +193,17 @@ def measure_roofline(model, step, B, nsteps=3):
     d = conv[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     total_ms = sum(v["ms"] for v in fam.values()) / nsteps
+    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same command
+    # (tools/pmc_traffic.py; counters cannot be read from inside the process), null when not collected
+    traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError, KeyError):
+        pass
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "flops_per_launch": round(d["flops"] / d["launches"]),
             "avg_launch_us": round(1000 * d["ms"] / d["launches"], 2), "launches_per_step": d["launches"] // nsteps,
             "family_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
             "engine_kernel_ms_per_step": round(total_ms, 3)}

@@ -91,11 +91,19 @@ typedef struct yh_conv_desc {
      * as per-block partial sums: stats[(blk*2+0)*Npad + n] = sum, [(blk*2+1)*Npad+n] = sumsq,
      * blk in [0, yh_conv_stat_blocks()).  NULL: not collected.                   */
     float*   stats;
+    /* launch tuning (0 = library default): output-channel tile width 32/64/128 and the cap on persistent
+     * blocks along the pixel axis.  Results are identical for every setting except the number (and so the
+     * summation grouping) of the statistics rows; yh_conv_stat_blocks() honours both.            */
+    int32_t  tile_n;
+    int32_t  grid_cap;
 } yh_conv_desc;
 
 /* number of partial-sum rows the conv kernel writes for this shape */
 int yh_conv_stat_blocks(const yh_conv_desc* d);
 int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream);
+/* name of the kernel instantiation yh_conv_igemm launches for this descriptor ("conv_v2_kernel<128, 2, 2, 2, 1>"),
+ * as rocprofv3 prints it: lets bench.py report per-kernel numbers that line up with the profiler's */
+int yh_conv_kernel_name(const yh_conv_desc* d, char* buf, int buflen);
 
 /* Weight gradient: dW[n][tap*Ctot + coff_k + c] += sum_m gy[m][n] * X[src(m,tap)][c]
  * (fp32 atomics into a zeroed packed buffer).  One launch per input segment.
@@ -111,6 +119,7 @@ typedef struct yh_wgrad_desc {
     int32_t  splits;                  /* split of the M (pixel) reduction, >=1      */
 } yh_wgrad_desc;
 int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
+const char* yh_conv_wgrad_kernel_name(int N, int Kseg);   /* instantiation used for a layer, profiler spelling */
 /* number of (out-channel x im2col-column) tiles the kernel uses for a layer; callers size `splits` so that
  * tiles*splits is about one resident wave of blocks */
 int yh_conv_wgrad_tiles(int N, int Kseg);

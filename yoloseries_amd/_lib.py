@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("out1", C.c_void_p), ("ld1", C.c_int32),
         ("res", C.c_void_p), ("ldr", C.c_int32),
         ("stats", C.c_void_p),
+        ("tile_n", C.c_int32), ("grid_cap", C.c_int32),
     ]
 
 
@@ -103,6 +104,8 @@ _SIGS = {
     "yh_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp]),
     "yh_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "yh_conv_wgrad_tiles": (_i32, [_i32, _i32]),
+    "yh_conv_wgrad_kernel_name": (C.c_char_p, [_i32, _i32]),
+    "yh_conv_kernel_name": (_i32, [C.POINTER(ConvDesc), C.c_char_p, _i32]),
     "yh_bn_finalize": (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
     "yh_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
     "yh_bn_silu_apply": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),

@@ -631,7 +631,7 @@ int pick_bn(int N) { return N <= 32 ? 32 : (N <= 64 ? 64 : 128); }
 void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
     long M = (long)d->B * d->Ho * d->Wo;
     int mtiles = (int)((M + BM - 1) / BM);
-    int b = pick_bn(d->N);
+    int b = (d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128) ? d->tile_n : pick_bn(d->N);
     int nt = (d->N + b - 1) / b;
     // persistent blocks: exactly one resident wave of blocks (256 CUs x blocks/CU of this instantiation), so there is
     // no partially filled second round; also bounds the BatchNorm partial-sum rows the finalize kernel reduces
@@ -639,6 +639,7 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
     int cap = (256 * occ) / nt;
     cap = (cap / 8) * 8;
     if (cap < 8) cap = 8;
+    if (d->grid_cap > 0) cap = d->grid_cap;
     int g = mtiles < cap ? mtiles : cap;
     *gx = g; *gy = nt; *bn = b;
 }
@@ -652,7 +653,9 @@ extern "C" int yh_conv_stat_blocks(const yh_conv_desc* d) {
     return gx;
 }
 
-extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream)
+namespace {
+// validates, plans and (name_out == nullptr) launches; with name_out only the instantiation's name is produced
+int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len)
 {
     YH_CHECK_ARG(d != nullptr, "yh_conv_igemm: null desc");
     YH_CHECK_ARG(d->nseg == 1 || d->nseg == 2, "yh_conv_igemm: nseg must be 1 or 2 (got %d)", d->nseg);
@@ -733,6 +736,12 @@ extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream)
     if (d->nseg == 1) { k.d.seg[1] = k.d.seg[0]; }
     const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || k.d.nsplit < d->N;
     if (generic && d->stats) k.v2 = 0;            // statistics of an affine/activated output: generic kernel only
+    if (name_out) {
+        const int wm = bn == 128 ? 2 : 4, wn = bn == 128 ? 2 : 1, minw = bn == 32 ? 4 : (bn == 64 ? 3 : 2);
+        if (k.v2) snprintf(name_out, name_len, "conv_v2_kernel<%d, %d, %d, %d, %d>", bn, wm, wn, minw, generic ? 2 : (d->stats ? 1 : 0));
+        else snprintf(name_out, name_len, "conv_igemm_kernel<%d, %d, %d, %s, %d>", bn, wm, wn, k.fast ? "true" : "false", minw);
+        return YH_OK;
+    }
     if (k.v2) {
         hipStream_t st2 = (hipStream_t)stream;
         const int epi = generic ? 2 : (d->stats ? 1 : 0);
@@ -763,6 +772,16 @@ extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream)
 #undef YH_LAUNCH_CONV
     YH_CHECK_LAUNCH("yh_conv_igemm");
     return YH_OK;
+}
+}  // namespace
+
+extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream) { return conv_run(d, stream, nullptr, 0); }
+
+/* name of the kernel instantiation yh_conv_igemm launches for this descriptor, as profilers print it */
+extern "C" int yh_conv_kernel_name(const yh_conv_desc* d, char* buf, int buflen)
+{
+    YH_CHECK_ARG(buf && buflen >= 64, "yh_conv_kernel_name: buffer too small");
+    return conv_run(d, nullptr, buf, buflen);
 }
 
 // diagnostics: resident blocks per CU the runtime predicts for each instantiation (bn = 32/64/128)

@@ -63,12 +63,21 @@ __global__ __launch_bounds__(256, MINW) void conv_wgrad_kernel(const WgK p)
     const int lane = t & 63;
     const int wave = t >> 6;
     const int wn = wave / WC, wc = wave % WC;
-    const int ntile = blockIdx.x / p.ctiles;
-    const int ctile = blockIdx.x - ntile * p.ctiles;
+    // XCD-aware block -> (tile, split) map: workgroups are dealt round-robin to the 8 XCDs by linear id, so the
+    // tiles of one pixel split (which re-read the same gy / X rows) are given to ONE XCD, back to back, and share
+    // its L2 instead of each XCD fetching the rows again (gridDim.y is padded to a multiple of 8).
+    const int T = gridDim.x;
+    const int lin = blockIdx.y * T + blockIdx.x;
+    const int seq = lin >> 3;
+    const int tile = seq % T;
+    const int split = (seq / T) * 8 + (lin & 7);
+    const int ntile = tile / p.ctiles;
+    const int ctile = tile - ntile * p.ctiles;
     const int n0 = ntile * TN, col0 = ctile * TCOLS;
-    const int mbeg = blockIdx.y * p.rows_per_split;
-    const int mend = min(p.M, mbeg + p.rows_per_split);
-    if (mbeg >= mend) return;
+    const long mb0 = (long)split * p.rows_per_split;
+    if (mb0 >= p.M) return;                         // padding split (uniform for the block)
+    const int mbeg = (int)mb0;
+    const int mend = (int)min((long)p.M, mb0 + p.rows_per_split);
     const int nkt = (mend - mbeg + TK - 1) / TK;
 
     const int row = t / TPR;          // pixel row within the k-step
@@ -219,7 +228,24 @@ constexpr size_t wg_smem() {
     return (size_t)2 * TK * (wg_pitch(WN * TNW * 32) + wg_pitch(WC * TCW * 32)) * 2;
 }
 
+// instantiation used for a layer (N out channels, Kseg im2col columns of the segment)
+int wg_config(int N, int Kseg)
+{
+    if (Kseg <= 384) {
+        if (N <= 32) return Kseg <= 256 ? 0 : 1;
+        return Kseg <= 128 ? 2 : (Kseg <= 256 ? 3 : 4);
+    }
+    return N <= 64 ? 5 : 6;
+}
+const char* const wg_names[7] = {
+    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3>", "conv_wgrad_kernel<1, 4, 1, 3, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 1, 32, 4>",
+    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 3, 32, 2>", "conv_wgrad_kernel<2, 2, 1, 2, 64, 3>",
+    "conv_wgrad_kernel<2, 2, 2, 2, 64, 2>"};
+
 }  // namespace
+
+/* name of the kernel instantiation yh_conv_wgrad launches for a layer, as profilers print it */
+extern "C" const char* yh_conv_wgrad_kernel_name(int N, int Kseg) { return wg_names[wg_config(N, Kseg)]; }
 
 /* tile the kernel will use for a layer: rows (out channels) x im2col columns per block; used by the host to size `splits` */
 extern "C" int yh_conv_wgrad_tiles(int N, int Kseg)
@@ -264,23 +290,21 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     rps = ((rps + TK - 1) / TK) * TK;
     k.rows_per_split = rps;
     splits = (int)((M + rps - 1) / rps);
-    YH_CHECK_ARG(splits <= 65535, "yh_conv_wgrad: too many splits");
+    YH_CHECK_ARG(splits <= 65528, "yh_conv_wgrad: too many splits");
 #define YH_WG(WN_, WC_, TNW_, TCW_, TK_, MINW_, NT_)                                                            \
     do {                                                                                                        \
-        dim3 grid((NT_) * k.ctiles, splits);                                                                    \
+        dim3 grid((NT_) * k.ctiles, (splits + 7) / 8 * 8);                                                      \
         conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_><<<grid, dim3(256), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
     } while (0)
-    if (wide) {
-        k.ctiles = 1;
-        if (d->N <= 32 && k.Kseg <= 256) YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32);
-        else if (d->N <= 32)             YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32);
-        else if (k.Kseg <= 128)          YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64);
-        else if (k.Kseg <= 256)          YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64);
-        else                             YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64);
-    } else {
-        k.ctiles = (k.Kseg + 127) / 128;
-        if (d->N <= 64) YH_WG(2, 2, 1, 2, 64, 3, (d->N + 63) / 64);
-        else            YH_WG(2, 2, 2, 2, 64, 2, (d->N + 127) / 128);
+    k.ctiles = wide ? 1 : (k.Kseg + 127) / 128;
+    switch (wg_config(d->N, k.Kseg)) {
+    case 0: YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32); break;
+    case 1: YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32); break;
+    case 2: YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64); break;
+    case 3: YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64); break;
+    case 4: YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64); break;
+    case 5: YH_WG(2, 2, 1, 2, 64, 3, (d->N + 63) / 64); break;
+    default: YH_WG(2, 2, 2, 2, 64, 2, (d->N + 127) / 128); break;
     }
 #undef YH_WG
     YH_CHECK_LAUNCH("yh_conv_wgrad");

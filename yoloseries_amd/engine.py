@@ -19,6 +19,7 @@ maps them to the packed bf16 weight images and back (packed fp32 grads -> parame
 with one index-gather launch each.
 """
 import ctypes as C
+import json
 import os
 
 import numpy as np
@@ -33,6 +34,40 @@ BN_EPS_DEFAULT = 1e-3
 
 def _rup(x, m):
     return ((x + m - 1) // m) * m
+
+
+def _tune_cache_path():
+    return os.environ.get("YH_TUNE_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), ".tune_cache.json"))
+
+
+def _tune_cache():
+    """launch parameters timed on this machine (per layer shape), kept across processes in a small JSON file"""
+    if _tune_cache.data is None:
+        _tune_cache.data = {}
+        try:
+            with open(_tune_cache_path()) as f:
+                _tune_cache.data = dict(json.load(f))
+        except (OSError, ValueError):
+            pass
+    return _tune_cache.data
+
+
+_tune_cache.data = None
+_tune_cache.dirty = False
+
+
+def _tune_cache_save():
+    if not _tune_cache.dirty:
+        return
+    _tune_cache.dirty = False
+    path = _tune_cache_path()
+    try:
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(_tune_cache.data, f, indent=0, sort_keys=True)
+        os.replace(tmp, path)
+    except OSError:
+        pass                               # read-only install: tune again next time
 
 
 def _pick_bn(n):
@@ -361,8 +396,8 @@ class Program:
                 d.act = YH_ACT_NONE
                 d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
                 st['desc'] = d
-                self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op)))
-                self.cmd_eval.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op)))
+                self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op, d)))
+                self.cmd_eval.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op, d)))
                 continue
             # ---- ConvBnAct, training: conv(+stats) -> finalize -> apply
             d = self._conv_desc(op, True)
@@ -372,7 +407,7 @@ class Program:
             st['stats'] = torch.zeros(nblk, 2, op.Npad, dtype=torch.float32, device=self.dev)
             d.stats = st['stats'].data_ptr()
             st['desc_train'] = d
-            self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op)))
+            self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op, d)))
             st['ws'] = []
             c0 = 0
             for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
@@ -410,12 +445,23 @@ class Program:
                 r = op.res.sl()
                 de.res, de.ldr = r.ptr(), r.ld
             st['desc_eval'] = de
-            self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name, self._fam_conv(op)))
+            self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name, self._fam_conv(op, de)))
 
     # -- forward ---------------------------------------------------------------------------
-    def _fam_conv(self, op):
+    def _kernel_name(self, d):
+        """instantiation yh_conv_igemm launches for descriptor d, spelled as rocprofv3 prints it"""
+        buf = C.create_string_buffer(96)
+        saved = d.seg[0].ptr
+        if not saved:                      # head gradient pointer is filled in at run time
+            d.seg[0].ptr = self.gy_scratch.data_ptr()
+        rc = self.L.yh_conv_kernel_name(C.byref(d), buf, 96)
+        d.seg[0].ptr = saved
+        check(rc, "yh_conv_kernel_name")
+        return buf.value.decode()
+
+    def _fam_conv(self, op, d):
         M = self.B * op.Ho * op.Wo
-        return (f'conv_igemm_kernel<{_pick_bn(op.N)}>', 2.0 * M * op.N * op.k * op.k * (12 if op.focus else op.Ctot))
+        return (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else op.Ctot))
 
     def _run(self, cmds):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -540,7 +586,7 @@ class Program:
                 ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
                 wd.splits = self._tune_wgrad_splits(wd, M, ntile, op)
                 self._keep.append(wd)
-                cmds.append(('wgrad', op, wd, ('conv_wgrad_kernel', 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
+                cmds.append(('wgrad', op, wd, (L.yh_conv_wgrad_kernel_name(gyN, op.k * op.k * sg.C).decode(), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
                 coff_k += sg.C
             # dgrad per segment
             for si, sg in enumerate(op.segs):
@@ -565,16 +611,17 @@ class Program:
                     acc = claim(Ref(sg.buf, sg.coff, sg.C))
                     gl = Slice(sg.buf.g, sg.coff, sg.C)
                     self._keep.append(d)
-                    cmds.append(('dgrad', op, d, (f'conv_igemm_kernel<{_pick_bn(sg.C)}>', 2.0 * M * op.N * op.k * op.k * sg.C)))
+                    cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C)))
                     cmds.append((L.yh_upsample2_bwd, (tmp.data_ptr(), sg.C, B, sg.buf.H, sg.buf.W, sg.C, gl.ptr(), gl.ld, acc), op.name, ('yh_upsample2_bwd', 0)))
                 else:
                     acc = claim(Ref(sg.buf, sg.coff, sg.C))
                     gl = Slice(sg.buf.g, sg.coff, sg.C)
                     d.out0, d.ld0, d.accumulate = gl.ptr(), gl.ld, acc
                     self._keep.append(d)
-                    cmds.append(('dgrad', op, d, (f'conv_igemm_kernel<{_pick_bn(sg.C)}>', 2.0 * M * op.N * op.k * op.k * sg.C)))
+                    cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C)))
         self.cmd_bwd = cmds
         self.bwd_ready = True
+        _tune_cache_save()
 
     def _tune_wgrad_splits(self, wd, M, ntile, op):
         """Split-M factor of one weight-gradient launch.  The best total block count depends on the tile
@@ -585,6 +632,11 @@ class Program:
             return max(1, min((M + 255) // 256, (total + ntile - 1) // ntile))
         if os.environ.get("YH_WGRAD_TUNE", "1") == "0":
             return splits_for(512)
+        key = "wgrad:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
+                                                         wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad))
+        cache = _tune_cache()
+        if key in cache:
+            return int(cache[key])
         gy_saved = wd.gy
         if not wd.gy:                      # head gradient arrives at run time: time against the scratch buffer
             if self.gy_scratch.numel() < M * wd.ldg:
@@ -606,6 +658,8 @@ class Program:
                 best, best_ms = sp, ms
         wd.gy = gy_saved
         self.wgrad_tuned[(op.name, wd.coff_k)] = (best, best_ms / 3)
+        cache[key] = int(best)
+        _tune_cache.dirty = True
         return best
 
     def backward(self, head_grads):
