@@ -83,11 +83,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("YH_DIST_BACKEND", "nccl")      # "gloo" only to rehearse N>1 on a one-GPU box
+    if world > 1 and backend == "nccl" and local_rank >= ndev:
+        sys.exit(f"bench.py: rank {local_rank} has no GPU ({ndev} visible)")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from yoloseries_amd import models
     from yoloseries_amd.loss import YOLOV5Loss
@@ -140,7 +147,12 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof = measure_roofline(model, step, B)
+        # rank 0 alone instruments a few extra steps: no gradient exchange in them (the other ranks wait below)
+        if dp is not None:
+            with dp.no_sync():
+                roof = measure_roofline(model, step, B)
+        else:
+            roof = measure_roofline(model, step, B)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -161,6 +173,7 @@ def main():
         }
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -37,6 +37,19 @@ def _worker(rank, world, port, q):
     with dp.no_sync():
         fm._yh_grad_hook(g3)
     res["nosync_ok"] = bool(torch.allclose(g3, torch.full((5,), float(rank))))
+    # overlapped exchange: the engine hands over contiguous slices of the packed gradient arena in backward order
+    from yoloseries_amd.engine import plan_grad_buckets
+    arena = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    marks = [(5, 900), (9, 700), (14, 650), (20, 300), (22, 280), (30, 0)]
+    buckets = plan_grad_buckets(marks, 1000, 4)
+    fins = [fm._yh_bucket_hook(arena[lo:hi]) for _, lo, hi in buckets]
+    for f in fins:
+        f()
+    res["bucket_ok"] = bool(torch.allclose(arena, torch.arange(1000, dtype=torch.float32) * 1.5))
+    covered = sorted((lo, hi) for _, lo, hi in buckets)
+    res["bucket_cover_ok"] = covered[0][0] == 0 and covered[-1][1] == 1000 and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    with dp.no_sync():
+        res["bucket_nosync_ok"] = fm._yh_bucket_hook(arena[:10]) is None
     bn = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
     with torch.no_grad():
         bn[1].running_mean.fill_(float(rank)); bn[1].weight.fill_(1.0 + rank)

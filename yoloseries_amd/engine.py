@@ -70,6 +70,25 @@ def _tune_cache_save():
         pass                               # read-only install: tune again next time
 
 
+def plan_grad_buckets(marks, gsize, nbuckets):
+    """Buckets of the packed gradient arena for the data-parallel exchange.  `marks` lists, in backward order,
+    (command index after which an op's gradients are complete, start of the op's slice); ops are laid out in
+    forward order, so the finished region grows downwards from `gsize` and every bucket is one contiguous slice.
+    Returns [(cmd_index, lo, hi)]: after command cmd_index-1 the slice [lo, hi) can be all-reduced while the
+    rest of the backward runs.  Cuts are made when a bucket holds >= gsize/nbuckets elements."""
+    out, hi, last = [], gsize, gsize
+    target = max(1, gsize // max(1, nbuckets))
+    for i, (ci, lo) in enumerate(marks):
+        if lo > last:
+            raise YoloHipError("gradient arena is not laid out in forward op order")
+        last = lo
+        if hi - lo >= target or i == len(marks) - 1:
+            lo_cut = 0 if i == len(marks) - 1 else lo
+            out.append((ci, lo_cut, hi))
+            hi = lo_cut
+    return out
+
+
 def _pick_bn(n):
     """output-channel tile the conv kernel picks (csrc/conv_igemm.hip pick_bn)"""
     return 32 if n <= 32 else (64 if n <= 64 else 128)
@@ -526,6 +545,7 @@ class Program:
             else:
                 o.buf.ginit[o.coff:o.coff + o.C] = True
 
+        marks = []
         for op in reversed(self.ops):
             if isinstance(op, PoolOp):
                 require(op.dst, op.name)
@@ -588,6 +608,8 @@ class Program:
                 self._keep.append(wd)
                 cmds.append(('wgrad', op, wd, (L.yh_conv_wgrad_kernel_name(gyN, op.k * op.k * sg.C).decode(), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
                 coff_k += sg.C
+            # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
+            marks.append((len(cmds), pk.gloc[op.name]))
             # dgrad per segment
             for si, sg in enumerate(op.segs):
                 if not sg.buf.needs_grad:
@@ -620,6 +642,7 @@ class Program:
                     self._keep.append(d)
                     cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C)))
         self.cmd_bwd = cmds
+        self.bwd_buckets = plan_grad_buckets(marks, pk.gsize, int(os.environ.get("YH_DP_BUCKETS", "4")))
         self.bwd_ready = True
         _tune_cache_save()
 
@@ -662,10 +685,15 @@ class Program:
         _tune_cache.dirty = True
         return best
 
-    def backward(self, head_grads):
-        """head_grads: list of [B,h,w,ld] bf16 gradient buffers matching self.outputs (plain ops)."""
+    def backward(self, head_grads, bucket_hook=None):
+        """head_grads: list of [B,h,w,ld] bf16 gradient buffers matching self.outputs (plain ops).
+        bucket_hook(slice of the packed fp32 gradient arena) -> finisher or None: called as soon as a bucket of
+        gradients is complete (data-parallel all-reduce overlapped with the remaining backward); finishers run
+        before the gradients are scattered to parameter order."""
         if not self.bwd_ready:
             self._build_backward()
+        buckets = self.bwd_buckets if bucket_hook is not None else []
+        nb, finishers = 0, []
         pk, L = self.pack, self.L
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         hipk.fill_zero(pk.gpack)
@@ -676,7 +704,10 @@ class Program:
             else:
                 o.buf.g[..., o.coff:o.coff + o.C].copy_(g)
         prof = self.profile
-        for cmd in self.cmd_bwd:
+        for ci, cmd in enumerate(self.cmd_bwd):
+            while nb < len(buckets) and buckets[nb][0] == ci:
+                finishers.append(bucket_hook(pk.gpack[buckets[nb][1]:buckets[nb][2]]))
+                nb += 1
             fn = cmd[0]
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -711,6 +742,12 @@ class Program:
             if prof is not None:
                 e1.record()
                 prof.setdefault(cmd[3] + (cmd[1].name if hasattr(cmd[1], 'name') else cmd[2],), []).append((e0, e1))
+        while nb < len(buckets):
+            finishers.append(bucket_hook(pk.gpack[buckets[nb][1]:buckets[nb][2]]))
+            nb += 1
+        for f in finishers:
+            if f is not None:
+                f()
         return pk.grads_to_params()
 
 
@@ -753,10 +790,11 @@ class _NetFn(torch.autograd.Function):
             else:
                 head_grads.append(g.permute(0, 2, 3, 1).to(torch.bfloat16) if g is not None else torch.zeros(
                     shape[0], shape[2], shape[3], shape[1], dtype=torch.bfloat16, device=prog.dev))
-        flat_g, pgrads = prog.backward(head_grads)
+        bucket_hook = getattr(ctx.host, "_yh_bucket_hook", None)   # data-parallel all-reduce, overlapped (utils/dist.py)
+        flat_g, pgrads = prog.backward(head_grads, bucket_hook)
         ctx.host._yh_last_flat_grad = flat_g
-        hook = getattr(ctx.host, "_yh_grad_hook", None)        # data-parallel all-reduce (utils/dist.py)
-        if hook is not None:
+        hook = getattr(ctx.host, "_yh_grad_hook", None)        # whole-gradient exchange (when no bucket hook is installed)
+        if hook is not None and bucket_hook is None:
             hook(flat_g)
         hook = getattr(ctx.host, "_yh_grad_hook_opt", None)    # flat-arena optimizer
         if hook is not None:
@@ -785,6 +823,7 @@ class HipModuleMixin:
         s.pop('_yh', None)
         s.pop('_yh_last_flat_grad', None)
         s.pop('_yh_grad_hook', None)
+        s.pop('_yh_bucket_hook', None)
         s.pop('_yh_grad_hook_opt', None)
         s.pop('flat_grads_only', None)
         return s

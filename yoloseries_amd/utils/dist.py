@@ -6,7 +6,8 @@ One process per GPU; torch.distributed backend "nccl" is RCCL on ROCm (xGMI insi
 use "gloo".  The reference wraps the model in DDP (train_yolov5.py:219-220): gradients are AVERAGED over
 ranks, BatchNorm statistics stay per-rank during training and are averaged only before evaluation
 (utils/allreduce_norm.py:56-98).  Here the engine hands over ONE flat fp32 gradient buffer per backward,
-so the exchange is a single (optionally chunked) all-reduce instead of DDP's per-bucket hooks.
+so the exchange is a few large all-reduces of contiguous slices, issued while the backward is still running
+(buckets follow the backward order of the layers), instead of DDP's per-parameter bucket hooks.
 """
 import os
 
@@ -73,14 +74,31 @@ class DataParallelGrads:
     """Averages the engine's flat gradient over the ranks right after each backward (DDP semantics:
     mean of per-rank gradients; no_sync() skips the exchange on accumulation steps, train_yolov5.py:327)."""
 
-    def __init__(self, model, group=None, chunks=2):
+    def __init__(self, model, group=None, chunks=2, overlap=True):
         self.model, self.group, self.chunks = model, group, chunks
         self.enabled = True
         model._yh_grad_hook = self._hook
+        if overlap:
+            # the engine calls this per finished gradient bucket DURING the backward (engine.Program.backward):
+            # the collective runs on RCCL's stream while the remaining dgrad/wgrad kernels keep the CUs busy
+            model._yh_bucket_hook = self._bucket
 
     def _hook(self, flat_g):
         if self.enabled:
             allreduce_flat_mean(flat_g, self.group, self.chunks)
+
+    def _bucket(self, part):
+        """async all-reduce of one contiguous slice of the packed gradient arena; returns the finisher that
+        makes the compute stream wait for it and turns the sum into the mean"""
+        world = dist.get_world_size(self.group) if _on() else 1
+        if not self.enabled or world == 1 or part.numel() == 0:
+            return None
+        work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+        def finish():
+            work.wait()
+            part.div_(world)
+        return finish
 
     class _NoSync:
         def __init__(self, dp):
