@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolohip.so")
+LIB_PATH = os.environ.get("YH_LIBRARY") or os.path.join(_HERE, "libyolohip.so")   # YH_LIBRARY: timing builds (tools/)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 

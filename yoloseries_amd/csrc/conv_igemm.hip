@@ -350,6 +350,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
 // of 32 channels and every operand is smaller than 2 GiB (host check).
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
+#ifdef YH_CONV_STAMPS
+// timing build only (make stamps): per-phase s_memtime totals of block 0's four waves
+__device__ long long g_stamps[32];
+#endif
+
 template <int BN, int WM, int WN, int MINW, int EPI>   // EPI 0: plain store, 1: + BatchNorm partial sums, 2: generic epilogue
 __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
 {
@@ -403,8 +408,18 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
     const int ldsB0 = rowA * LDSP + kc * 8;          // row id>>2 == rowA (+64 per extra chunk)
 
     float run_s = 0.f, run_q = 0.f;
+#ifdef YH_CONV_STAMPS
+    long long st_load = 0, st_mma = 0, st_store = 0, st_bar = 0, st_pro = 0, st_epi = 0, st_n = 0;
+    const long long st_begin = __builtin_amdgcn_s_memtime();
+#define STAMP(var) do { const long long now_ = __builtin_amdgcn_s_memtime(); var += now_ - st_t; st_t = now_; } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
 
     for (int mt = blockIdx.x; mt < p.mtiles; mt += gridDim.x) {
+#ifdef YH_CONV_STAMPS
+        long long st_t = __builtin_amdgcn_s_memtime();
+#endif
         const int m0 = mt * BM;
         int hb[2], wb[2], img[2];
         unsigned voff0[2], voff1[2];
@@ -471,6 +486,9 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
             if (ld_cb == 0) tap_setup(ld_tap);
             const int c = ld_cb * 32;
             const bool s1 = d.nseg > 1 && c >= C0;           // wave-uniform
+#ifdef YH_CONV_STAMPS
+            if (p.dbg & 1) { ra[0] = u32x4_t{0, 0, 0, 0}; ra[1] = ra[0]; } else
+#endif
             if (s1) {
                 const int so = (c - C0) * 2;
 #pragma unroll
@@ -481,6 +499,12 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
                 for (int i = 0; i < 2; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, voff0[i], so, 0);
             }
             const int sw = (kcol_base + c) * 2;
+#ifdef YH_CONV_STAMPS
+            if (p.dbg & 8) {
+#pragma unroll
+                for (int j = 0; j < NBL; ++j) rb[j] = u32x4_t{0, 0, 0, 0};
+            } else
+#endif
 #pragma unroll
             for (int j = 0; j < NBL; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, voffB[j], sw, 0);
             if (++ld_cb == ncb) { ld_cb = 0; ++ld_tap; }
@@ -498,10 +522,12 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
         load_tile();
         store_tile(0);
         __syncthreads();
+        STAMP(st_pro);
         for (int kt = 0; kt < nkt; ++kt) {
             const int buf = kt & 1;
             const bool more = (kt + 1) < nkt;
             if (more) load_tile();
+            STAMP(st_load);
             const uint16_t* a = sA + buf * BM * LDSP;
             const uint16_t* b = sB + buf * BN * LDSP;
 #pragma unroll
@@ -514,14 +540,28 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + (wn * (TN * 32) + j * 32 + (lane & 31)) * LDSP + koff));
+#ifdef YH_CONV_STAMPS
+                if (p.dbg & 4) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j][0] += (float)af[i][0] * (float)bfr[j][0];
+                } else
+#endif
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
+            STAMP(st_mma);
             if (more) store_tile(buf ^ 1);
+            STAMP(st_store);
             __syncthreads();
+            STAMP(st_bar);
+#ifdef YH_CONV_STAMPS
+            ++st_n;
+#endif
         }
 
         // ---- epilogue
@@ -611,7 +651,16 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
             }
         }
         __syncthreads();
+        STAMP(st_epi);
     }
+#ifdef YH_CONV_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+        long long* o = g_stamps + wave * 8;
+        o[0] = st_load; o[1] = st_mma; o[2] = st_store; o[3] = st_bar; o[4] = st_pro; o[5] = st_epi; o[6] = st_n;
+        o[7] = __builtin_amdgcn_s_memtime() - st_begin;
+    }
+#endif
+#undef STAMP
 
     if (EPI == 1 && t < BN) {
         d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
@@ -783,6 +832,13 @@ extern "C" int yh_conv_kernel_name(const yh_conv_desc* d, char* buf, int buflen)
     YH_CHECK_ARG(buf && buflen >= 64, "yh_conv_kernel_name: buffer too small");
     return conv_run(d, nullptr, buf, buflen);
 }
+
+#ifdef YH_CONV_STAMPS
+extern "C" int yh_debug_read_stamps(long long* host_out32)
+{
+    return hipMemcpyFromSymbol(host_out32, HIP_SYMBOL(g_stamps), sizeof(long long) * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // diagnostics: resident blocks per CU the runtime predicts for each instantiation (bn = 32/64/128)
 extern "C" int yh_debug_conv_occupancy(int bn)

@@ -169,28 +169,40 @@ __global__ __launch_bounds__(RED_THREADS, 4) void col_reduce_kernel(const uint16
                 for (int e = 0; e < 8; ++e) a1[e] += g[e];
             }
         };
-        // Blocks sweep the tensor together (block b takes row chunks b, b+grid, ...: the chip reads one moving
-        // window, like the apply passes); four rows in flight per thread.  The assignment is fixed -> deterministic.
-        const long CH = 4L * RG;
-        for (long base = (long)blockIdx.x * CH; base < M; base += (long)gridDim.x * CH) {
-            const long m = base + rg;
-            if (base + CH <= M) {
-                uint4 gv[4], yv[4];
+        // Blocks sweep the tensor together: block b takes the row groups (RG rows each) b, b+grid, b+2*grid, ...,
+        // so the chip reads one moving window (like the apply passes) and the blocks' shares differ by at most
+        // one group; four groups in flight per thread.  The assignment is fixed -> deterministic sums.
+        const long G = (M + RG - 1) / RG;
+        const long nb = gridDim.x;
+        long gi = blockIdx.x;
+        for (; gi + 3 * nb < G - 1; gi += 4 * nb) {
+            uint4 gv[4], yv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    gv[u] = *reinterpret_cast<const uint4*>(ga + (m + (long)u * RG) * ldga + c);
-                    if (MODE == 0) yv[u] = *reinterpret_cast<const uint4*>(y + (m + (long)u * RG) * ldy + c);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const long m = (gi + u * nb) * RG + rg;
+                gv[u] = *reinterpret_cast<const uint4*>(ga + m * ldga + c);
+                if (MODE == 0) yv[u] = *reinterpret_cast<const uint4*>(y + m * ldy + c);
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) accum(gv[u], yv[u]);
-            } else {
-                for (long mm = m; mm < M; mm += RG) {
-                    uint4 gv = *reinterpret_cast<const uint4*>(ga + mm * ldga + c);
-                    uint4 yv = gv;
-                    if (MODE == 0) yv = *reinterpret_cast<const uint4*>(y + mm * ldy + c);
-                    accum(gv, yv);
+            for (int u = 0; u < 4; ++u) accum(gv[u], yv[u]);
+        }
+        {   // remainder: at most four groups are left for this block; their loads are issued together as well
+            uint4 gv[4], yv[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long m = (gi + u * nb) * RG + rg;
+                ok[u] = m < M;
+                gv[u] = make_uint4(0, 0, 0, 0);
+                yv[u] = gv[u];
+                if (ok[u]) {
+                    gv[u] = *reinterpret_cast<const uint4*>(ga + m * ldga + c);
+                    if (MODE == 0) yv[u] = *reinterpret_cast<const uint4*>(y + m * ldy + c);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u]) accum(gv[u], yv[u]);
         }
     }
     // sP layout [rg][2][C]  (RG*2*C = RED_THREADS/cpr*2*cpr*8 <= RED_THREADS*16 floats)
