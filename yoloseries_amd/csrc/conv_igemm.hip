@@ -18,6 +18,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef YH_CONV_ABLATE
+#define YH_CONV_ABLATE 0      // timing builds only (make ablate ABL=mask): compile parts of the main loop out
+#endif
+
 namespace {
 
 constexpr int BM = 128;
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (okr[i] && !(p.dbg & 1)) v = *reinterpret_cast<const uint4*>(sp + (size_t)(s1 ? pix1[i] : pix0[i]) * sld + cc);
+                if (okr[i] && !(YH_CONV_ABLATE & 1)) v = *reinterpret_cast<const uint4*>(sp + (size_t)(s1 ? pix1[i] : pix0[i]) * sld + cc);
                 ra[i] = v;
             }
             const uint16_t* wp = d.w + (size_t)n0 * p.Ktot + kcol_base + c;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
             for (int i = 0; i < NBL; ++i) {
                 const int id = t + i * 256;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (id < BN * 4 && !(p.dbg & 8)) v = *reinterpret_cast<const uint4*>(wp + (size_t)(id >> 2) * p.Ktot);
+                if (id < BN * 4 && !(YH_CONV_ABLATE & 8)) v = *reinterpret_cast<const uint4*>(wp + (size_t)(id >> 2) * p.Ktot);
                 rb[i] = v;
             }
             if (++ld_cb == ncb) { ld_cb = 0; ++ld_tap; }
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        if (!(p.dbg & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        if (!(YH_CONV_ABLATE & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
             if (more) store_tile(buf ^ 1);
             __syncthreads();
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
                     v = v * scl + sft;
                     if (d.act == YH_ACT_SILU) v = silu_fast(v);
                     uint16_t hb16 = f2bf(v);
-                    if (!(p.dbg & 2)) sC[row * CP + c] = hb16;
+                    if (!(YH_CONV_ABLATE & 2)) sC[row * CP + c] = hb16;
                     float vr = (m0 + row < p.M) ? bf2f(hb16) : 0.f;   // rows past M carry only the bias
                     s += vr; q += vr * vr;
                 }
@@ -355,19 +359,23 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 __device__ long long g_stamps[32];
 #endif
 
-template <int BN, int WM, int WN, int MINW, int EPI>   // EPI 0: plain store, 1: + BatchNorm partial sums, 2: generic epilogue
+template <int BN, int WM, int WN, int MINW, int EPI, int BKT>   // BKT: channels per k-step (32 | 64); EPI 0: plain store, 1: + BatchNorm partial sums, 2: generic epilogue
 __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
 {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
-    constexpr int NBL = (BN * 4 + 255) / 256;
+    constexpr int LDSPX = BKT + 8;                  // LDS row pitch in elements: 80 B / 144 B rows, conflict-free ds_read_b128
+    constexpr int CHR = BKT / 8;                    // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CHR;                  // tile rows covered by one pass of the 256 threads
+    constexpr int NA = BM / RPP;                    // A chunks per thread
+    constexpr int NBL = (BN * CHR + 255) / 256;     // B chunks per thread
     constexpr int CP = BN + 8;
-    constexpr int MAIN_BYTES = (2 * (BM + BN) * LDSP * 2) > (BM * CP * 2) ? (2 * (BM + BN) * LDSP * 2) : (BM * CP * 2);
+    constexpr int MAIN_BYTES = (2 * (BM + BN) * LDSPX * 2) > (BM * CP * 2) ? (2 * (BM + BN) * LDSPX * 2) : (BM * CP * 2);
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* sA = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* sB = sA + 2 * BM * LDSP;
+    uint16_t* sB = sA + 2 * BM * LDSPX;
     uint16_t* sC = reinterpret_cast<uint16_t*>(smem);
     float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);
     int* sPix = reinterpret_cast<int*>(smem + MAIN_BYTES + WM * 2 * BN * 4);
@@ -378,8 +386,8 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
     const int wave = t >> 6;
     const int wm = wave / WN;
     const int wn = wave % WN;
-    const int kc = t & 3;
-    const int rowA = t >> 2;
+    const int kc = t % CHR;
+    const int rowA = t / CHR;
     const int n0 = blockIdx.y * BN;
     const int HoWo = d.Ho * d.Wo;
     const int sdmask = (1 << p.sdshift) - 1;
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
     const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
     const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
     const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
-    const int ncb = p.Ctot >> 5;
+    const int ncb = p.Ctot / BKT;
     const int nkt = nkh * nkw * ncb;
     const int HcWc = p.Hc * p.Wc;
     const int C0 = d.seg[0].C;
@@ -402,10 +410,10 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
 #pragma unroll
     for (int j = 0; j < NBL; ++j) {
         const int id = t + j * 256;
-        voffB[j] = id < BN * 4 ? (unsigned)(((n0 + (id >> 2)) * p.Ktot + kc * 8) * 2) : OOB;
+        voffB[j] = id < BN * CHR ? (unsigned)(((n0 + id / CHR) * p.Ktot + kc * 8) * 2) : OOB;
     }
-    const int ldsA0 = rowA * LDSP + kc * 8;          // + 64*LDSP for the second row
-    const int ldsB0 = rowA * LDSP + kc * 8;          // row id>>2 == rowA (+64 per extra chunk)
+    const int ldsA0 = rowA * LDSPX + kc * 8;         // + RPP*LDSPX per further row of this thread
+    const int ldsB0 = rowA * LDSPX + kc * 8;         // row (t + j*256)/CHR == rowA + j*RPP
 
     float run_s = 0.f, run_q = 0.f;
 #ifdef YH_CONV_STAMPS
@@ -421,11 +429,11 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
         long long st_t = __builtin_amdgcn_s_memtime();
 #endif
         const int m0 = mt * BM;
-        int hb[2], wb[2], img[2];
-        unsigned voff0[2], voff1[2];
+        int hb[NA], wb[NA], img[NA];
+        unsigned voff0[NA], voff1[NA];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + rowA + 64 * i;
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + rowA + RPP * i;
             voff0[i] = OOB; voff1[i] = OOB;
             img[i] = 0; hb[i] = -(1 << 28); wb[i] = -(1 << 28);
             if (m < p.M) {
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
                         wo = rem - ho * d.Wo;
                     }
                     img[i] = im; hb[i] = ho * p.sa + p.sc; wb[i] = wo * p.sa + p.sc;
-                    if (p.cls && kc == 0) sPix[rowA + 64 * i] = (im * d.Ho + ho) * d.Wo + wo;
+                    if (p.cls && kc == 0) sPix[rowA + RPP * i] = (im * d.Ho + ho) * d.Wo + wo;
                 }
             }
         }
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        u32x4_t ra[2], rb[NBL];
+        u32x4_t ra[NA], rb[NBL];
         int ld_tap = 0, ld_cb = 0, kcol_base = 0;
 
         auto tap_setup = [&](int tapl) {
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
             if (p.pointwise) return;
             const int u0 = d.seg[0].ups, u1 = d.seg[1].ups;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const int hn = hb[i] + kh * p.sb;
                 const int wn_ = wb[i] + kw * p.sb;
                 bool ok = hn >= 0 && wn_ >= 0 && (((hn | wn_) & sdmask) == 0);
@@ -484,23 +492,26 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
         };
         auto load_tile = [&]() {
             if (ld_cb == 0) tap_setup(ld_tap);
-            const int c = ld_cb * 32;
+            const int c = ld_cb * BKT;
             const bool s1 = d.nseg > 1 && c >= C0;           // wave-uniform
-#ifdef YH_CONV_STAMPS
-            if (p.dbg & 1) { ra[0] = u32x4_t{0, 0, 0, 0}; ra[1] = ra[0]; } else
+#if YH_CONV_ABLATE
+            if (YH_CONV_ABLATE & 1) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) ra[i] = u32x4_t{0, 0, 0, 0};
+            } else
 #endif
             if (s1) {
                 const int so = (c - C0) * 2;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs1, voff1[i], so, 0);
+                for (int i = 0; i < NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs1, voff1[i], so, 0);
             } else {
                 const int so = c * 2;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, voff0[i], so, 0);
+                for (int i = 0; i < NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, voff0[i], so, 0);
             }
             const int sw = (kcol_base + c) * 2;
-#ifdef YH_CONV_STAMPS
-            if (p.dbg & 8) {
+#if YH_CONV_ABLATE
+            if (YH_CONV_ABLATE & 8) {
 #pragma unroll
                 for (int j = 0; j < NBL; ++j) rb[j] = u32x4_t{0, 0, 0, 0};
             } else
@@ -510,13 +521,13 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
             if (++ld_cb == ncb) { ld_cb = 0; ++ld_tap; }
         };
         auto store_tile = [&](int buf) {
-            uint16_t* a = sA + buf * BM * LDSP + ldsA0;
-            uint16_t* b = sB + buf * BN * LDSP + ldsB0;
-            *reinterpret_cast<u32x4_t*>(a) = ra[0];
-            *reinterpret_cast<u32x4_t*>(a + 64 * LDSP) = ra[1];
+            uint16_t* a = sA + buf * BM * LDSPX + ldsA0;
+            uint16_t* b = sB + buf * BN * LDSPX + ldsB0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4_t*>(a + i * RPP * LDSPX) = ra[i];
 #pragma unroll
             for (int j = 0; j < NBL; ++j)
-                if (t + j * 256 < BN * 4) *reinterpret_cast<u32x4_t*>(b + j * 64 * LDSP) = rb[j];
+                if (t + j * 256 < BN * CHR) *reinterpret_cast<u32x4_t*>(b + j * RPP * LDSPX) = rb[j];
         };
 
         load_tile();
@@ -528,20 +539,31 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
             const bool more = (kt + 1) < nkt;
             if (more) load_tile();
             STAMP(st_load);
-            const uint16_t* a = sA + buf * BM * LDSP;
-            const uint16_t* b = sB + buf * BN * LDSP;
+            const uint16_t* a = sA + buf * BM * LDSPX;
+            const uint16_t* b = sB + buf * BN * LDSPX;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BKT / 16; ++ks) {
                 bf16x8_t af[TM], bfr[TN];
                 const int koff = (ks * 2 + (lane >> 5)) * 8;
+#if YH_CONV_ABLATE
+                if (YH_CONV_ABLATE & 64) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, ra[0]);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, rb[0]);
+                } else {
+#endif
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + (wm * (TM * 32) + i * 32 + (lane & 31)) * LDSP + koff));
+                    af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + (wm * (TM * 32) + i * 32 + (lane & 31)) * LDSPX + koff));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + (wn * (TN * 32) + j * 32 + (lane & 31)) * LDSP + koff));
-#ifdef YH_CONV_STAMPS
-                if (p.dbg & 4) {
+                    bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + (wn * (TN * 32) + j * 32 + (lane & 31)) * LDSPX + koff));
+#if YH_CONV_ABLATE
+                }
+#endif
+#if YH_CONV_ABLATE
+                if (YH_CONV_ABLATE & 4) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -555,9 +577,15 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
             STAMP(st_mma);
+#if YH_CONV_ABLATE
+            if (more && !(YH_CONV_ABLATE & 128)) store_tile(buf ^ 1);
+            STAMP(st_store);
+            if (!(YH_CONV_ABLATE & 256)) __syncthreads();
+#else
             if (more) store_tile(buf ^ 1);
             STAMP(st_store);
             __syncthreads();
+#endif
             STAMP(st_bar);
 #ifdef YH_CONV_STAMPS
             ++st_n;
@@ -565,6 +593,19 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
         }
 
         // ---- epilogue
+#if YH_CONV_ABLATE
+        if (YH_CONV_ABLATE & 2) {
+            float sink = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sink += acc[i][j][r];
+            if (sink == 12345.678f) d.out0[0] = 1;
+            continue;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int c = wn * (TN * 32) + j * 32 + (lane & 31);
@@ -668,14 +709,24 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
     }
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int BKT = 32>
 constexpr size_t conv_smem_bytes() {
-    size_t a = 2 * (BM + BN) * LDSP * 2;
+    size_t a = 2 * (BM + BN) * (BKT + 8) * 2;
     size_t c = BM * (BN + 8) * 2;
     return (a > c ? a : c) + WM * 2 * BN * 4 + BM * 4;
 }
 
 int pick_bn(int N) { return N <= 32 ? 32 : (N <= 64 ? 64 : 128); }
+
+// channels per k-step: 64 (128-byte tile rows: whole cache lines per row, half the barriers) when every input
+// segment has a multiple of 64 channels (128-wide output tiles only), else 32
+int pick_bkt(const yh_conv_desc* d, int bn) {
+    if (bn != 128) return 32;              // measured: the narrower tiles lose more from the lower residency than they gain
+    if (d->nseg < 1 || d->nseg > 2) return 32;
+    for (int s = 0; s < d->nseg; ++s) if (d->seg[s].C % 64) return 32;
+    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 64)) return 32; }
+    return 64;
+}
 
 void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
     long M = (long)d->B * d->Ho * d->Wo;
@@ -684,7 +735,7 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
     int nt = (d->N + b - 1) / b;
     // persistent blocks: exactly one resident wave of blocks (256 CUs x blocks/CU of this instantiation), so there is
     // no partially filled second round; also bounds the BatchNorm partial-sum rows the finalize kernel reduces
-    const int occ = b == 32 ? 4 : (b == 64 ? 3 : 2);
+    const int occ = pick_bkt(d, b) == 64 ? (b == 32 ? 3 : 2) : (b == 32 ? 4 : (b == 64 ? 3 : 2));
     int cap = (256 * occ) / nt;
     cap = (cap / 8) * 8;
     if (cap < 8) cap = 8;
@@ -764,6 +815,7 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (k.cls) { gx = (gx + 3) / 4; if (gx > k.mtiles) gx = k.mtiles; }
     dim3 grid(gx, gy, k.cls ? 4 : 1), block(256);
     // ---- lean buffer-load kernel
+    const int bkt = pick_bkt(d, bn);
     k.v2 = k.fast && !(k.dbg & 16);
     k.pointwise = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !k.cls) ? 1 : 0;
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -787,23 +839,32 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (generic && d->stats) k.v2 = 0;            // statistics of an affine/activated output: generic kernel only
     if (name_out) {
         const int wm = bn == 128 ? 2 : 4, wn = bn == 128 ? 2 : 1, minw = bn == 32 ? 4 : (bn == 64 ? 3 : 2);
-        if (k.v2) snprintf(name_out, name_len, "conv_v2_kernel<%d, %d, %d, %d, %d>", bn, wm, wn, minw, generic ? 2 : (d->stats ? 1 : 0));
+        if (k.v2) {
+            const int minw2 = bkt == 64 ? (bn == 32 ? 3 : 2) : minw;
+            snprintf(name_out, name_len, "conv_v2_kernel<%d, %d, %d, %d, %d, %d>", bn, wm, wn, minw2, generic ? 2 : (d->stats ? 1 : 0), bkt);
+        }
         else snprintf(name_out, name_len, "conv_igemm_kernel<%d, %d, %d, %s, %d>", bn, wm, wn, k.fast ? "true" : "false", minw);
         return YH_OK;
     }
     if (k.v2) {
         hipStream_t st2 = (hipStream_t)stream;
         const int epi = generic ? 2 : (d->stats ? 1 : 0);
-#define YH_LAUNCH_V2(BN_, WM_, WN_, MINW_)                                                                     \
+#define YH_LAUNCH_V2(BN_, WM_, WN_, MINW_, BKT_)                                                               \
         do {                                                                                                   \
-            const size_t sm = conv_smem_bytes<BN_, WM_, WN_>();                                                \
-            if (epi == 2)      conv_v2_kernel<BN_, WM_, WN_, MINW_, 2><<<grid, block, sm, st2>>>(k);           \
-            else if (epi == 1) conv_v2_kernel<BN_, WM_, WN_, MINW_, 1><<<grid, block, sm, st2>>>(k);           \
-            else               conv_v2_kernel<BN_, WM_, WN_, MINW_, 0><<<grid, block, sm, st2>>>(k);           \
+            const size_t sm = conv_smem_bytes<BN_, WM_, WN_, BKT_>();                                          \
+            if (epi == 2)      conv_v2_kernel<BN_, WM_, WN_, MINW_, 2, BKT_><<<grid, block, sm, st2>>>(k);     \
+            else if (epi == 1) conv_v2_kernel<BN_, WM_, WN_, MINW_, 1, BKT_><<<grid, block, sm, st2>>>(k);     \
+            else               conv_v2_kernel<BN_, WM_, WN_, MINW_, 0, BKT_><<<grid, block, sm, st2>>>(k);     \
         } while (0)
-        if (bn == 32) YH_LAUNCH_V2(32, 4, 1, 4);
-        else if (bn == 64) YH_LAUNCH_V2(64, 4, 1, 3);
-        else YH_LAUNCH_V2(128, 2, 2, 2);
+        if (bkt == 64) {
+            if (bn == 32) YH_LAUNCH_V2(32, 4, 1, 3, 64);
+            else if (bn == 64) YH_LAUNCH_V2(64, 4, 1, 2, 64);
+            else YH_LAUNCH_V2(128, 2, 2, 2, 64);
+        } else {
+            if (bn == 32) YH_LAUNCH_V2(32, 4, 1, 4, 32);
+            else if (bn == 64) YH_LAUNCH_V2(64, 4, 1, 3, 32);
+            else YH_LAUNCH_V2(128, 2, 2, 2, 32);
+        }
 #undef YH_LAUNCH_V2
         YH_CHECK_LAUNCH("yh_conv_igemm(v2)");
         return YH_OK;
