@@ -359,16 +359,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 __device__ long long g_stamps[32];
 #endif
 
-template <int BN, int WM, int WN, int MINW, int EPI, int BKT>   // BKT: channels per k-step (32 | 64); EPI 0: plain store, 1: + BatchNorm partial sums, 2: generic epilogue
-__global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
+template <int BN, int WM, int WN, int MINW, int EPI, int BKT>     // block = WM x WN waves   // BKT: channels per k-step (32 | 64); EPI 0: plain store, 1: + BatchNorm partial sums, 2: generic epilogue
+__global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK p)
 {
+    constexpr int NT = WM * WN * 64;                // threads per block
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int LDSPX = BKT + 8;                  // LDS row pitch in elements: 80 B / 144 B rows, conflict-free ds_read_b128
     constexpr int CHR = BKT / 8;                    // 16-byte chunks per tile row
-    constexpr int RPP = 256 / CHR;                  // tile rows covered by one pass of the 256 threads
+    constexpr int RPP = NT / CHR;                   // tile rows covered by one pass of the block's threads
     constexpr int NA = BM / RPP;                    // A chunks per thread
-    constexpr int NBL = (BN * CHR + 255) / 256;     // B chunks per thread
+    constexpr int NBL = (BN * CHR + NT - 1) / NT;   // B chunks per thread
     constexpr int CP = BN + 8;
     constexpr int MAIN_BYTES = (2 * (BM + BN) * LDSPX * 2) > (BM * CP * 2) ? (2 * (BM + BN) * LDSPX * 2) : (BM * CP * 2);
     constexpr unsigned OOB = 0x80000000u;
@@ -409,11 +410,11 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
     unsigned voffB[NBL];
 #pragma unroll
     for (int j = 0; j < NBL; ++j) {
-        const int id = t + j * 256;
+        const int id = t + j * NT;
         voffB[j] = id < BN * CHR ? (unsigned)(((n0 + id / CHR) * p.Ktot + kc * 8) * 2) : OOB;
     }
     const int ldsA0 = rowA * LDSPX + kc * 8;         // + RPP*LDSPX per further row of this thread
-    const int ldsB0 = rowA * LDSPX + kc * 8;         // row (t + j*256)/CHR == rowA + j*RPP
+    const int ldsB0 = rowA * LDSPX + kc * 8;         // row (t + j*NT)/CHR == rowA + j*RPP
 
     float run_s = 0.f, run_q = 0.f;
 #ifdef YH_CONV_STAMPS
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
             for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4_t*>(a + i * RPP * LDSPX) = ra[i];
 #pragma unroll
             for (int j = 0; j < NBL; ++j)
-                if (t + j * 256 < BN * CHR) *reinterpret_cast<u32x4_t*>(b + j * RPP * LDSPX) = rb[j];
+                if (t + j * NT < BN * CHR) *reinterpret_cast<u32x4_t*>(b + j * RPP * LDSPX) = rb[j];
         };
 
         load_tile();
@@ -644,10 +645,10 @@ __global__ __launch_bounds__(256, MINW) void conv_v2_kernel(const ConvK p)
         __syncthreads();
 
         constexpr int CPR = BN / 8;
-        constexpr int NCH = BM * CPR / 256;
+        constexpr int NCH = BM * CPR / NT;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int id = t + i * 256;
+            const int id = t + i * NT;
             const int row = id / CPR;
             const int cch = id - row * CPR;
             const int m = m0 + row;
@@ -840,8 +841,9 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (name_out) {
         const int wm = bn == 128 ? 2 : 4, wn = bn == 128 ? 2 : 1, minw = bn == 32 ? 4 : (bn == 64 ? 3 : 2);
         if (k.v2) {
-            const int minw2 = bkt == 64 ? (bn == 32 ? 3 : 2) : minw;
-            snprintf(name_out, name_len, "conv_v2_kernel<%d, %d, %d, %d, %d, %d>", bn, wm, wn, minw2, generic ? 2 : (d->stats ? 1 : 0), bkt);
+            const bool e8 = bn == 128;
+            snprintf(name_out, name_len, "conv_v2_kernel<%d, %d, %d, %d, %d, %d>", bn, e8 ? 4 : wm, e8 ? 2 : wn, e8 ? 4 : minw,
+                     generic ? 2 : (d->stats ? 1 : 0), bkt);
         }
         else snprintf(name_out, name_len, "conv_igemm_kernel<%d, %d, %d, %s, %d>", bn, wm, wn, k.fast ? "true" : "false", minw);
         return YH_OK;
@@ -852,18 +854,18 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
 #define YH_LAUNCH_V2(BN_, WM_, WN_, MINW_, BKT_)                                                               \
         do {                                                                                                   \
             const size_t sm = conv_smem_bytes<BN_, WM_, WN_, BKT_>();                                          \
-            if (epi == 2)      conv_v2_kernel<BN_, WM_, WN_, MINW_, 2, BKT_><<<grid, block, sm, st2>>>(k);     \
-            else if (epi == 1) conv_v2_kernel<BN_, WM_, WN_, MINW_, 1, BKT_><<<grid, block, sm, st2>>>(k);     \
-            else               conv_v2_kernel<BN_, WM_, WN_, MINW_, 0, BKT_><<<grid, block, sm, st2>>>(k);     \
+            const dim3 blk(WM_ * WN_ * 64);                                                                    \
+            if (epi == 2)      conv_v2_kernel<BN_, WM_, WN_, MINW_, 2, BKT_><<<grid, blk, sm, st2>>>(k);       \
+            else if (epi == 1) conv_v2_kernel<BN_, WM_, WN_, MINW_, 1, BKT_><<<grid, blk, sm, st2>>>(k);       \
+            else               conv_v2_kernel<BN_, WM_, WN_, MINW_, 0, BKT_><<<grid, blk, sm, st2>>>(k);       \
         } while (0)
-        if (bkt == 64) {
-            if (bn == 32) YH_LAUNCH_V2(32, 4, 1, 3, 64);
-            else if (bn == 64) YH_LAUNCH_V2(64, 4, 1, 2, 64);
-            else YH_LAUNCH_V2(128, 2, 2, 2, 64);
+        if (bn == 128) {                     // 8 waves: 4 per SIMD with two resident blocks, wave tile 32 x 64
+            if (bkt == 64) YH_LAUNCH_V2(128, 4, 2, 4, 64);
+            else           YH_LAUNCH_V2(128, 4, 2, 4, 32);
+        } else if (bn == 64) {
+            YH_LAUNCH_V2(64, 4, 1, 3, 32);   // (8 waves of 32 x 32 measured equal: LDS reads per MFMA double)
         } else {
-            if (bn == 32) YH_LAUNCH_V2(32, 4, 1, 4, 32);
-            else if (bn == 64) YH_LAUNCH_V2(64, 4, 1, 3, 32);
-            else YH_LAUNCH_V2(128, 2, 2, 2, 32);
+            YH_LAUNCH_V2(32, 4, 1, 4, 32);
         }
 #undef YH_LAUNCH_V2
         YH_CHECK_LAUNCH("yh_conv_igemm(v2)");
