@@ -13,9 +13,10 @@
 // 128-byte row segments per wave instruction).  Tilings:
 //   wide    (K <= 384: stem, 3x3x32 and most 1x1 layers) one block covers ALL im2col columns, so gy
 //           is read once and the 9 taps of a pixel are gathered by the same block (L1/L2 hits);
-//   general 128 x 128 (or 64 x 128) tiles, 64 pixels per k-step, one column tile per block.
+//   general 128 x 128 (8 waves) or 64 x 128 tiles, 64 pixels per k-step, one column tile per block.
 // Replaces autograd's conv weight gradient (train_yolov5.py:337).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -39,8 +40,9 @@ constexpr int wg_pitch(int cols) { return (cols % 64 == 32) ? cols : cols + 32; 
 
 // WN x WC waves, each wave computes (TNW*32) x (TCW*32); TK pixels per k-step
 template <int WN, int WC, int TNW, int TCW, int TK, int MINW>
-__global__ __launch_bounds__(256, MINW) void conv_wgrad_kernel(const WgK p)
+__global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const WgK p)
 {
+    constexpr int NT = WN * WC * 64;              // threads per block
     constexpr int TN = WN * TNW * 32;             // out-channel rows of the tile
     constexpr int TCOLS = WC * TCW * 32;          // im2col columns of the tile
     // LDS pitches in elements: pitch bytes == 64 or 192 (mod 256) puts the 4 rows of a transposing read on
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256, MINW) void conv_wgrad_kernel(const WgK p)
     constexpr int PA = wg_pitch(TN);
     constexpr int PB = wg_pitch(TCOLS);
     static_assert(((PA * 2) % 256 == 64 || (PA * 2) % 256 == 192) && ((PB * 2) % 256 == 64 || (PB * 2) % 256 == 192), "bad LDS pitch");
-    constexpr int TPR = 256 / TK;                 // threads per pixel row
+    constexpr int TPR = NT / TK;                  // threads per pixel row
     constexpr int ACH = (TN / 8 + TPR - 1) / TPR; // A chunks per thread
     constexpr int BCH = (TCOLS / 8) / TPR;        // B chunks per thread
     static_assert((TCOLS / 8) % TPR == 0, "column chunks must divide over the row's threads");
@@ -240,7 +242,7 @@ int wg_config(int N, int Kseg)
 const char* const wg_names[7] = {
     "conv_wgrad_kernel<1, 4, 1, 2, 32, 3>", "conv_wgrad_kernel<1, 4, 1, 3, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 1, 32, 4>",
     "conv_wgrad_kernel<1, 4, 2, 2, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 3, 32, 2>", "conv_wgrad_kernel<2, 2, 1, 2, 64, 3>",
-    "conv_wgrad_kernel<2, 2, 2, 2, 64, 2>"};
+    "conv_wgrad_kernel<4, 2, 1, 2, 64, 4>"};
 
 }  // namespace
 
@@ -294,7 +296,7 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
 #define YH_WG(WN_, WC_, TNW_, TCW_, TK_, MINW_, NT_)                                                            \
     do {                                                                                                        \
         dim3 grid((NT_) * k.ctiles, (splits + 7) / 8 * 8);                                                      \
-        conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_><<<grid, dim3(256), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
+        conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_><<<grid, dim3(WN_ * WC_ * 64), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
     } while (0)
     k.ctiles = wide ? 1 : (k.Kseg + 127) / 128;
     switch (wg_config(d->N, k.Kseg)) {
@@ -304,7 +306,7 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     case 3: YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64); break;
     case 4: YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64); break;
     case 5: YH_WG(2, 2, 1, 2, 64, 3, (d->N + 63) / 64); break;
-    default: YH_WG(2, 2, 2, 2, 64, 2, (d->N + 127) / 128); break;
+    default: YH_WG(4, 2, 1, 2, 64, 4, (d->N + 127) / 128); break;      // 8 waves of 32 x 64 (measured 5% over 4 waves of 64 x 64)
     }
 #undef YH_WG
     YH_CHECK_LAUNCH("yh_conv_wgrad");
