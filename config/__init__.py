@@ -1,0 +1,1 @@
+from .config import Config  # noqa: F401

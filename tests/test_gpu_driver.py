@@ -28,3 +28,34 @@ def test_training_driver_smoke(dev, tmp_path, monkeypatch):
     assert t2.start_epoch == 2
     for (k, a), (_, b2) in zip(t.model.state_dict().items(), t2.model.state_dict().items()):
         assert torch.equal(a.cpu(), b2.cpu()), k
+
+
+def test_training_driver_dataset_path(dev, tmp_path, monkeypatch):
+    """same driver fed through the reference's data path: DataLoader -> fixed_imgsize_collate_fn -> DataPrefetcher"""
+    sys.path.insert(0, ROOT)
+    monkeypatch.chdir(tmp_path)
+    import train_yolov5
+    t = train_yolov5.main(["--epochs", "1", "--img", "128", "--batch", "4", "--steps-per-epoch", "3", "--data", "dataset"])
+    losses = [h["tot_loss"] for h in t.history]
+    assert len(losses) == 3 and all(np.isfinite(losses)) and all(h["tar_nums"] > 0 for h in t.history)
+    assert set(t.last_metrics) == {"map", "map50", "precision", "recall", "n_pred"}
+
+
+def test_validation_driver(dev, tmp_path, monkeypatch):
+    """val_yolov5.py mirror: checkpoint from the training driver -> evaluator -> un-letterboxed boxes -> mAP_v2"""
+    sys.path.insert(0, ROOT)
+    monkeypatch.chdir(tmp_path)
+    import train_yolov5
+    import val_yolov5
+    t = train_yolov5.main(["--epochs", "1", "--img", "128", "--batch", "4", "--steps-per-epoch", "2"])
+    v = val_yolov5.main(["--img", "128", "--batch", "4", "--val-batches", "2", "--ckpt", t.last_ckpt])
+    assert v.loaded_ema and v.metrics["images"] == 8
+    assert all(np.isfinite([v.metrics[k] for k in ("map", "map50", "precision", "recall")]))
+    # frame transforms are inverses of the letterbox (utils/letterbox.py)
+    info = [{'scale': 0.5, 'pad_top': 10, 'pad_left': 4, 'pad_bottom': 10, 'pad_right': 4, 'org_shape': (200, 240)}]
+    pred = [torch.tensor([[14., 20., 64., 70., 0.9, 3.]], device=dev)]
+    out = val_yolov5.Training.preds_postprocess(pred, info)[0]
+    assert np.allclose(out[0, :4], [20., 20., 120., 120.]) and out[0, 5] == 3
+    ann = torch.tensor([[[14., 20., 64., 70., 3., 0.], [-1., -1., -1., -1., -1., -1.]]])
+    bb, cc = val_yolov5.Training.gt_bbox_postprocess(ann, info)
+    assert np.allclose(bb[0], [[20., 20., 120., 120.]]) and cc[0].tolist() == [3]

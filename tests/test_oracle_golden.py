@@ -201,3 +201,63 @@ def test_g9_map_v2():
         np.testing.assert_allclose(m[k], g[k], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(mAP_v2(gts, preds).get_mean_metrics(), g["mean"], rtol=1e-12)
     assert g["mean"][1] > 0.1
+
+
+# ---------------------------------------------------------------- G10 letterbox + collate format (host side)
+def test_letterbox_and_collate_match_reference():
+    """dataset/data_collater.py:20-64, utils/data_aug.py:21-70, utils/bbox_tools.py:38-49 on geometries the
+    reference runs without OpenCV (scale == 1): resize_info, padded image, boxes and the (B,maxbox,6) tensor."""
+    from yoloseries_amd.dataset import SyntheticDetectionDataset, fixed_imgsize_collate_fn, test_dataset_collate_fn
+    from yoloseries_amd.utils.letterbox import letter_resize_bbox, letter_resize_img
+    g = np.load(os.path.join(G, "g10_collate.npz"))
+    length, nc, mb, seed0 = (int(v) for v in g["dataset_args"])
+    items = []
+    for i, hw in enumerate(g["shapes"]):
+        ds = SyntheticDetectionDataset(length, img_hw=tuple(int(v) for v in hw), num_class=nc, max_boxes=mb, seed=seed0 + i)
+        img, ann, iid = ds[i]
+        if i == 3:
+            ann = {'bboxes': np.zeros((0, 4), np.float32), 'classes': []}
+        items.append((img, ann, iid))
+        out, info = letter_resize_img(img, [640, 640])
+        got = np.array([info['scale'], info['pad_top'], info['pad_left'], info['pad_bottom'], info['pad_right'],
+                        info['org_shape'][0], info['org_shape'][1]], np.float64)
+        assert np.array_equal(got, g[f"lr{i}_info"])
+        assert out.dtype == np.uint8 and np.array_equal(out.astype(np.float64).sum(axis=(0, 1)), g[f"lr{i}_sum"])
+        assert np.array_equal(out.reshape(-1)[::997], g[f"lr{i}_sample"])
+        if len(ann['classes']):
+            assert np.array_equal(letter_resize_bbox(np.array(ann['bboxes'], np.float64).copy(), info), g[f"lb{i}"])
+    batch = fixed_imgsize_collate_fn(items, [640, 640])
+    assert batch['img'].dtype == torch.float32 and batch['ann'].dtype == torch.float32
+    assert np.array_equal(batch['ann'].numpy(), g["c_ann"])
+    assert np.array_equal(batch['img'].double().sum(dim=(2, 3)).numpy(), g["c_img_sum"])
+    assert np.array_equal(batch['img'].reshape(-1)[::9973].numpy(), g["c_img_sample"])
+    info = np.array([[r['scale'], r['pad_top'], r['pad_left'], r['pad_bottom'], r['pad_right']] for r in batch['resize_info']], np.float64)
+    assert np.array_equal(info, g["c_info"]) and np.array_equal(np.array(batch['img_id']), g["c_ids"])
+    tb = test_dataset_collate_fn([(torch.full((3, 64, 96), float(k)), {'scale': 1.0 + k}) for k in range(3)])
+    assert np.array_equal(tb['img'].double().sum(dim=(1, 2, 3)).numpy(), g["t_img_sum"]) and tb['resize_info'][2]['scale'] == 3.0
+
+
+def test_letterbox_resize_paths():
+    """scale != 1 (nearest-neighbour index rule of cv2.INTER_NEAREST) and the test-time minimal padding:
+    geometry invariants of utils/data_aug.py:21-70 (OpenCV is absent, these paths have no reference vector)."""
+    from yoloseries_amd.utils.letterbox import letter_resize_img, resize_nearest
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, size=(375, 500, 3), dtype=np.uint8)
+    out, info = letter_resize_img(img, 640)
+    assert out.shape == (640, 640, 3) and abs(info['scale'] - 1.28) < 1e-12
+    rh, rw = int(375 * 1.28), int(500 * 1.28)
+    assert info['pad_top'] == (640 - rh) // 2 and info['pad_left'] == (640 - rw) // 2
+    assert info['pad_top'] + info['pad_bottom'] + rh == 640 and info['pad_left'] + info['pad_right'] + rw == 640
+    inner = out[info['pad_top']:info['pad_top'] + rh, info['pad_left']:info['pad_left'] + rw]
+    ys = np.minimum(np.floor(np.arange(rh) * (375 / rh)).astype(int), 374)
+    xs = np.minimum(np.floor(np.arange(rw) * (500 / rw)).astype(int), 499)
+    assert np.array_equal(inner, img[ys][:, xs]) and np.array_equal(resize_nearest(img, rw, rh), inner)
+    assert (out[:info['pad_top']] == 128).all() and (out[info['pad_top'] + rh:] == 128).all()
+    # test time: pad only up to the next multiple of the stride
+    out2, info2 = letter_resize_img(img, 640, training=False)
+    assert out2.shape[0] % 64 == 0 and out2.shape[1] % 64 == 0 and out2.shape[1] == 640 and out2.shape[0] == 512
+    assert info2['pad_top'] + info2['pad_bottom'] == 512 - rh and info2['pad_left'] + info2['pad_right'] == 0
+    # only_ds never upsamples
+    small = rs.randint(0, 256, size=(100, 200, 3), dtype=np.uint8)
+    out3, info3 = letter_resize_img(small, 640, only_ds=True)
+    assert info3['scale'] == 1.0 and out3.shape == (640, 640, 3)

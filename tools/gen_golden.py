@@ -77,6 +77,9 @@ def main():
     import models as ref_models
     import trainer as ref_trainer
     import utils as ref_utils
+    if sys.argv[1:] == ["--only", "g10"]:
+        gen_g10(ref_utils)
+        return
     from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_head_outputs, synth_targets
 
     os.makedirs(OUT, exist_ok=True)
@@ -453,8 +456,51 @@ def main():
         g9[f"gt{i}"] = a; g9[f"pred{i}"] = b
     np.savez_compressed(os.path.join(OUT, "g9_map.npz"), **g9)
 
+    gen_g10(ref_utils)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden written:", sorted(os.listdir(OUT)), f"{total / 1e6:.2f} MB")
+
+
+def gen_g10(ref_utils):
+    """G10 letterbox + collate format (utils/data_aug.py:21-70, utils/bbox_tools.py:38-49, dataset/data_collater.py:20-64).
+    OpenCV is absent here, so only geometries the reference handles without cv2 are run (scale == 1, training=True);
+    the nearest-neighbour resize itself stays unpinned."""
+    import importlib.util
+    import torch
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    sys.modules.setdefault("torchvision", tv)
+    spec = importlib.util.spec_from_file_location("ref_data_collater", os.path.join(REF, "dataset", "data_collater.py"))
+    coll = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(coll)
+    from yoloseries_amd.dataset.synthetic import SyntheticDetectionDataset
+    g = {}
+    shapes = [(480, 640), (640, 640), (640, 512), (640, 576)]
+    g["shapes"] = np.array(shapes)
+    items = []
+    for i, hw in enumerate(shapes):
+        ds = SyntheticDetectionDataset(8, img_hw=hw, num_class=80, max_boxes=12, seed=40 + i)
+        img, ann, iid = ds[i]
+        if i == 3:
+            ann = {'bboxes': np.zeros((0, 4), np.float32), 'classes': []}     # image without objects
+        items.append((img, ann, iid))
+        out, info = ref_utils.letter_resize_img(img, [640, 640])
+        g[f"lr{i}_info"] = np.array([info['scale'], info['pad_top'], info['pad_left'], info['pad_bottom'], info['pad_right'],
+                                      info['org_shape'][0], info['org_shape'][1]], np.float64)
+        g[f"lr{i}_sum"] = out.astype(np.float64).sum(axis=(0, 1))
+        g[f"lr{i}_sample"] = out.reshape(-1)[::997].copy()
+        if len(ann['classes']):
+            g[f"lb{i}"] = ref_utils.letter_resize_bbox(np.array(ann['bboxes'], np.float64).copy(), info)
+    g["dataset_args"] = np.array([8, 80, 12, 40])      # length, num_class, max_boxes, seed base (seed = base + i, item i)
+    batch = coll.fixed_imgsize_collate_fn(items, [640, 640])
+    g["c_ann"] = batch['ann'].numpy()
+    g["c_img_sum"] = batch['img'].double().sum(dim=(2, 3)).numpy()
+    g["c_img_sample"] = batch['img'].reshape(-1)[::9973].numpy()
+    g["c_info"] = np.array([[r['scale'], r['pad_top'], r['pad_left'], r['pad_bottom'], r['pad_right']] for r in batch['resize_info']], np.float64)
+    g["c_ids"] = np.array(batch['img_id'])
+    tb = coll.test_dataset_collate_fn([(torch.full((3, 64, 96), float(k)), {'scale': 1.0 + k}) for k in range(3)])
+    g["t_img_sum"] = tb['img'].double().sum(dim=(1, 2, 3)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g10_collate.npz"), **g)
 
 
 if __name__ == "__main__":

@@ -50,6 +50,31 @@ class SyntheticLoader:
             yield {'img': img.to(self.device, non_blocking=True), 'ann': ann.to(self.device, non_blocking=True)}
 
 
+class PrefetchedDataset:
+    """the reference's data path on a synthetic dataset: torch DataLoader -> fixed_imgsize_collate_fn
+    (dataset/data_collater.py:20-64) -> DataPrefetcher (dataset/data_prefetcher.py:6-56, train_yolov5.py:458-497)"""
+
+    def __init__(self, steps, batch, img, num_class, seed, workers=0):
+        from functools import partial
+        from torch.utils.data import DataLoader
+        from yoloseries_amd.dataset import DataPrefetcher, SyntheticDetectionDataset, fixed_imgsize_collate_fn
+        self._prefetcher = DataPrefetcher
+        ds = SyntheticDetectionDataset(steps * batch, img_hw=(int(img * 0.75) // 8 * 8, img), num_class=num_class, seed=seed)
+        self.loader = DataLoader(ds, batch_size=batch, shuffle=False, num_workers=workers, drop_last=True, pin_memory=True,
+                                 collate_fn=partial(fixed_imgsize_collate_fn, dst_size=[img, img]))
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        pf = self._prefetcher(self.loader)
+        for _ in range(len(self.loader)):
+            x = pf.next()
+            if x['img'] is None:
+                return
+            yield x
+
+
 class Training:
 
     def __init__(self, anchors, hyp):
@@ -77,8 +102,13 @@ class Training:
         hyp['lr'] = hyp['basic_lr_per_img'] * hyp['batch_size']                                      # :184
         torch.manual_seed(hyp['random_seed'])
         img = hyp['input_img_size'][0]
-        self.train_dataloader = SyntheticLoader(hyp['steps_per_epoch'], hyp['batch_size'], img, hyp['num_class'], self.device, 1 + self.rank)
-        self.val_dataloader = SyntheticLoader(hyp['val_batches'], hyp['batch_size'], img, hyp['num_class'], self.device, 101 + self.rank)
+        if hyp.get('data_source', 'tensor') == 'dataset':
+            self.train_dataloader = PrefetchedDataset(hyp['steps_per_epoch'], hyp['batch_size'], img, hyp['num_class'], 1 + self.rank,
+                                                      hyp.get('num_workers', 0))
+            self.val_dataloader = PrefetchedDataset(hyp['val_batches'], hyp['batch_size'], img, hyp['num_class'], 101 + self.rank)
+        else:
+            self.train_dataloader = SyntheticLoader(hyp['steps_per_epoch'], hyp['batch_size'], img, hyp['num_class'], self.device, 1 + self.rank)
+            self.val_dataloader = SyntheticLoader(hyp['val_batches'], hyp['batch_size'], img, hyp['num_class'], self.device, 101 + self.rank)
         hyp['warmup_steps'] = max(hyp.get('warmup_epoch', 3) * len(self.train_dataloader), 1)       # :192
         self.model = self.select_model().to(self.device)
         self.dp = DataParallelGrads(self.model) if self.is_distributed else None
@@ -223,6 +253,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int)
     ap.add_argument("--steps-per-epoch", type=int)
     ap.add_argument("--model-type")
+    ap.add_argument("--data", choices=["tensor", "dataset"], help="tensor: batches generated on the device; dataset: "
+                    "synthetic images through DataLoader + fixed_imgsize_collate_fn + DataPrefetcher (the reference's data path)")
     args = ap.parse_args(argv)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.cuda.set_device(get_local_rank())
@@ -233,6 +265,7 @@ def main(argv=None):
     if args.batch: hyp['batch_size'] = args.batch; hyp['accumulate_loss_step'] = args.batch   # noqa: E701,E702
     if args.steps_per_epoch: hyp['steps_per_epoch'] = args.steps_per_epoch  # noqa: E701
     if args.model_type: hyp['model_type'] = args.model_type              # noqa: E701
+    if args.data: hyp['data_source'] = args.data                         # noqa: E701
     anchors = torch.from_numpy(COCO_ANCHORS.copy())                      # train_yolov5.py:819
     t = Training(anchors, hyp)
     t.step()

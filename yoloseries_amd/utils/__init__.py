@@ -5,3 +5,4 @@ from .layer_tools import *  # noqa: F401,F403
 from .optim import *  # noqa: F401,F403
 from .dist import *  # noqa: F401,F403
 from .mAP import mAP_v2  # noqa: F401
+from .letterbox import letter_resize_bbox, letter_resize_img  # noqa: F401
