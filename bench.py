@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense MFMA peak, MI355X (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 TRAIN_GFLOP_PER_IMG = 49.30    # YOLOv5s@640: 3 x 16.434 GFLOP conv fwd
+# conv GFLOP per image at 640x640, forward only (v5m / v5x from the same census of this package's graph)
+FWD_GFLOP_640 = {"small": 16.434, "middle": 48.87, "large": 108.99, "xlarge": 218.56, "yolox_s": 24.14}
 
 
 def make_hyp(dev, img, batch):
@@ -76,6 +78,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--model", default="small", choices=["small", "middle", "large", "xlarge"])
+    ap.add_argument("--workload", default="train", choices=["train", "yolox", "infer"],
+                    help="train: YOLOv5 train step (BASELINE configs[1], the default and the judged metric); yolox: YOLOXs + SimOTA "
+                         "train step (configs[2]); infer: YOLOv5 eval forward + decode + class-aware NMS (configs[4]: --model xlarge --img 1280)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,24 +111,82 @@ def main():
     B, img = args.batch, args.img
     torch.manual_seed(0)
     cls = {"small": models.YOLOV5Small, "middle": models.YOLOV5Middle, "large": models.YOLOV5Large, "xlarge": models.YOLOV5XLarge}[args.model]
-    model = cls(3, 80).to(dev).train()
-    hyp = make_hyp(dev, img, B)
-    lossf = YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), hyp)
-    lr = 0.000625 * B                       # basic_lr_per_img x per-rank batch (train_yolov5.py:184)
-    opt = FlatSGD(model, lr=lr, momentum=0.937, weight_decay=1e-4, nesterov=True)
-    ema = ExponentialMovingAverageModel(model)
-    dp = DataParallelGrads(model) if world > 1 else None
     x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(rank), dtype=torch.float32).to(dev)
     t = torch.from_numpy(synth_targets(B, img, 80, 20, seed=1 + rank)).to(dev)
+    dp = None
+    extra = {}
+    if args.workload == "infer":
+        # eval forward (BN folded, SiLU in the conv epilogue) + fused decode / filter / class-aware NMS; only kept rows cross PCIe
+        from yoloseries_amd.trainer import YOLOV5Evaluator
+        from yoloseries_amd.utils.synth import synth_nms_heads
+        model = cls(3, 80).to(dev).eval()
+        ehyp = dict(device=dev, num_class=80, input_img_size=[img, img], iou_threshold=0.2, conf_threshold=0.3, cls_threshold=0.3,
+                    max_predictions_per_img=300, iou_type="iou", mutil_label=False, agnostic=True, postprocess_bbox=True, wfb=False,
+                    use_tta=False, half=False, compute_metric_conf_threshold=0.001, compute_metric_iou_threshold=0.65,
+                    compute_metric_cls_threshold=0.001)
+        ev = YOLOV5Evaluator(model, torch.from_numpy(COCO_ANCHORS).to(dev), ehyp, compute_metric=True)
+        gflop_img = FWD_GFLOP_640[args.model] * (img / 640.0) ** 2
+        metric = f"images/sec ({img}x{img}) YOLOv5{args.model[0]} inference (forward + decode + NMS)"
+        workload = (f"YOLOv5{args.model[0]} bf16 inference: eval forward + decode + filter(conf 0.001) + class-aware NMS, batch {B}/GPU x "
+                    f"{img}x{img} synthetic, random-init (BASELINE.json configs[4] shape)")
 
-    def step():
-        out = lossf(model(x), t)
-        out["tot_loss"].backward()
-        opt.clip_grad_norm_(10.0)
-        opt.step()
-        opt.zero_grad()
-        ema.update(model)
-        return out
+        def step():
+            return {"tot_loss": torch.zeros((), device=dev), "dets": ev(x)}
+
+        # a random-init net yields ~no detections: NMS throughput is measured on synthetic head tensors:
+        # ~1 % of the anchors pass conf 0.001, 50 clusters of overlapping boxes per image
+        nb = min(B, 16)
+        heads = [torch.from_numpy(h).to(dev) for h in synth_nms_heads(nb, img, 80, 3, seed=2, wh_shift=1.2)]
+        for _ in range(2):
+            res = ev._nms_from_heads(heads)
+        torch.cuda.synchronize()
+        t0n = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            res = ev._nms_from_heads(heads)
+        torch.cuda.synchronize()
+        dtn = (time.perf_counter() - t0n) / reps
+        kept = sum(0 if r is None else len(r) for r in res)
+        n_anchor = sum(3 * (img // s) ** 2 for s in (8, 16, 32))
+        ncand = sum(ev.last_ncand)
+        extra["nms_synthetic"] = {"images": nb, "anchors_per_image": n_anchor, "candidates_per_image": round(ncand / nb, 1),
+                                  "kept_boxes_per_image": round(kept / nb, 1), "images_per_s": round(nb / dtn, 1),
+                                  "anchors_per_s": round(nb * n_anchor / dtn), "candidate_boxes_per_s": round(ncand / dtn),
+                                  "kept_boxes_per_s": round(kept / dtn)}
+    else:
+        if args.workload == "yolox":
+            from yoloseries_amd.loss import YOLOXLoss
+            model = models.YOLOXSmall(1, 3, 80).to(dev).train()
+            hyp = dict(device=dev, num_class=80, input_img_size=[img, img], batch_size=B, use_focal_loss=False, focal_loss_gamma=1.5,
+                       focal_loss_alpha=0.25, iou_loss_scale=5.0, use_l1=True, l1_loss_scale=1.0, cls_loss_scale=1.0, cof_loss_scale=1.0,
+                       class_smooth_factor=1.0, cls_pos_weight=1.0, cof_pos_weight=1.0, num_anchors=1, iou_type="ciou", topk=13,
+                       center_radius=3, num_stage=3, loss_items_on_device=True)
+            lossf = YOLOXLoss(hyp)
+            gflop_img = 3 * FWD_GFLOP_640["yolox_s"] * (img / 640.0) ** 2
+            metric = f"images/sec ({img}x{img}) YOLOXs train-step"
+            workload = (f"YOLOXs bf16 train step (fwd+SimOTA loss+bwd+clip+SGD+EMA), batch {B}/GPU x {img}x{img} synthetic COCO-80, "
+                        f"random-init (BASELINE.json configs[2])")
+        else:
+            model = cls(3, 80).to(dev).train()
+            hyp = make_hyp(dev, img, B)
+            lossf = YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), hyp)
+            gflop_img = 3 * FWD_GFLOP_640[args.model] * (img / 640.0) ** 2
+            metric = f"images/sec ({img}x{img}) YOLOv5{args.model[0]} train-step"
+            workload = (f"YOLOv5{args.model[0]} bf16 train step (fwd+loss+bwd+clip+SGD+EMA), batch {B}/GPU x {img}x{img} synthetic COCO-80, "
+                        f"random-init (BASELINE.json configs[1])")
+        lr = 0.000625 * B                       # basic_lr_per_img x per-rank batch (train_yolov5.py:184)
+        opt = FlatSGD(model, lr=lr, momentum=0.937, weight_decay=1e-4, nesterov=True)
+        ema = ExponentialMovingAverageModel(model)
+        dp = DataParallelGrads(model) if world > 1 else None
+
+        def step():
+            out = lossf(model(x), t)
+            out["tot_loss"].backward()
+            opt.clip_grad_norm_(10.0)
+            opt.step()
+            opt.zero_grad()
+            ema.update(model)
+            return out
 
     def sync_all():
         if world > 1:
@@ -154,21 +217,20 @@ def main():
         else:
             roof = measure_roofline(model, step, B)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "train" and args.model == "small":
         try:
             cpu = cpu_baseline()
         except Exception as e:      # the oracle is test infrastructure; never let it fail the measurement
             cpu = {"error": repr(e)}
     if rank == 0:
         res = {
-            "metric": "images/sec (640x640) YOLOv5s train-step", "value": round(ips, 2), "unit": "images/sec",
+            "metric": metric, "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"YOLOv5{args.model[0]} bf16 train step (fwd+loss+bwd+clip+SGD+EMA), batch {B}/GPU x {img}x{img} synthetic COCO-80, "
-                                   f"random-init (BASELINE.json configs[1])", "global_batch": B * world, "parallelism": f"dp{world}"},
-            "train_tflops": round(ips * TRAIN_GFLOP_PER_IMG / 1000.0, 2),
-            "mfma_frac_step": round(ips * TRAIN_GFLOP_PER_IMG / 1000.0 / (MFMA_PEAK_TFLOPS * world), 4),
-            "final_loss": round(loss_val, 4),
+            "config": {"workload": workload, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "train_tflops": round(ips * gflop_img / 1000.0, 2),
+            "mfma_frac_step": round(ips * gflop_img / 1000.0 / (MFMA_PEAK_TFLOPS * world), 4),
+            "final_loss": round(loss_val, 4), **extra,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res))

@@ -101,6 +101,7 @@ class YOLOV5Evaluator:
                                out.data_ptr(), nkeep.data_ptr(), keep.data_ptr(), ws.data_ptr(), _lib.stream_ptr()), "yh_nms_batched")
         nc_h = ncand.cpu().tolist()
         nk_h = nkeep.cpu().tolist()
+        self.last_ncand = nc_h                 # candidates that entered NMS per image (bench.py reports boxes/s from it)
         out_h = out.cpu().numpy()
         return [None if nc_h[b] == 0 else out_h[b, :nk_h[b]].copy() for b in range(B)]
 

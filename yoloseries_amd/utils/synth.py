@@ -36,7 +36,7 @@ def synth_head_outputs(batch, img_size=640, num_class=80, num_anchor=3, seed=3, 
             for s in strides]
 
 
-def synth_nms_heads(batch, img_size=640, num_class=80, num_anchor=3, seed=2, frac=0.01, clusters=50, strides=(8, 16, 32)):
+def synth_nms_heads(batch, img_size=640, num_class=80, num_anchor=3, seed=2, frac=0.01, clusters=50, strides=(8, 16, 32), wh_shift=0.0):
     """Head tensors whose decode yields ~`frac` of the anchors above conf 0.001, grouped in
     overlapping clusters: objectness logits are shifted far negative except on
     cells near `clusters` random centres; class logits ~N(0,1) with one boosted class."""
@@ -49,6 +49,8 @@ def synth_nms_heads(batch, img_size=640, num_class=80, num_anchor=3, seed=2, fra
         h = w = img_size // s
         t = rs.randn(batch, num_anchor, E, h, w).astype(np.float32)
         t[:, :, 4] -= 12.0
+        if wh_shift:
+            t[:, :, 2:4] = t[:, :, 2:4] * 0.5 + wh_shift       # boxes of about (2*sigmoid(wh_shift))^2 anchors: distinct objects survive NMS
         n_pick = max(1, int(frac * num_anchor * h * w / clusters))
         for b in range(batch):
             for k in range(clusters):
