@@ -180,7 +180,9 @@ def main():
         dp = DataParallelGrads(model) if world > 1 else None
 
         def step():
-            out = lossf(model(x), t)
+            # YOLOXLoss converts the target boxes to xywh IN PLACE like the reference (loss/yolox_loss.py:70-75): every step
+            # gets a fresh copy, as a data loader would deliver
+            out = lossf(model(x), t.clone() if args.workload == "yolox" else t)
             out["tot_loss"].backward()
             opt.clip_grad_norm_(10.0)
             opt.step()

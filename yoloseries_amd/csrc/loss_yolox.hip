@@ -207,6 +207,148 @@ __global__ __launch_bounds__(1024) void yolox_assign_kernel(const XK p, const St
     const int Y = s_misc[3];
     if (Y == 0) { if (t == 0) *fg_count = 0; return; }
 
+    // ---- register-resident path (Y <= 8192 candidates, every 640x640 case): thread t owns candidates t, t+1024, ...;
+    // their decoded boxes stay in registers, IoU / cost of a (gt, candidate) pair are computed on the fly with the
+    // same fp32 expressions as the matrix path below, the ground truths are processed one after the other by the
+    // whole block, and each top-k pick is ONE block-wide arg-max (wave shuffle + 16 LDS slots, one barrier).
+    constexpr int MAXJ = 8;
+    if (Y <= MAXJ * 1024) {
+        __shared__ float s_rv[2][16];
+        __shared__ int s_ri[2][16];
+        float qx0[MAXJ], qy0[MAXJ], qx1[MAXJ], qy1[MAXJ];
+        int qxy[MAXJ], cnt_l[MAXJ], mgt_l[MAXJ];         // qxy: cell column | row << 16
+        unsigned invalid = 0;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int y = t + 1024 * j;
+            cnt_l[j] = 0; mgt_l[j] = -1; qxy[j] = 0;
+            qx0[j] = qy0[j] = qx1[j] = qy1[j] = 0.f;
+            if (y < Y) {
+                const int cell = cand[y];
+                const T* row = pred + (size_t)cell * st.ld;
+                const float gxc = (float)(cell % st.W), gyc = (float)(cell / st.W);
+                const float px = (ldx<T>(row) + gxc) * stride, py = (ldx<T>(row + 1) + gyc) * stride;
+                const float pw = expf(ldx<T>(row + 2)) * stride, ph = expf(ldx<T>(row + 3)) * stride;
+                qx0[j] = px - pw / 2.f; qy0[j] = py - ph / 2.f; qx1[j] = px + pw / 2.f; qy1[j] = py + ph / 2.f;
+                qxy[j] = (cell % st.W) | ((cell / st.W) << 16);
+            } else {
+                invalid |= 1u << j;
+            }
+        }
+        auto pair = [&](int g, int j, float& iou, float& cost) __attribute__((always_inline)) {
+            const float x = gt[g][0], yy = gt[g][1], w = gt[g][2], h = gt[g][3];
+            iou = iou_xyxy(x - w / 2.f, yy - h / 2.f, x + w / 2.f, yy + h / 2.f, qx0[j], qy0[j], qx1[j], qy1[j]);
+            const float cx = ((float)(qxy[j] & 0xffff) + 0.5f) * stride, cy = ((float)(qxy[j] >> 16) + 0.5f) * stride;
+            const float xmin = x + w * -0.5f, ymin = yy + h * -0.5f, xmax = x + w * 0.5f, ymax = yy + h * 0.5f;
+            const bool inb = fminf(fminf(-xmin + cx, -ymin + cy), fminf(xmax + -cx, ymax + -cy)) > eps;
+            const float r = d.center_radius;
+            const bool inc = fminf(fminf(cx + -(x + -r), cy + -(yy + -r)), fminf(-cx + (x + r), -cy + (yy + r))) > eps;
+            cost = (d.cls_cost_const + 3.f * (-logf(iou + 1e-9f))) + 100000.f * ((inb && inc) ? 0.f : 1.f);
+        };
+        const int K = d.topk < Y ? d.topk : Y;
+        int par = 0;
+        for (int g = 0; g < G; ++g) {
+            float vio[MAXJ], vco[MAXJ];
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                vio[j] = -INFINITY; vco[j] = INFINITY;
+                if (!(invalid & (1u << j))) pair(g, j, vio[j], vco[j]);
+            }
+            // sum of the K largest IoUs, picked in (value desc, index asc) order
+            unsigned taken = invalid;
+            float ksum = 0.f;
+            for (int k = 0; k < K; ++k) {
+                float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j)
+                    if (!(taken & (1u << j)) && (vio[j] > bv || (vio[j] == bv && t + 1024 * j < bi))) { bv = vio[j]; bi = t + 1024 * j; }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) { s_rv[par][wv] = bv; s_ri[par][wv] = bi; }
+                __syncthreads();
+                bv = s_rv[par][0]; bi = s_ri[par][0];
+#pragma unroll
+                for (int w = 1; w < 16; ++w) {
+                    const float ov = s_rv[par][w]; const int oi = s_ri[par][w];
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                par ^= 1;
+                ksum += bv;
+                if ((bi & 1023) == t) taken |= 1u << (bi >> 10);
+            }
+            int dk = (int)ksum;
+            dk = dk < 1 ? 1 : (dk > Y ? Y : dk);
+            taken = invalid;
+            for (int k = 0; k < dk; ++k) {          // dk smallest costs, (value asc, index asc)
+                float bv = INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j)
+                    if (!(taken & (1u << j)) && (vco[j] < bv || (vco[j] == bv && t + 1024 * j < bi))) { bv = vco[j]; bi = t + 1024 * j; }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) { s_rv[par][wv] = bv; s_ri[par][wv] = bi; }
+                __syncthreads();
+                bv = s_rv[par][0]; bi = s_ri[par][0];
+#pragma unroll
+                for (int w = 1; w < 16; ++w) {
+                    const float ov = s_rv[par][w]; const int oi = s_ri[par][w];
+                    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                par ^= 1;
+                if (bi == 0x7fffffff) break;          // block-uniform
+                if ((bi & 1023) == t) {
+                    const int jj = bi >> 10;
+                    taken |= 1u << jj;
+#pragma unroll
+                    for (int j = 0; j < MAXJ; ++j)
+                        if (j == jj) { cnt_l[j] += 1; mgt_l[j] = g; }
+                }
+            }
+        }
+        // conflicts: a candidate claimed by several gts goes to the one with the smallest cost over ALL gts (:341-346)
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            if (cnt_l[j] > 1) {
+                float bv = INFINITY; int bg = 0;
+                for (int g = 0; g < G; ++g) { float io, co; pair(g, j, io, co); if (co < bv) { bv = co; bg = g; } }
+                mgt_l[j] = bg;
+            }
+        }
+        // ordered foreground list
+        if (t == 0) s_misc[4] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            if (1024 * j >= Y) break;                 // block-uniform
+            const bool f = cnt_l[j] > 0;
+            const unsigned long long bal = __ballot(f);
+            if (lane == 0) s_cnt[wv] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 16; ++w) { if (w < wv) before += s_cnt[w]; total += s_cnt[w]; }
+            const int base = s_misc[4];
+            if (f) {
+                const int pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));
+                float io, co;
+                pair(mgt_l[j], j, io, co);
+                const int cell = (qxy[j] >> 16) * st.W + (qxy[j] & 0xffff);
+                fg_cell[pos] = cell;
+                fg_gt[pos] = gt_row[mgt_l[j]];
+                fg_iou[pos] = io;
+                cellmap[cell] = pos;
+            }
+            __syncthreads();
+            if (t == 0) s_misc[4] = base + total;
+            __syncthreads();
+        }
+        if (t == 0) *fg_count = s_misc[4];
+        return;
+    }
+
     // ---- IoU and cost matrices (label_assign :131-149)
     for (int e = t; e < G * Y; e += 1024) {
         const int g = e / Y, y = e - g * Y;
