@@ -92,10 +92,14 @@ __device__ __forceinline__ float iou_xyxy(float ax0, float ay0, float ax1, float
 struct StageX { const void* pred; void* gpred; int s, H, W, ld; float stride; };
 
 // ------------------------------------------------------------------------------------------------
+struct StagesX { StageX s[MAXS]; };
+
+// grid (B, stages): the stages are matched independently (loss/yolox_loss.py:60-69) and share one launch
 template <typename T>
-__global__ __launch_bounds__(1024) void yolox_assign_kernel(const XK p, const StageX st, const float* __restrict__ targets,
+__global__ __launch_bounds__(1024) void yolox_assign_kernel(const XK p, const StagesX sts, const float* __restrict__ targets,
                                                             unsigned char* __restrict__ wsb, unsigned char* __restrict__ svb)
 {
+    const StageX st = sts.s[blockIdx.y];
     __shared__ float gt[MAXG][4];          // x, y, w, h (pixels)
     __shared__ int gt_row[MAXG];
     __shared__ int s_near[MAXG];
@@ -792,12 +796,17 @@ extern "C" int yh_yolox_loss_fwd(const yh_yolox_desc* d, const void* const* pred
     unsigned char* wsb = (unsigned char*)ws;
     double* part = reinterpret_cast<double*>(wsb + k.L.w_part);
     const int nb_fg = 256, nb_obj = 512;
+    StagesX all;
     for (int s = 0; s < d->num_stage; ++s) {
         YH_CHECK_ARG(preds[s] && yh_aligned16(preds[s]), "yh_yolox_loss_fwd: preds[%d] null/unaligned", s);
-        StageX sg; sg.pred = preds[s]; sg.gpred = nullptr; sg.s = s; sg.H = d->H[s]; sg.W = d->W[s]; sg.ld = d->ldp[s];
+        StageX& sg = all.s[s];
+        sg.pred = preds[s]; sg.gpred = nullptr; sg.s = s; sg.H = d->H[s]; sg.W = d->W[s]; sg.ld = d->ldp[s];
         sg.stride = d->img_size0 / (float)d->H[s];
-        if (d->pred_is_f32) hipLaunchKernelGGL((yolox_assign_kernel<float>), dim3(d->B), dim3(1024), 0, st, k, sg, targets_xywh, wsb, sv);
-        else                hipLaunchKernelGGL((yolox_assign_kernel<uint16_t>), dim3(d->B), dim3(1024), 0, st, k, sg, targets_xywh, wsb, sv);
+    }
+    if (d->pred_is_f32) hipLaunchKernelGGL((yolox_assign_kernel<float>), dim3(d->B, d->num_stage), dim3(1024), 0, st, k, all, targets_xywh, wsb, sv);
+    else                hipLaunchKernelGGL((yolox_assign_kernel<uint16_t>), dim3(d->B, d->num_stage), dim3(1024), 0, st, k, all, targets_xywh, wsb, sv);
+    for (int s = 0; s < d->num_stage; ++s) {
+        const StageX sg = all.s[s];
         if (d->pred_is_f32) {
             hipLaunchKernelGGL((yolox_fg_kernel<float, false>), dim3(nb_fg), dim3(256), 0, st, k, sg, targets_xywh, sv, part, (const float*)nullptr);
             hipLaunchKernelGGL((yolox_obj_fwd_kernel<float>), dim3(nb_obj), dim3(256), 0, st, k, sg, sv, part);
