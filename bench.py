@@ -44,7 +44,20 @@ def cpu_baseline(budget_s=20.0, batch=4, img=640):
     from oracle.v5net import V5NetOracle
     from yoloseries_amd import models
     from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
-    cores = os.cpu_count() or 1
+    # the threads this process may actually run on (a 1-GPU box shares its host: affinity / cgroup share, not the
+    # socket's core count — 256 OpenMP threads on a 16-CPU share ran 40x slower than 16), capped at 16
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                cores = min(cores, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = V5NetOracle(models.YOLOV5Small(3, 80).state_dict(), train=True)

@@ -431,17 +431,22 @@ __global__ __launch_bounds__(1024) void v5_finalize_kernel(const LossK p, const 
 }
 
 // ---------------------------------------------------------------- backward
-// One thread per 8-channel chunk of the gradient tensor: zeros, plus objectness gradients.
+// Whole gradient tensor = zeros + objectness gradients.  A block walks tiles of 64 pixels: first ONE THREAD PER
+// (pixel, anchor) evaluates the objectness gradient (dense lanes: BCE / focal terms, positive-list lookup) into LDS,
+// then all threads stream the tile's 16-byte chunks.  (One thread per chunk with the objectness math inlined left
+// 6 of 64 lanes busy in that branch while every wave paid for it: 0.5 ms for the stride-8 head.)
 template <typename T>
 __global__ __launch_bounds__(256) void v5_obj_bwd_kernel(const LossK p, const Stage st, const float* __restrict__ gout,
                                                          const double* __restrict__ bal_used, const float* __restrict__ ciou,
                                                          const int32_t* __restrict__ next, const int32_t* __restrict__ head)
 {
+    constexpr int TP = 64;                 // pixels per tile
+    __shared__ float sG[TP * 4];
     const yh_v5loss_desc& d = p.d;
     const int s = st.s, A = d.num_anchor, E = 5 + d.num_class;
     const int cpr = st.ld / 8;
-    const long npix = (long)d.B * st.H * st.W;
-    const long nchunk = npix * cpr;
+    const int npix = d.B * st.H * st.W;
+    const int t = threadIdx.x;
     const T* pred = reinterpret_cast<const T*>(st.pred);
     T* gp = reinterpret_cast<T*>(st.gpred);
     const int32_t* hd = head + p.L.head_off[s];
@@ -449,38 +454,52 @@ __global__ __launch_bounds__(256) void v5_obj_bwd_kernel(const LossK p, const St
     const float* ci = ciou + (size_t)s * p.L.cap;
     const double s3 = 3.0 / d.num_stage;
     const float coef = (float)((double)(*gout) * d.B * d.cof_scale * s3 * (d.num_stage == 3 ? 1.0 : 1.4) * bal_used[s] / (double)p.L.ncell[s]);
-    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < nchunk; id += (long)gridDim.x * blockDim.x) {
-        const long pix = id / cpr;
-        const int c0 = (int)(id - pix * cpr) * 8;
-        float g[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = 0.f;
-        // objectness channels are a*E+4; at most one falls into an 8-wide chunk when E >= 8
-        for (int a = 0; a < A; ++a) {
-            const int ch = a * E + 4;
-            if (ch >= c0 && ch < c0 + 8) {
-                const int x = (int)(pix % st.W);
-                const long r2 = pix / st.W;
-                const int y = (int)(r2 % st.H);
-                const int img = (int)(r2 / st.H);
-                const float lg = ldp<T>(pred + (size_t)pix * st.ld + ch);
+    const int ntile = (npix + TP - 1) / TP;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int pix0 = tile * TP;
+        if (t < TP * A) {
+            const int pl = t / A, a = t - pl * A;
+            const int pix = pix0 + pl;
+            float gv = 0.f;
+            if (pix < npix) {
+                const int x = pix % st.W;
+                const int r2 = pix / st.W;
+                const int y = r2 % st.H;
+                const int img = r2 / st.H;
+                const float lg = ldp<T>(pred + (size_t)pix * st.ld + a * E + 4);
                 const int h = hd[((img * A + a) * st.H + y) * st.W + x];
                 float tt = 0.f;
                 if (h >= 0) tt = fmaxf(ci[list_max(nx, h)], 0.f);
                 float dl, df = 0.f, f = 1.f;
                 const float l = bce_logits(lg, tt, d.cof_pos_weight, &dl);
                 if (d.use_focal) f = focal_factor(lg, tt, d.focal_gamma, d.focal_alpha, &df);
-                g[ch - c0] = coef * (dl * f + l * df);
+                gv = coef * (dl * f + l * df);
+            }
+            sG[pl * 4 + a] = gv;
+        }
+        __syncthreads();
+        for (int i = t; i < TP * cpr; i += 256) {
+            const int pl = i / cpr;
+            const int c0 = (i - pl * cpr) * 8;
+            const int pix = pix0 + pl;
+            if (pix >= npix) break;
+            float g[8];
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) g[e2] = 0.f;
+            for (int a = 0; a < A; ++a) {                       // objectness channels are a*E+4
+                const int ch = a * E + 4;
+                if (ch >= c0 && ch < c0 + 8) g[ch - c0] = sG[pl * 4 + a];
+            }
+            T* dst = gp + (size_t)pix * st.ld + c0;
+            if (sizeof(T) == 2) {
+                *reinterpret_cast<uint4*>(dst) = pack8(g);
+            } else {
+                float4* d4 = reinterpret_cast<float4*>(dst);
+                d4[0] = make_float4(g[0], g[1], g[2], g[3]);
+                d4[1] = make_float4(g[4], g[5], g[6], g[7]);
             }
         }
-        T* dst = gp + (size_t)pix * st.ld + c0;
-        if (sizeof(T) == 2) {
-            *reinterpret_cast<uint4*>(dst) = pack8(g);
-        } else {
-            float4* d4 = reinterpret_cast<float4*>(dst);
-            d4[0] = make_float4(g[0], g[1], g[2], g[3]);
-            d4[1] = make_float4(g[4], g[5], g[6], g[7]);
-        }
+        __syncthreads();
     }
 }
 
@@ -653,8 +672,8 @@ extern "C" int yh_v5_loss_bwd(const yh_v5loss_desc* d, const void* const* preds,
     for (int s = 0; s < d->num_stage; ++s) {
         YH_CHECK_ARG(preds[s] && gpreds[s] && yh_aligned16(gpreds[s]), "yh_v5_loss_bwd: stage %d pointers null/unaligned", s);
         Stage sg; sg.pred = preds[s]; sg.gpred = gpreds[s]; sg.s = s; sg.H = d->H[s]; sg.W = d->W[s]; sg.ld = d->ldp[s];
-        long nchunk = (long)d->B * sg.H * sg.W * (sg.ld / 8);
-        int gb = (int)((nchunk + 255) / 256 > 8192 ? 8192 : (nchunk + 255) / 256);
+        const long ntile = ((long)d->B * sg.H * sg.W + 63) / 64;
+        int gb = (int)(ntile > 4096 ? 4096 : ntile);
         if (d->pred_is_f32) {
             hipLaunchKernelGGL((v5_obj_bwd_kernel<float>), dim3(gb), dim3(256), 0, st, k, sg, gout, bal_used, ciou, next, head);
             hipLaunchKernelGGL((v5_pos_bwd_kernel<float>), dim3(nb_pos), dim3(256), 0, st, k, sg, gout, count, tbox, tidx, next, head);

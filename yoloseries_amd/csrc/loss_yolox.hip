@@ -720,42 +720,61 @@ __global__ __launch_bounds__(1024) void yolox_finalize_kernel(const XK p, const 
     result[7] = 0.f;
 }
 
-// whole gradient tensor: zeros + objectness gradient (channel 4); fg_bwd then fills the other channels of fg cells
+// whole gradient tensor: zeros + objectness gradient (channel 4); fg_bwd then fills the other channels of fg cells.
+// Tiles of 256 cells: one thread per cell evaluates the objectness gradient (dense lanes) into LDS, then the block
+// streams the tile's 16-byte chunks.
 template <typename T>
 __global__ __launch_bounds__(256) void yolox_obj_bwd_kernel(const XK p, const StageX st, const unsigned char* __restrict__ svb,
                                                             const float* __restrict__ gout)
 {
+    constexpr int TP = 256;
+    __shared__ float sG[TP];
     const yh_yolox_desc& d = p.d;
     const int s = st.s, n = st.H * st.W;
     const int cpr = st.ld / 8;
-    const long nchunk = (long)d.B * n * cpr;
+    const long ncell = (long)d.B * n;
+    const int t = threadIdx.x;
     const int32_t* cellmap = reinterpret_cast<const int32_t*>(svb + p.L.cellmap) + p.L.cell_off[s];
     const int32_t* nfg_stage = reinterpret_cast<const int32_t*>(svb + p.L.nfg_stage);
     const double* bal_used = reinterpret_cast<const double*>(svb + p.L.bal_used);
     const T* pred = reinterpret_cast<const T*>(st.pred);
     T* gp = reinterpret_cast<T*>(st.gpred);
     const float coef = (float)((double)(*gout) * d.cof_scale * bal_used[s] / (double)(nfg_stage[s] > 1 ? nfg_stage[s] : 1));
-    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < nchunk; id += (long)gridDim.x * blockDim.x) {
-        const long cell = id / cpr;
-        const int c0 = (int)(id - cell * cpr) * 8;
-        float g[8];
+    const long ntile = (ncell + TP - 1) / TP;
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long cell0 = tile * TP;
+        {
+            const long cell = cell0 + t;
+            float gv = 0.f;
+            if (cell < ncell) {
+                const float x = ldx<T>(pred + (size_t)cell * st.ld + 4);
+                const float tt = cellmap[cell] >= 0 ? 1.f : 0.f;
+                float dx, fdx = 0.f, f = 1.f;
+                const float l = bce_logits(x, tt, d.cof_pos_weight, &dx, nullptr);
+                if (d.use_focal) f = focal_factor(x, tt, d.focal_gamma, d.focal_alpha, &fdx, nullptr);
+                gv = coef * (dx * f + l * fdx);
+            }
+            sG[t] = gv;
+        }
+        __syncthreads();
+        for (int i = t; i < TP * cpr; i += 256) {
+            const int pl = i / cpr;
+            const int c0 = (i - pl * cpr) * 8;
+            const long cell = cell0 + pl;
+            if (cell >= ncell) break;
+            float g[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = 0.f;
-        if (c0 == 0) {
-            const float x = ldx<T>(pred + (size_t)cell * st.ld + 4);
-            const float tt = cellmap[cell] >= 0 ? 1.f : 0.f;
-            float dx, fdx = 0.f, f = 1.f;
-            const float l = bce_logits(x, tt, d.cof_pos_weight, &dx, nullptr);
-            if (d.use_focal) f = focal_factor(x, tt, d.focal_gamma, d.focal_alpha, &fdx, nullptr);
-            g[4] = coef * (dx * f + l * fdx);
+            for (int e = 0; e < 8; ++e) g[e] = 0.f;
+            if (c0 == 0) g[4] = sG[pl];
+            T* dst = gp + (size_t)cell * st.ld + c0;
+            if (sizeof(T) == 2) *reinterpret_cast<uint4*>(dst) = pack8(g);
+            else {
+                float4* d4 = reinterpret_cast<float4*>(dst);
+                d4[0] = make_float4(g[0], g[1], g[2], g[3]);
+                d4[1] = make_float4(g[4], g[5], g[6], g[7]);
+            }
         }
-        T* dst = gp + (size_t)cell * st.ld + c0;
-        if (sizeof(T) == 2) *reinterpret_cast<uint4*>(dst) = pack8(g);
-        else {
-            float4* d4 = reinterpret_cast<float4*>(dst);
-            d4[0] = make_float4(g[0], g[1], g[2], g[3]);
-            d4[1] = make_float4(g[4], g[5], g[6], g[7]);
-        }
+        __syncthreads();
     }
 }
 
@@ -833,8 +852,8 @@ extern "C" int yh_yolox_loss_bwd(const yh_yolox_desc* d, const void* const* pred
         YH_CHECK_ARG(preds[s] && gpreds[s] && yh_aligned16(gpreds[s]), "yh_yolox_loss_bwd: stage %d pointers null/unaligned", s);
         StageX sg; sg.pred = preds[s]; sg.gpred = gpreds[s]; sg.s = s; sg.H = d->H[s]; sg.W = d->W[s]; sg.ld = d->ldp[s];
         sg.stride = d->img_size0 / (float)d->H[s];
-        long nchunk = (long)d->B * sg.H * sg.W * (sg.ld / 8);
-        int gb = (int)((nchunk + 255) / 256 > 4096 ? 4096 : (nchunk + 255) / 256);
+        const long ntile = ((long)d->B * sg.H * sg.W + 255) / 256;
+        int gb = (int)(ntile > 4096 ? 4096 : ntile);
         if (d->pred_is_f32) {
             hipLaunchKernelGGL((yolox_obj_bwd_kernel<float>), dim3(gb), dim3(256), 0, st, k, sg, sv, gout);
             hipLaunchKernelGGL((yolox_fg_kernel<float, true>), dim3(256), dim3(256), 0, st, k, sg, targets_xywh, sv, (double*)nullptr, gout);
