@@ -91,11 +91,13 @@ typedef struct yh_conv_desc {
      * as per-block partial sums: stats[(blk*2+0)*Npad + n] = sum, [(blk*2+1)*Npad+n] = sumsq,
      * blk in [0, yh_conv_stat_blocks()).  NULL: not collected.                   */
     float*   stats;
-    /* launch tuning (0 = library default): output-channel tile width 32/64/128 and the cap on persistent
-     * blocks along the pixel axis.  Results are identical for every setting except the number (and so the
+    /* launch tuning (0 = library default): output-channel tile width 32/64/128, channels per k-step and the cap on
+     * persistent blocks along the pixel axis.  Results are identical for every setting except the number (and so the
      * summation grouping) of the statistics rows; yh_conv_stat_blocks() honours both.            */
     int32_t  tile_n;
     int32_t  grid_cap;
+    int32_t  tile_k;      /* channels per k-step, 32 or 64 (64 needs every segment C % 64 == 0 and the 128-wide tile) */
+    int32_t  reserved0;
 } yh_conv_desc;
 
 /* number of partial-sum rows the conv kernel writes for this shape */

@@ -725,6 +725,7 @@ int pick_bkt(const yh_conv_desc* d, int bn) {
     if (bn != 128) return 32;              // measured: the narrower tiles lose more from the lower residency than they gain
     if (d->nseg < 1 || d->nseg > 2) return 32;
     for (int s = 0; s < d->nseg; ++s) if (d->seg[s].C % 64) return 32;
+    if (d->tile_k == 32) return 32;
     { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 64)) return 32; }
     return 64;
 }

@@ -394,6 +394,53 @@ class Program:
         d.w, d.N, d.Npad = wp, op.N, npad
         return d
 
+    def _tune_conv(self, d, kind, name, stats_ok=False):
+        """Launch parameters of one conv / dgrad launch (k-step width, cap on persistent blocks), timed once when the
+        program is built: the best setting differs per layer shape by 5-20 % (YH_CONV_TUNE=0: library defaults).
+        Results never change (identical math); only the number of BatchNorm partial-sum rows follows the grid."""
+        if os.environ.get("YH_CONV_TUNE", "1") == "0":
+            return
+        key = f"conv:{kind}:" + ",".join(str(int(v)) for v in (
+            d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
+            d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
+            int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale))))
+        cache = _tune_cache()
+        if key in cache:
+            d.tile_k, d.grid_cap = (int(v) for v in cache[key])
+            return
+        L = self.L
+        saved = (d.seg[0].ptr, d.stats)
+        if not d.seg[0].ptr:
+            d.seg[0].ptr = self.gy_scratch.data_ptr()
+        d.tile_k = d.grid_cap = 0
+        base = L.yh_conv_stat_blocks(C.byref(d))
+        tmp_stats = None
+        if stats_ok:
+            tmp_stats = torch.zeros(2 * base + 8, 2, d.Npad, dtype=torch.float32, device=self.dev)
+            d.stats = tmp_stats.data_ptr()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        best, best_ms = (0, 0), None
+        tks = (0, 32) if all(d.seg[i].C % 64 == 0 for i in range(d.nseg)) and d.N > 64 else (0,)
+        for tk in tks:
+            for cap in (0, 2 * base):
+                d.tile_k, d.grid_cap = tk, cap
+                if cap and L.yh_conv_stat_blocks(C.byref(d)) == base:
+                    continue                       # fewer tiles than blocks: the cap changes nothing
+                check(L.yh_conv_igemm(C.byref(d), st), f"yh_conv_igemm tune [{name}]")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    L.yh_conv_igemm(C.byref(d), st)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if best_ms is None or ms < best_ms * 0.97:       # keep the default unless clearly better
+                    best, best_ms = (tk, cap), ms
+        d.tile_k, d.grid_cap = best
+        d.seg[0].ptr, d.stats = saved
+        cache[key] = [int(best[0]), int(best[1])]
+        _tune_cache.dirty = True
+
     def _build_forward(self):
         B, pk, L = self.B, self.pack, self.L
         self.cmd_train, self.cmd_eval = [], []
@@ -422,6 +469,7 @@ class Program:
             d = self._conv_desc(op, True)
             d.act = YH_ACT_NONE
             d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
+            self._tune_conv(d, 'fwd', op.name, stats_ok=True)
             nblk = L.yh_conv_stat_blocks(C.byref(d))
             st['stats'] = torch.zeros(nblk, 2, op.Npad, dtype=torch.float32, device=self.dev)
             d.stats = st['stats'].data_ptr()
@@ -633,6 +681,7 @@ class Program:
                     acc = claim(Ref(sg.buf, sg.coff, sg.C))
                     gl = Slice(sg.buf.g, sg.coff, sg.C)
                     self._keep.append(d)
+                    self._tune_conv(d, 'dgrad', op.name)
                     cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C)))
                     cmds.append((L.yh_upsample2_bwd, (tmp.data_ptr(), sg.C, B, sg.buf.H, sg.buf.W, sg.C, gl.ptr(), gl.ld, acc), op.name, ('yh_upsample2_bwd', 0)))
                 else:
@@ -640,6 +689,7 @@ class Program:
                     gl = Slice(sg.buf.g, sg.coff, sg.C)
                     d.out0, d.ld0, d.accumulate = gl.ptr(), gl.ld, acc
                     self._keep.append(d)
+                    self._tune_conv(d, 'dgrad', op.name)
                     cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C)))
         self.cmd_bwd = cmds
         self.bwd_buckets = plan_grad_buckets(marks, pk.gsize, int(os.environ.get("YH_DP_BUCKETS", "4")))
