@@ -710,6 +710,161 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stem ("focus") kernel: 3x3 / stride 1 / pad 1 on the 16-channel space-to-depth image, 32 output channels
+// (utils/layer_tools.py:82-94 applied to models/normal/yolov5s.py's 6x6/s2 stem).  K per tap is exactly one
+// v_mfma_f32_32x32x16_bf16, the whole weight matrix (9 fragments) lives in registers, and a WAVE works alone on strips
+// of 32 consecutive output pixels of one image row: 9 coalesced 1-KB loads (one per tap, fragments straight from
+// global memory in MFMA layout, hardware zero fill at the borders), 9 MFMAs, no LDS staging, no barriers.
+// The MFMA runs with swapped operands (D = W x X^T): a lane then holds 4 consecutive CHANNELS of one pixel per
+// accumulator group, lanes l and l+32 exchange halves with v_permlane32_swap, and every lane stores two 16-byte
+// chunks.  BatchNorm statistics are per-lane running sums over all strips of the wave, reduced once at the end.
+// The layer moves 630 MB for 0.6 GFLOP/MB: it is HBM bound.
+struct StemTag {};
+
+template <int EPI>    // 0 plain, 1 + BatchNorm partial sums, 2 folded BN (scale, shift) + SiLU
+__global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvK p)
+{
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ float sRed[4][2][32];
+    const yh_conv_desc& d = p.d;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int W = d.Wo, H = d.Ho;
+    const int ldx = d.seg[0].ld * 2;                  // bytes per input pixel
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg[0].ptr, 0, p.segbytes[0], 0x00020000);
+
+    // weights: fragment of tap t for this lane = W[n = r][t*16 + 8h .. +8]
+    bf16x8_t wf[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+        wf[tp] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(d.w + (size_t)r * p.Ktot + tp * 16 + 8 * h));
+
+    // channels of this lane after the MFMA: group g (0..3) -> 8g + 4h + (0..3)
+    float scl[16], sft[16];
+    if (EPI == 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { scl[g * 4 + e] = d.scale[8 * g + 4 * h + e]; sft[g * 4 + e] = d.shift[8 * g + 4 * h + e]; }
+    }
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+
+    const int nstrip = p.M >> 5;                      // W % 32 == 0: strips never cross an image row
+    const int wstride = gridDim.x * 4;
+    const int spr = W >> 5;                           // strips per row
+
+    u32x4_t xa[2][9];
+    auto issue = [&](int s, int set) __attribute__((always_inline)) {
+        const int rowid = s / spr;                    // img*H + ho
+        const int wo0 = (s - rowid * spr) << 5;
+        const int ho = rowid % H;
+        const unsigned base = (unsigned)((rowid * W + wo0 + r) * ldx + h * 16);
+        const bool lok = (wo0 + r) > 0, rok = (wo0 + r) < W - 1;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const bool row_ok = (ho + kh - 1) >= 0 && (ho + kh - 1) < H;        // wave-uniform
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const bool ok = row_ok && (kw == 0 ? lok : (kw == 2 ? rok : true));
+                const unsigned vo = base + (unsigned)(((kh - 1) * W + (kw - 1)) * ldx);
+                if (set == 0) xa[0][kh * 3 + kw] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? vo : OOB, 0, 0);
+                else          xa[1][kh * 3 + kw] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ok ? vo : OOB, 0, 0);
+            }
+        }
+    };
+    auto compute = [&](int s, int set) __attribute__((always_inline)) {
+        f32x16_t acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tp], __builtin_bit_cast(bf16x8_t, set == 0 ? xa[0][tp] : xa[1][tp]), acc, 0, 0, 0);
+        // acc[g*4 + e]: pixel r, channel 8g + 4h + e
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[g * 4 + e];
+                if (EPI == 2) { v[e] = v[e] * scl[g * 4 + e] + sft[g * 4 + e]; if (d.act == YH_ACT_SILU) v[e] = silu_fast(v[e]); }
+            }
+            pk[g][0] = pack2(v[0], v[1]);
+            pk[g][1] = pack2(v[2], v[3]);
+            if (EPI == 1) {                           // statistics of the stored (bf16-rounded) values
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float q = __uint_as_float(e & 1 ? (pk[g][e >> 1] & 0xffff0000u) : (pk[g][e >> 1] << 16));
+                    ssum[g * 4 + e] += q; ssq[g * 4 + e] += q * q;
+                }
+            }
+        }
+        // lanes l / l+32: lower half keeps its channels 8g..8g+3 of g = 0, 2 and receives 8g+4..8g+7 from the upper
+        // half; the upper half ends up with the 16-byte chunks of g = 1, 3
+        uint4 c01, c23;
+        {
+            auto a0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            auto a1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            auto b0 = __builtin_amdgcn_permlane32_swap(pk[2][0], pk[3][0], false, false);
+            auto b1 = __builtin_amdgcn_permlane32_swap(pk[2][1], pk[3][1], false, false);
+            c01 = make_uint4(a0[0], a1[0], a0[1], a1[1]);
+            c23 = make_uint4(b0[0], b1[0], b0[1], b1[1]);
+        }
+        const size_t m = (size_t)s * 32 + r;
+        uint16_t* dst = d.out0 + m * d.ld0 + 8 * h;
+        *reinterpret_cast<uint4*>(dst) = c01;            // channels  0..7  (h = 0) /  8..15 (h = 1)
+        *reinterpret_cast<uint4*>(dst + 16) = c23;       // channels 16..23 (h = 0) / 24..31 (h = 1)
+    };
+
+    int s = blockIdx.x * 4 + wave;
+    if (s < nstrip) issue(s, 0);
+    for (; s < nstrip; s += 2 * wstride) {
+        const int s1 = s + wstride, s2 = s + 2 * wstride;
+        if (s1 < nstrip) issue(s1, 1);
+        compute(s, 0);
+        if (s1 < nstrip) {
+            if (s2 < nstrip) issue(s2, 0);
+            compute(s1, 1);
+        }
+    }
+
+    if (EPI == 1) {
+        // lane holds 16 channels x its pixel column: sum over the 32 pixel lanes of each half, then over the waves
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float a = ssum[e], q = ssq[e];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+            if (r == 0) { const int ch = 8 * (e >> 2) + 4 * h + (e & 3); sRed[wave][0][ch] = a; sRed[wave][1][ch] = q; }
+        }
+        __syncthreads();
+        if (t < 64) {
+            const int which = t >> 5, ch = t & 31;
+            const float v = sRed[0][which][ch] + sRed[1][which][ch] + sRed[2][which][ch] + sRed[3][which][ch];
+            d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + ch] = v;
+        }
+    }
+}
+
+// geometry the stem kernel covers
+bool stem_eligible(const yh_conv_desc* d)
+{
+    if (d->mode != YH_CONV_FWD || d->nseg != 1 || d->seg[0].C != 16 || d->seg[0].ups) return false;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->N != 32 || d->Npad < 32) return false;
+    if (d->Wo % 32 || d->bias || d->res || d->accumulate || d->nsplit < d->N) return false;
+    if ((d->scale == nullptr) != (d->shift == nullptr)) return false;
+    if (d->stats && d->scale) return false;
+    if (!d->scale && d->act != YH_ACT_NONE) return false;
+    const unsigned long npix = (unsigned long)d->B * d->Hi * d->Wi;
+    if (((npix - 1) * d->seg[0].ld + 16) * 2 >= (1ul << 31) || (long)d->B * d->Ho * d->Wo >= (1L << 31) - 64) return false;
+    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 256)) return false; }
+    return true;
+}
+constexpr int STEM_BLOCKS = 256 * 2;
+
 template <int BN, int WM, int WN, int BKT = 32>
 constexpr size_t conv_smem_bytes() {
     size_t a = 2 * (BM + BN) * (BKT + 8) * 2;
@@ -732,6 +887,11 @@ int pick_bkt(const yh_conv_desc* d, int bn) {
 
 void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
     long M = (long)d->B * d->Ho * d->Wo;
+    if (stem_eligible(d)) {
+        const long blocks = (M / 32 + 3) / 4;
+        *gx = (int)(blocks < STEM_BLOCKS ? blocks : STEM_BLOCKS); *gy = 1; *bn = 32;
+        return;
+    }
     int mtiles = (int)((M + BM - 1) / BM);
     int b = (d->tile_n == 32 || d->tile_n == 64 || d->tile_n == 128) ? d->tile_n : pick_bn(d->N);
     int nt = (d->N + b - 1) / b;
@@ -837,6 +997,17 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         k.wbytes = (unsigned)wb;
     }
     if (d->nseg == 1) { k.d.seg[1] = k.d.seg[0]; }
+    if (stem_eligible(d)) {
+        const int epi = d->scale ? 2 : (d->stats ? 1 : 0);
+        if (name_out) { snprintf(name_out, name_len, "conv_stem_kernel<%d>", epi); return YH_OK; }
+        hipStream_t sst = (hipStream_t)stream;
+        const dim3 sg(gx), sb(256);
+        if (epi == 2)      conv_stem_kernel<2><<<sg, sb, 0, sst>>>(k);
+        else if (epi == 1) conv_stem_kernel<1><<<sg, sb, 0, sst>>>(k);
+        else               conv_stem_kernel<0><<<sg, sb, 0, sst>>>(k);
+        YH_CHECK_LAUNCH("yh_conv_igemm(stem)");
+        return YH_OK;
+    }
     const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || k.d.nsplit < d->N;
     if (generic && d->stats) k.v2 = 0;            // statistics of an affine/activated output: generic kernel only
     if (name_out) {
