@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
         if (p.pointwise) {
             const unsigned sx = (unsigned)mb * (unsigned)(d.seg.ld * 2);
 #pragma unroll
-            for (int j = 0; j < BCH; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsx, mv ? bcoff[j] : OOB, sx, 0);
+            for (int j = 0; j < BCH; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsx, mv ? bcoff[j] : OOB, sx, 2 /* nt: last reader of the layer input */);
         } else {
             const int m = mb + row;
             int im = 0, hb = -(1 << 28), wb = -(1 << 28);

@@ -10,6 +10,12 @@ namespace {
 
 constexpr int EW_THREADS = 256;
 
+__device__ __forceinline__ uint4 ld_nt(const uint16_t* p) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // ---------------------------------------------------------------- BN finalize
 // Deterministic column sums of a [nblk][nwhich][ld] partial slab: one block = 64 channels (lane = channel,
 // coalesced rows), 16 waves stride over the partial rows, fixed-order combine through LDS in fp64.
@@ -270,8 +276,10 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
         D[e] = gi * (mu * is * c2 - c1);
     }
     for (; m < M; m += rstep) {
-        uint4 gv = *reinterpret_cast<const uint4*>(ga + m * ldga + c);
-        uint4 yv = *reinterpret_cast<const uint4*>(y + m * ldy + c);
+        // last readers of both tensors: streamed (non-temporal), they should not displace the gz rows written below,
+        // which the weight- and data-gradient kernels read next
+        uint4 gv = ld_nt(ga + m * ldga + c);
+        uint4 yv = ld_nt(y + m * ldy + c);
         float g[8], yy[8], o[8];
         unpack8(gv, g);
         unpack8(yv, yy);
