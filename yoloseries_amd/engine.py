@@ -567,6 +567,12 @@ class Program:
             if isinstance(op, ConvOp) and op.kind == 'cba':
                 max_gy = max(max_gy, B * op.Ho * op.Wo * op.N)
         self.gy_scratch = torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev)
+        # the weight gradients run on a side stream next to the data-gradient / BatchNorm chain (they only share the
+        # layer's gz): consecutive layers alternate between two gz buffers so that a layer's wgrad may still be
+        # reading its gz while the next layer's BN backward writes the other one
+        self.two_streams = os.environ.get("YH_BWD_STREAMS", "1") != "0"
+        self.gy_scratch_b = torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev) if self.two_streams else self.gy_scratch
+        n_cba = 0
         self.part_scratch = torch.zeros(1024 * 2 * 2048, dtype=torch.float32, device=self.dev)
         self.coef_scratch = {}
         self.ups_scratch = {}
@@ -605,6 +611,11 @@ class Program:
             M = B * op.Ho * op.Wo
             st = self.op_state[op.name]
             gdw = pk.gpack.data_ptr() + 4 * pk.gloc[op.name]
+            gys = self.gy_scratch
+            if op.kind == 'cba':
+                gys = self.gy_scratch if n_cba % 2 == 0 else self.gy_scratch_b
+                cmds.append(('gz_begin', n_cba % 2, None, ('sync', 0)))       # main stream: wait until this gz buffer's last wgrad is done
+                n_cba += 1
             if op.kind == 'plain':
                 # gradient arrives in op.y.g (set per call); bias grad = column sums
                 st['gy_ref'] = 'head'
@@ -635,15 +646,16 @@ class Program:
                         gr = op.res.sl(True)
                         gres_ptr, gres_ld = gr.ptr(), gr.ld
                     cmds.append((L.yh_bn_silu_bwd_apply, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), bn.weight.data_ptr(),
-                                                          coef.data_ptr(), n, M, self.gy_scratch.data_ptr() + 2 * c0, op.N,
+                                                          coef.data_ptr(), n, M, gys.data_ptr() + 2 * c0, op.N,
                                                           gres_ptr, gres_ld, gres_acc), op.name, ('yh_bn_silu_bwd_apply', 0)))
                     c0 += n
                 gy_ld, gyN = op.N, op.N
-            # wgrad per segment
+            # wgrad per segment (side stream: starts when gz is ready)
+            cmds.append(('wg_begin', None, None, ('sync', 0)))
             coff_k = 0
             for si, sg in enumerate(op.segs):
                 wd = WgradDesc()
-                wd.gy = self.gy_scratch.data_ptr() if op.kind == 'cba' else 0
+                wd.gy = gys.data_ptr() if op.kind == 'cba' else 0
                 wd.ldg, wd.N = gy_ld, gyN
                 wd.seg = hipk.make_seg(sg.sl())
                 wd.coff_k, wd.Ctot = coff_k, op.Ctot
@@ -656,6 +668,7 @@ class Program:
                 self._keep.append(wd)
                 cmds.append(('wgrad', op, wd, (L.yh_conv_wgrad_kernel_name(gyN, op.k * op.k * sg.C).decode(), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
                 coff_k += sg.C
+            cmds.append(('wg_end', (n_cba - 1) % 2 if op.kind == 'cba' else None, None, ('sync', 0)))
             # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
             marks.append((len(cmds), pk.gloc[op.name]))
             # dgrad per segment
@@ -665,7 +678,7 @@ class Program:
                 wp, cpad, Kd = pk.wptr((op.name, 'dgrad', si))
                 Nk = _rup(op.N, 8)
                 d = ConvDesc()
-                d.seg[0].ptr = self.gy_scratch.data_ptr() if op.kind == 'cba' else 0
+                d.seg[0].ptr = gys.data_ptr() if op.kind == 'cba' else 0
                 d.seg[0].ld, d.seg[0].C, d.seg[0].ups = gy_ld, Nk, 0
                 d.nseg, d.mode = 1, YH_CONV_DGRAD
                 d.B, d.Ho, d.Wo, d.Hi, d.Wi = B, op.Hi, op.Wi, op.Ho, op.Wo
@@ -754,14 +767,50 @@ class Program:
             else:
                 o.buf.g[..., o.coff:o.coff + o.C].copy_(g)
         prof = self.profile
+        two = self.two_streams
+        if two:
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+                self._ev_gz = torch.cuda.Event()
+                self._ev_wg = [torch.cuda.Event(), torch.cuda.Event()]
+                self._ev_all = torch.cuda.Event()
+            main = torch.cuda.current_stream()
+            side = self._side
+            st_side = C.c_void_p(side.cuda_stream)
+            self._ev_gz.record(main)               # packed arena zeroed, head gradients in place
+            side.wait_event(self._ev_gz)
+            pending = [False, False]
+            side_dirty = False
         for ci, cmd in enumerate(self.cmd_bwd):
             while nb < len(buckets) and buckets[nb][0] == ci:
+                if two and side_dirty:             # the bucket's weight gradients were enqueued on the side stream
+                    self._ev_all.record(side)
+                    main.wait_event(self._ev_all)
+                    side_dirty = False
                 finishers.append(bucket_hook(pk.gpack[buckets[nb][1]:buckets[nb][2]]))
                 nb += 1
             fn = cmd[0]
+            if fn == 'gz_begin':
+                if two and pending[cmd[1]]:
+                    main.wait_event(self._ev_wg[cmd[1]])
+                    pending[cmd[1]] = False
+                continue
+            if fn == 'wg_begin':
+                if two:
+                    self._ev_gz.record(main)
+                    side.wait_event(self._ev_gz)
+                continue
+            if fn == 'wg_end':
+                if two:
+                    side_dirty = True
+                    if cmd[1] is not None:
+                        self._ev_wg[cmd[1]].record(side)
+                        pending[cmd[1]] = True
+                continue
+            on_side = two and fn == 'wgrad'
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                e0.record(side if on_side else None)
             if fn == 'head_colsum':
                 _, op, boff, _m = cmd
                 g = heads[op.name]
@@ -774,7 +823,7 @@ class Program:
                 _, op, wd, _m = cmd
                 if op.kind == 'plain':
                     wd.gy = heads[op.name].data_ptr()
-                rc = L.yh_conv_wgrad(C.byref(wd), st)
+                rc = L.yh_conv_wgrad(C.byref(wd), st_side if two else st)
                 if rc:
                     check(rc, f"yh_conv_wgrad [{op.name}]")
             elif fn == 'dgrad':
@@ -790,8 +839,11 @@ class Program:
                 if rc:
                     check(rc, f"{fn.__name__} bwd [{name}]")
             if prof is not None:
-                e1.record()
+                e1.record(side if on_side else None)
                 prof.setdefault(cmd[3] + (cmd[1].name if hasattr(cmd[1], 'name') else cmd[2],), []).append((e0, e1))
+        if two:
+            self._ev_all.record(side)
+            main.wait_event(self._ev_all)
         while nb < len(buckets):
             finishers.append(bucket_hook(pk.gpack[buckets[nb][1]:buckets[nb][2]]))
             nb += 1
