@@ -283,6 +283,21 @@ def measure_roofline(model, step, B, nsteps=3):
     d = conv[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     total_ms = sum(v["ms"] for v in fam.values()) / nsteps
+    # the backward runs weight gradients on a side stream: kernel durations above include that contention (they match a
+    # rocprofv3 trace of this command).  The same kernel timed with the side stream off (kernels back to back):
+    isolated = None
+    if getattr(prog, "two_streams", False):
+        prog.two_streams, prog.profile = False, {}
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        prof2, prog.profile, prog.two_streams = prog.profile, None, True
+        ms2 = sum(s.elapsed_time(e) for key, recs in prof2.items() if key[0] == dom for s, e in recs)
+        n2 = sum(len(recs) for key, recs in prof2.items() if key[0] == dom)
+        if ms2 > 0:
+            a2 = d["flops"] / (ms2 * 1e-3) / 1e12
+            isolated = {"achieved": round(a2, 2), "frac": round(a2 / MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(1000 * ms2 / max(n2, 1), 2),
+                        "engine_kernel_ms_per_step": round(sum(s.elapsed_time(e) for recs in prof2.values() for s, e in recs) / nsteps, 3)}
     # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same command
     # (tools/pmc_traffic.py; counters cannot be read from inside the process), null when not collected
     traffic = None
@@ -293,7 +308,7 @@ def measure_roofline(model, step, B, nsteps=3):
         pass
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "flops_per_launch": round(d["flops"] / d["launches"]),
+            "flops_per_launch": round(d["flops"] / d["launches"]), "isolated": isolated,
             "avg_launch_us": round(1000 * d["ms"] / d["launches"], 2), "launches_per_step": d["launches"] // nsteps,
             "family_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
             "engine_kernel_ms_per_step": round(total_ms, 3)}
