@@ -70,6 +70,9 @@ def _tune_cache_save():
         pass                               # read-only install: tune again next time
 
 
+NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weight gradients may lag behind by
+
+
 def plan_grad_buckets(marks, gsize, nbuckets):
     """Buckets of the packed gradient arena for the data-parallel exchange.  `marks` lists, in backward order,
     (command index after which an op's gradients are complete, start of the op's slice); ops are laid out in
@@ -571,7 +574,7 @@ class Program:
         # layer's gz): consecutive layers alternate between two gz buffers so that a layer's wgrad may still be
         # reading its gz while the next layer's BN backward writes the other one
         self.two_streams = os.environ.get("YH_BWD_STREAMS", "1") != "0"
-        self.gy_scratch_b = torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev) if self.two_streams else self.gy_scratch
+        self.gy_ring = [self.gy_scratch] + ([torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev) for _ in range(NGZ - 1)] if self.two_streams else [self.gy_scratch] * (NGZ - 1))
         n_cba = 0
         self.part_scratch = torch.zeros(1024 * 2 * 2048, dtype=torch.float32, device=self.dev)
         self.coef_scratch = {}
@@ -613,8 +616,8 @@ class Program:
             gdw = pk.gpack.data_ptr() + 4 * pk.gloc[op.name]
             gys = self.gy_scratch
             if op.kind == 'cba':
-                gys = self.gy_scratch if n_cba % 2 == 0 else self.gy_scratch_b
-                cmds.append(('gz_begin', n_cba % 2, None, ('sync', 0)))       # main stream: wait until this gz buffer's last wgrad is done
+                gys = self.gy_ring[n_cba % NGZ]
+                cmds.append(('gz_begin', n_cba % NGZ, None, ('sync', 0)))       # main stream: wait until this gz buffer's last wgrad is done
                 n_cba += 1
             if op.kind == 'plain':
                 # gradient arrives in op.y.g (set per call); bias grad = column sums
@@ -668,7 +671,7 @@ class Program:
                 self._keep.append(wd)
                 cmds.append(('wgrad', op, wd, (L.yh_conv_wgrad_kernel_name(gyN, op.k * op.k * sg.C).decode(), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
                 coff_k += sg.C
-            cmds.append(('wg_end', (n_cba - 1) % 2 if op.kind == 'cba' else None, None, ('sync', 0)))
+            cmds.append(('wg_end', (n_cba - 1) % NGZ if op.kind == 'cba' else None, None, ('sync', 0)))
             # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
             marks.append((len(cmds), pk.gloc[op.name]))
             # dgrad per segment
@@ -772,14 +775,14 @@ class Program:
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(device=self.dev)
                 self._ev_gz = torch.cuda.Event()
-                self._ev_wg = [torch.cuda.Event(), torch.cuda.Event()]
+                self._ev_wg = [torch.cuda.Event() for _ in range(NGZ)]
                 self._ev_all = torch.cuda.Event()
             main = torch.cuda.current_stream()
             side = self._side
             st_side = C.c_void_p(side.cuda_stream)
             self._ev_gz.record(main)               # packed arena zeroed, head gradients in place
             side.wait_event(self._ev_gz)
-            pending = [False, False]
+            pending = [False] * NGZ
             side_dirty = False
         for ci, cmd in enumerate(self.cmd_bwd):
             while nb < len(buckets) and buckets[nb][0] == ci:
