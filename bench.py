@@ -254,17 +254,14 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_roofline(model, step, B, nsteps=3):
-    """HIP-event timing of every engine launch over `nsteps` instrumented steps (events are recorded on the
-    stream the kernels are launched on).  Reports the conv kernel family with the largest total time."""
-    prog = next(iter(model._yh_state()['progs'].values()))
+def _instrument(prog, step, nsteps):
+    """HIP-event pairs around every engine launch (recorded on the stream the kernel is launched on) over `nsteps` steps"""
     prog.profile = {}
     for _ in range(nsteps):
         step()
     torch.cuda.synchronize()
     prof, prog.profile = prog.profile, None
-    fam = {}
-    per_op = []
+    fam, per_op = {}, []
     for key, recs in prof.items():
         name, flops, opname = key
         ms = sum(s.elapsed_time(e) for s, e in recs)
@@ -273,6 +270,22 @@ def measure_roofline(model, step, B, nsteps=3):
         f["ms"] += ms
         f["flops"] += flops * len(recs)
         f["launches"] += len(recs)
+    return fam, per_op
+
+
+def measure_roofline(model, step, B, nsteps=3):
+    """Roofline of the conv kernel (template instantiation, profiler spelling) with the largest total time.
+
+    The timed region runs the weight gradients on a side stream next to the dgrad / BatchNorm chain; a kernel's duration
+    then includes whatever ran beside it.  The roofline numbers are therefore taken with the kernels back to back
+    (`two_streams` off == `YH_BWD_STREAMS=0`; profiles/r01_kernel_stats_serial.csv is the rocprofv3 summary of that
+    run) — a statement about the kernel, not about the overlap; `overlapped` repeats the same kernel as it runs in the
+    timed configuration (profiles/r01_kernel_stats_bench_b64.csv)."""
+    prog = next(iter(model._yh_state()['progs'].values()))
+    two = getattr(prog, "two_streams", False)
+    prog.two_streams = False
+    fam, per_op = _instrument(prog, step, nsteps)
+    prog.two_streams = two
     if os.environ.get("YH_BENCH_LAYERS"):
         for ms, name, opname, flops in sorted(per_op, reverse=True)[:int(os.environ["YH_BENCH_LAYERS"])]:
             print(f"# {ms:8.3f} ms/step  {name:28s} {opname:40s} {flops / 1e9 / max(ms, 1e-9):9.1f} TFLOP/s", file=sys.stderr)
@@ -283,23 +296,17 @@ def measure_roofline(model, step, B, nsteps=3):
     d = conv[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     total_ms = sum(v["ms"] for v in fam.values()) / nsteps
-    # the backward runs weight gradients on a side stream: kernel durations above include that contention (they match a
-    # rocprofv3 trace of this command).  The same kernel timed with the side stream off (kernels back to back):
-    isolated = None
-    if getattr(prog, "two_streams", False):
-        prog.two_streams, prog.profile = False, {}
-        for _ in range(nsteps):
-            step()
-        torch.cuda.synchronize()
-        prof2, prog.profile, prog.two_streams = prog.profile, None, True
-        ms2 = sum(s.elapsed_time(e) for key, recs in prof2.items() if key[0] == dom for s, e in recs)
-        n2 = sum(len(recs) for key, recs in prof2.items() if key[0] == dom)
-        if ms2 > 0:
-            a2 = d["flops"] / (ms2 * 1e-3) / 1e12
-            isolated = {"achieved": round(a2, 2), "frac": round(a2 / MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(1000 * ms2 / max(n2, 1), 2),
-                        "engine_kernel_ms_per_step": round(sum(s.elapsed_time(e) for recs in prof2.values() for s, e in recs) / nsteps, 3)}
-    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes of this same command
-    # (tools/pmc_traffic.py; counters cannot be read from inside the process), null when not collected
+    overlapped = None
+    if two:
+        fam2, _ = _instrument(prog, step, nsteps)
+        d2 = fam2.get(dom)
+        if d2 and d2["ms"] > 0:
+            a2 = d2["flops"] / (d2["ms"] * 1e-3) / 1e12
+            overlapped = {"achieved": round(a2, 2), "frac": round(a2 / MFMA_PEAK_TFLOPS, 4),
+                          "avg_launch_us": round(1000 * d2["ms"] / d2["launches"], 2),
+                          "engine_kernel_ms_per_step": round(sum(v["ms"] for v in fam2.values()) / nsteps, 3)}
+    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py; counters
+    # cannot be read from inside the process), null when not collected
     traffic = None
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
@@ -307,8 +314,8 @@ def measure_roofline(model, step, B, nsteps=3):
     except (OSError, ValueError, KeyError):
         pass
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "flops_per_launch": round(d["flops"] / d["launches"]), "isolated": isolated,
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "mode": "kernels back to back (side stream off)",
+            "flops_per_launch": round(d["flops"] / d["launches"]), "overlapped": overlapped,
             "avg_launch_us": round(1000 * d["ms"] / d["launches"], 2), "launches_per_step": d["launches"] // nsteps,
             "family_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
             "engine_kernel_ms_per_step": round(total_ms, 3)}
