@@ -96,3 +96,50 @@ def test_evaluator_call_with_stub_model(dev):
         if r is not None:
             assert o.shape == r.shape and o.dtype == torch.float32 and o.device.type == "cpu"
             np.testing.assert_allclose(o.numpy(), r, rtol=1e-4, atol=1e-3)
+
+
+def test_tta_matches_oracle_composition(dev):
+    """use_tta: 3 passes (scale 1 / 0.83 + flip-y / 0.67 + flip-x), un-scaled and un-flipped, concatenated before NMS
+    (trainer/eval_yolov5.py:152-179, 211-227).  The stub model records what it is fed and returns fixed heads."""
+    import torch.nn.functional as F
+    from yoloseries_amd.trainer import YOLOV5Evaluator
+    img = 320
+    heads = synth_nms_heads(2, img, 80, 3, seed=9, clusters=10)
+    ht = [torch.from_numpy(h).to(dev) for h in heads]
+    seen = []
+
+    def stub(x):
+        seen.append(x.detach().cpu())
+        return ht
+    ev = YOLOV5Evaluator(stub, torch.from_numpy(COCO_ANCHORS), _hyp(dev, img=img, use_tta=True))
+    x = torch.rand(2, 3, img, img, generator=torch.Generator().manual_seed(3)).to(dev)
+    merged, parts = ev.test_time_augmentation(x)
+    # the three network inputs: identity, flipped rows + 0.83 bilinear + 0.447 padding, flipped columns + 0.67
+    assert len(seen) == 3 and all(s.shape == (2, 3, img, img) for s in seen)
+    assert torch.equal(seen[0], x.cpu())
+    for s, f, k in ((0.83, 2, 1), (0.67, 3, 2)):
+        nh = int(s * img)
+        want = F.pad(F.interpolate(x.cpu().flip(dims=(f,)), size=(nh, nh), align_corners=False, mode='bilinear'),
+                     [0, img - nh, 0, img - nh], value=0.447)
+        assert torch.allclose(seen[k], want, atol=1e-6)
+    dec = opp.decode_v5(heads, COCO_ANCHORS, (8, 16, 32))
+    want = []
+    for s, f in ((1, None), (0.83, 2), (0.67, 3)):
+        d = dec.copy()
+        d[..., :4] /= np.float32(s)
+        if f == 2:
+            d[..., 1] = img - d[..., 1]
+        if f == 3:
+            d[..., 0] = img - d[..., 0]
+        want.append(d)
+    want = np.concatenate(want, axis=1)
+    assert merged.shape == want.shape and len(parts) == 3
+    np.testing.assert_allclose(merged.cpu().numpy(), want, rtol=2e-5, atol=2e-4)
+    # end to end: NMS over the concatenation, against the oracle on the HIP-produced tensor
+    seen.clear()
+    res = ev(x)
+    ref = opp.postprocess_v5(merged.cpu().numpy(), 0.3, 0.3, 0.2)
+    for o, r in zip(res, ref):
+        assert (o is None) == (r is None)
+        if r is not None:
+            np.testing.assert_array_equal(o.numpy(), r)
