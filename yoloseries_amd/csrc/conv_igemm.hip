@@ -39,7 +39,8 @@ struct ConvK {
     int v2;        // lean buffer-load kernel eligible
     unsigned segbytes[2], wbytes;   // addressable bytes from seg[i].ptr / w (hardware range check zero-fills beyond)
     int pointwise; // 1x1 / stride 1 / no upsample: input pixel == output pixel
-    int dbg;       // YH_CONV_DBG ablation bits (timing experiments only): 1 skip A loads, 2 skip sC writes, 4 skip MFMA, 8 skip B loads
+    int dbg;       // YH_CONV_DBG kernel-selection switches for A/B timing: 16 generic kernel instead of v2, 64 32-channel
+                   // k-steps only, 256 no stem kernel (the ablation masks are compile-time: make ablate ABL=mask)
 };
 
 template <int BN, int WM, int WN, bool FAST, int MINW>
