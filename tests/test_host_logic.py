@@ -158,3 +158,17 @@ def test_product_refuses_cpu_tensors():
     lf = YOLOV5Loss(torch.from_numpy(COCO_ANCHORS), dict(device="cpu", input_img_size=[64, 64], num_class=80))
     with pytest.raises(YoloHipError):
         lf([torch.zeros(1, 255, 8, 8)], torch.zeros(1, 2, 6))
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under yoloseries_amd/ (nor the drivers) may import or call it"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    files = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(root, "yoloseries_amd")) for f in fs if f.endswith(".py")]
+    files += [os.path.join(root, f) for f in ("train_yolov5.py", "val_yolov5.py")]
+    for path in files:
+        src = open(path).read()
+        if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M):
+            offenders.append(path)
+    assert not offenders, offenders
