@@ -751,6 +751,19 @@ class Program:
         _tune_cache.dirty = True
         return best
 
+    def _bucket_ready(self, bucket_hook, bucket, main, side):
+        """hand a finished gradient bucket to the data-parallel hook.  With the side stream, the bucket's weight gradients
+        were enqueued THERE and its BatchNorm / bias gradients on the main stream: the hook is called in the side stream's
+        context after it has been made to wait for the main stream's position, so the collective is ordered behind both
+        without stalling the dgrad / BatchNorm chain."""
+        part = self.pack.gpack[bucket[1]:bucket[2]]
+        if side is None:
+            return bucket_hook(part)
+        self._ev_gz.record(main)
+        side.wait_event(self._ev_gz)
+        with torch.cuda.stream(side):
+            return bucket_hook(part)
+
     def backward(self, head_grads, bucket_hook=None):
         """head_grads: list of [B,h,w,ld] bf16 gradient buffers matching self.outputs (plain ops).
         bucket_hook(slice of the packed fp32 gradient arena) -> finisher or None: called as soon as a bucket of
@@ -783,14 +796,9 @@ class Program:
             self._ev_gz.record(main)               # packed arena zeroed, head gradients in place
             side.wait_event(self._ev_gz)
             pending = [False] * NGZ
-            side_dirty = False
         for ci, cmd in enumerate(self.cmd_bwd):
             while nb < len(buckets) and buckets[nb][0] == ci:
-                if two and side_dirty:             # the bucket's weight gradients were enqueued on the side stream
-                    self._ev_all.record(side)
-                    main.wait_event(self._ev_all)
-                    side_dirty = False
-                finishers.append(bucket_hook(pk.gpack[buckets[nb][1]:buckets[nb][2]]))
+                finishers.append(self._bucket_ready(bucket_hook, buckets[nb], main if two else None, side if two else None))
                 nb += 1
             fn = cmd[0]
             if fn == 'gz_begin':
@@ -805,7 +813,6 @@ class Program:
                 continue
             if fn == 'wg_end':
                 if two:
-                    side_dirty = True
                     if cmd[1] is not None:
                         self._ev_wg[cmd[1]].record(side)
                         pending[cmd[1]] = True
@@ -844,12 +851,12 @@ class Program:
             if prof is not None:
                 e1.record(side if on_side else None)
                 prof.setdefault(cmd[3] + (cmd[1].name if hasattr(cmd[1], 'name') else cmd[2],), []).append((e0, e1))
+        while nb < len(buckets):
+            finishers.append(self._bucket_ready(bucket_hook, buckets[nb], main if two else None, side if two else None))
+            nb += 1
         if two:
             self._ev_all.record(side)
             main.wait_event(self._ev_all)
-        while nb < len(buckets):
-            finishers.append(bucket_hook(pk.gpack[buckets[nb][1]:buckets[nb][2]]))
-            nb += 1
         for f in finishers:
             if f is not None:
                 f()
