@@ -98,6 +98,14 @@ typedef struct yh_conv_desc {
     int32_t  grid_cap;
     int32_t  tile_k;      /* channels per k-step, 32 or 64 (64 needs every segment C % 64 == 0 and the 128-wide tile) */
     int32_t  reserved0;
+    /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
+     * (it must be the ONLY writer of that gradient: out0 covers exactly the producer's N channels, no accumulate):
+     * bnr_z = the producer's raw conv output (same pixel grid / channels as out0), bnr_ws = its scale | shift (stride bnr_C),
+     * bnr_part = slab [yh_conv_bnr_rows()][2][N] receiving sum(dz), sum(dz*z) per block, dz = g * silu'(z*scale+shift).
+     * Replaces yh_bn_silu_bwd_reduce for that layer; yh_bn_bwd_finalize consumes the slab.  NULL: off.          */
+    const yh_bf16* bnr_z; int32_t bnr_ldz; int32_t bnr_C;
+    const float* bnr_ws;
+    float*   bnr_part;
 } yh_conv_desc;
 
 /* number of partial-sum rows the conv kernel writes for this shape */
@@ -106,6 +114,8 @@ int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream);
 /* name of the kernel instantiation yh_conv_igemm launches for this descriptor ("conv_v2_kernel<128, 2, 2, 2, 1>"),
  * as rocprofv3 prints it: lets bench.py report per-kernel numbers that line up with the profiler's */
 int yh_conv_kernel_name(const yh_conv_desc* d, char* buf, int buflen);
+/* rows of the bnr_part slab for this data-gradient descriptor; 0 = fused reduction not available for it */
+int yh_conv_bnr_rows(const yh_conv_desc* d);
 
 /* Weight gradient: dW[n][tap*Ctot + coff_k + c] += sum_m gy[m][n] * X[src(m,tap)][c]
  * (fp32 atomics into a zeroed packed buffer).  One launch per input segment.

@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("res", C.c_void_p), ("ldr", C.c_int32),
         ("stats", C.c_void_p),
         ("tile_n", C.c_int32), ("grid_cap", C.c_int32), ("tile_k", C.c_int32), ("reserved0", C.c_int32),
+        ("bnr_z", C.c_void_p), ("bnr_ldz", C.c_int32), ("bnr_C", C.c_int32), ("bnr_ws", C.c_void_p), ("bnr_part", C.c_void_p),
     ]
 
 
@@ -105,6 +106,7 @@ _SIGS = {
     "yh_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "yh_conv_wgrad_tiles": (_i32, [_i32, _i32]),
     "yh_conv_wgrad_kernel_name": (C.c_char_p, [_i32, _i32]),
+    "yh_conv_bnr_rows": (_i32, [C.POINTER(ConvDesc)]),
     "yh_conv_kernel_name": (_i32, [C.POINTER(ConvDesc), C.c_char_p, _i32]),
     "yh_bn_finalize": (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
     "yh_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),

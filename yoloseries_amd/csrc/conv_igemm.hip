@@ -418,6 +418,19 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
     const int ldsB0 = rowA * LDSPX + kc * 8;         // row (t + j*NT)/CHR == rowA + j*RPP
 
     float run_s = 0.f, run_q = 0.f;
+    // EPI 3 (data gradient that is the ONLY writer of a ConvBnAct output's gradient): the BatchNorm+SiLU backward
+    // reduction of that producer is taken here, from the tile that is being stored anyway: dz = g * silu'(bn(z)),
+    // partial sums of dz and dz*z per channel.  A thread always handles the same 8-channel chunk (NT % (BN/8) == 0).
+    float bs_[8], bq_[8];
+    if (EPI == 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bs_[e] = 0.f; bq_[e] = 0.f; }
+        for (int i = t; i < 2 * BN; i += NT) {          // scale | shift of the block's channels -> LDS (sStat is free in this mode)
+            const int which = i / BN, c = i - which * BN;
+            sStat[i] = (n0 + c < d.N) ? d.bnr_ws[(size_t)which * d.bnr_C + n0 + c] : 0.f;
+        }
+        __syncthreads();
+    }
 #ifdef YH_CONV_STAMPS
     long long st_load = 0, st_mma = 0, st_store = 0, st_bar = 0, st_pro = 0, st_epi = 0, st_n = 0;
     const long long st_begin = __builtin_amdgcn_s_memtime();
@@ -683,6 +696,25 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
                     *reinterpret_cast<uint4*>(dst) = v;
                 } else {
                     *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
+                    if (EPI == 3) {
+                        const uint4 zv = *reinterpret_cast<const uint4*>(d.bnr_z + orow * d.bnr_ldz + n);
+                        float g[8], z[8];
+                        unpack8(v, g);
+                        unpack8(zv, z);
+                        const float4 s0 = *reinterpret_cast<const float4*>(sStat + cch * 8);
+                        const float4 s1 = *reinterpret_cast<const float4*>(sStat + cch * 8 + 4);
+                        const float4 h0 = *reinterpret_cast<const float4*>(sStat + BN + cch * 8);
+                        const float4 h1 = *reinterpret_cast<const float4*>(sStat + BN + cch * 8 + 4);
+                        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = z[e] * sc[e] + sh[e];
+                            const float sg = sigmoid_fast(a);
+                            const float dz = g[e] * (sg * (1.f + a * (1.f - sg)));
+                            bs_[e] += dz; bq_[e] += dz * z[e];
+                        }
+                    }
                 }
             }
         }
@@ -708,6 +740,21 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
     if (EPI == 1 && t < BN) {
         d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
         d.stats[((size_t)blockIdx.x * 2 + 1) * d.Npad + n0 + t] = run_q;
+    }
+    if (EPI == 3) {
+        constexpr int CPR2 = BN / 8;
+        float* sRed = reinterpret_cast<float*>(smem);          // [NT][16], aliases the (now idle) tile buffers
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sRed[t * 16 + e] = bs_[e]; sRed[t * 16 + 8 + e] = bq_[e]; }
+        __syncthreads();
+        const size_t rowi = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+        for (int i = t; i < 2 * BN; i += NT) {
+            const int which = i / BN, c = i - which * BN;
+            float v = 0.f;
+            for (int j = c / 8; j < NT; j += CPR2) v += sRed[j * 16 + which * 8 + (c & 7)];
+            if (n0 + c < d.N) d.bnr_part[(rowi * 2 + which) * d.N + n0 + c] = v;
+        }
     }
 }
 
@@ -1011,24 +1058,31 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     }
     const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || k.d.nsplit < d->N;
     if (generic && d->stats) k.v2 = 0;            // statistics of an affine/activated output: generic kernel only
+    if (d->bnr_part) {
+        YH_CHECK_ARG(k.v2 && !generic && !d->stats && d->mode == YH_CONV_DGRAD && !stem_eligible(d),
+                     "yh_conv_igemm: the fused BatchNorm-backward reduction needs the plain buffer-load data-gradient path");
+        YH_CHECK_ARG(d->bnr_z && yh_aligned16(d->bnr_z) && d->bnr_ldz % 8 == 0 && d->bnr_ws && d->bnr_C >= d->N && d->N % 8 == 0,
+                     "yh_conv_igemm: bad fused-reduction operands");
+    }
     if (name_out) {
         const int wm = bn == 128 ? 2 : 4, wn = bn == 128 ? 2 : 1, minw = bn == 32 ? 4 : (bn == 64 ? 3 : 2);
         if (k.v2) {
             const bool e8 = bn == 128;
             snprintf(name_out, name_len, "conv_v2_kernel<%d, %d, %d, %d, %d, %d>", bn, e8 ? 4 : wm, e8 ? 2 : wn, e8 ? 4 : minw,
-                     generic ? 2 : (d->stats ? 1 : 0), bkt);
+                     d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0)), bkt);
         }
         else snprintf(name_out, name_len, "conv_igemm_kernel<%d, %d, %d, %s, %d>", bn, wm, wn, k.fast ? "true" : "false", minw);
         return YH_OK;
     }
     if (k.v2) {
         hipStream_t st2 = (hipStream_t)stream;
-        const int epi = generic ? 2 : (d->stats ? 1 : 0);
+        const int epi = d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0));
 #define YH_LAUNCH_V2(BN_, WM_, WN_, MINW_, BKT_)                                                               \
         do {                                                                                                   \
             const size_t sm = conv_smem_bytes<BN_, WM_, WN_, BKT_>();                                          \
             const dim3 blk(WM_ * WN_ * 64);                                                                    \
-            if (epi == 2)      conv_v2_kernel<BN_, WM_, WN_, MINW_, 2, BKT_><<<grid, blk, sm, st2>>>(k);       \
+            if (epi == 3)      conv_v2_kernel<BN_, WM_, WN_, MINW_, 3, BKT_><<<grid, blk, sm, st2>>>(k);       \
+            else if (epi == 2) conv_v2_kernel<BN_, WM_, WN_, MINW_, 2, BKT_><<<grid, blk, sm, st2>>>(k);       \
             else if (epi == 1) conv_v2_kernel<BN_, WM_, WN_, MINW_, 1, BKT_><<<grid, blk, sm, st2>>>(k);       \
             else               conv_v2_kernel<BN_, WM_, WN_, MINW_, 0, BKT_><<<grid, blk, sm, st2>>>(k);       \
         } while (0)
@@ -1061,6 +1115,31 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
 }  // namespace
 
 extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream) { return conv_run(d, stream, nullptr, 0); }
+
+/* rows of the partial-sum slab a data-gradient launch with the fused BatchNorm-backward reduction (bnr_*) writes:
+ * [rows][2][N] floats (sum dz | sum dz*z), consumed by yh_bn_bwd_finalize(part, rows, ...).  0: this descriptor
+ * cannot take the fused path (the caller keeps the separate yh_bn_silu_bwd_reduce pass). */
+extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
+{
+    if (!d || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 32 || d->seg[0].ups || d->N % 8) return 0;
+    if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || d->nsplit < d->N || d->stats) return 0;
+    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 16)) return 0; }
+    const unsigned long M = (unsigned long)d->B * d->Ho * d->Wo;
+    if (M >= (1ul << 31) - BM) return 0;
+    const unsigned long npix = (unsigned long)d->B * d->Hi * d->Wi;
+    if (((npix - 1) * d->seg[0].ld + d->seg[0].C) * 2 >= (1ul << 31)) return 0;
+    if ((unsigned long)d->Npad * d->KH * d->KW * d->seg[0].C * 2 >= (1ul << 31)) return 0;
+    int gx, gy, bn;
+    conv_grid(d, &gx, &gy, &bn);
+    const bool cls = d->stride == 2 && d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->KH >= 2 && d->KW >= 2;
+    if (cls) {
+        const long mt = ((long)(M / 4) + BM - 1) / BM;
+        gx = (gx + 3) / 4;
+        if (gx > mt) gx = (int)mt;
+        return gx * 4;
+    }
+    return gx;
+}
 
 /* name of the kernel instantiation yh_conv_igemm launches for this descriptor, as profilers print it */
 extern "C" int yh_conv_kernel_name(const yh_conv_desc* d, char* buf, int buflen)

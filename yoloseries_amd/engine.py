@@ -406,7 +406,7 @@ class Program:
         key = f"conv:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
-            int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale))))
+            int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part))))
         cache = _tune_cache()
         if key in cache:
             d.tile_k, d.grid_cap = (int(v) for v in cache[key])
@@ -421,6 +421,10 @@ class Program:
         if stats_ok:
             tmp_stats = torch.zeros(2 * base + 8, 2, d.Npad, dtype=torch.float32, device=self.dev)
             d.stats = tmp_stats.data_ptr()
+        saved_part, tmp_part = d.bnr_part, None
+        if d.bnr_part:                   # a slab big enough for every grid tried below
+            tmp_part = torch.zeros((2 * base + 8) * 4 * 2 * d.N, dtype=torch.float32, device=self.dev)
+            d.bnr_part = tmp_part.data_ptr()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         best, best_ms = (0, 0), None
         tks = (0, 32) if all(d.seg[i].C % 64 == 0 for i in range(d.nseg)) and d.N > 64 else (0,)
@@ -441,6 +445,7 @@ class Program:
                     best, best_ms = (tk, cap), ms
         d.tile_k, d.grid_cap = best
         d.seg[0].ptr, d.stats = saved
+        d.bnr_part = saved_part
         cache[key] = [int(best[0]), int(best[1])]
         _tune_cache.dirty = True
 
@@ -602,6 +607,36 @@ class Program:
             else:
                 o.buf.ginit[o.coff:o.coff + o.C] = True
 
+        # Which ConvBnAct outputs get their gradient from exactly ONE data-gradient launch (one conv reads exactly that
+        # slice, no residual / pool / overlapping use, no upsampling in between)?  For those the BatchNorm-backward
+        # reduction is taken in that dgrad's epilogue (yh_conv_desc.bnr_*) and the separate reduce pass is dropped.
+        fuse_ok = os.environ.get("YH_FUSE_BNR", "1") != "0"
+        uses, producer_of = {}, {}
+        for o2 in self.ops:
+            if isinstance(o2, PoolOp):
+                uses.setdefault((o2.src.buf.name, o2.src.coff, o2.src.C), []).append(('pool',))
+                continue
+            for sg2 in o2.segs:
+                uses.setdefault((sg2.buf.name, sg2.coff, sg2.C), []).append(('seg', sg2.ups))
+            if o2.res is not None:
+                uses.setdefault((o2.res.buf.name, o2.res.coff, o2.res.C), []).append(('res',))
+            if o2.kind == 'cba':
+                c0_ = 0
+                for pi2, n2 in enumerate(o2.part_N):
+                    r2 = o2.outs[pi2]
+                    producer_of[(r2.buf.name, r2.coff, r2.C)] = (o2, pi2, c0_)
+                    c0_ += n2
+        for o2 in self.outputs:
+            if not isinstance(o2, ConvOp):
+                uses.setdefault((o2.buf.name, o2.coff, o2.C), []).append(('out',))
+
+        def sole_writer(key):
+            u = uses.get(key, [])
+            if len(u) != 1 or u[0][0] != 'seg' or u[0][1]:
+                return False
+            return not any(k2[0] == key[0] and k2 != key and not (k2[1] + k2[2] <= key[1] or k2[1] >= key[1] + key[2]) for k2 in uses)
+        self.bnr_fused = {}
+
         marks = []
         for op in reversed(self.ops):
             if isinstance(op, PoolOp):
@@ -637,10 +672,15 @@ class Program:
                     self.coef_scratch[(op.name, pi)] = coef
                     nblk = L.yh_ew_blocks(M)
                     ypart = op.y.t.data_ptr() + 2 * c0
-                    cmds.append((L.yh_bn_silu_bwd_reduce, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), n, M,
-                                                           self.part_scratch.data_ptr()), op.name, ('yh_bn_silu_bwd_reduce', 0)))
+                    part_ptr = self.part_scratch.data_ptr()
+                    fused = self.bnr_fused.get((op.name, pi))
+                    if fused is not None:          # the consumer's data gradient already left the partial sums in its own slab
+                        part_ptr, nblk = fused[0].data_ptr(), fused[1]
+                    else:
+                        cmds.append((L.yh_bn_silu_bwd_reduce, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), n, M,
+                                                               part_ptr), op.name, ('yh_bn_silu_bwd_reduce', 0)))
                     goff, boff = pk.bn_g[(op.name, pi)]
-                    cmds.append((L.yh_bn_bwd_finalize, (self.part_scratch.data_ptr(), nblk, n, M, ws.data_ptr(),
+                    cmds.append((L.yh_bn_bwd_finalize, (part_ptr, nblk, n, M, ws.data_ptr(),
                                                         pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
                                                         coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0)))
                     gres_ptr, gres_ld, gres_acc = None, 0, 0
@@ -705,7 +745,23 @@ class Program:
                     gl = Slice(sg.buf.g, sg.coff, sg.C)
                     d.out0, d.ld0, d.accumulate = gl.ptr(), gl.ld, acc
                     self._keep.append(d)
+                    key = (sg.buf.name, sg.coff, sg.C)
+                    if fuse_ok and acc == 0 and key in producer_of and sole_writer(key):
+                        rows = L.yh_conv_bnr_rows(C.byref(d))
+                        if rows > 0:
+                            po, ppi, pc0 = producer_of[key]
+                            slab = torch.zeros(rows * 2 * sg.C, dtype=torch.float32, device=self.dev)
+                            d.bnr_z, d.bnr_ldz = po.y.t.data_ptr() + 2 * pc0, po.y.C
+                            d.bnr_ws, d.bnr_C = self.op_state[po.name]['ws'][ppi].data_ptr(), sg.C
+                            d.bnr_part = slab.data_ptr()
+                            self.bnr_fused[(po.name, ppi)] = (slab, rows)
                     self._tune_conv(d, 'dgrad', op.name)
+                    if d.bnr_part and L.yh_conv_bnr_rows(C.byref(d)) != self.bnr_fused[(po.name, ppi)][1]:
+                        # the tuned block cap changed the grid: size the slab for it
+                        rows = L.yh_conv_bnr_rows(C.byref(d))
+                        slab = torch.zeros(rows * 2 * sg.C, dtype=torch.float32, device=self.dev)
+                        d.bnr_part = slab.data_ptr()
+                        self.bnr_fused[(po.name, ppi)] = (slab, rows)
                     cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C)))
         self.cmd_bwd = cmds
         self.bwd_buckets = plan_grad_buckets(marks, pk.gsize, int(os.environ.get("YH_DP_BUCKETS", "4")))
