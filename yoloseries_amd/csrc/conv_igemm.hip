@@ -621,6 +621,25 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
             continue;
         }
 #endif
+        // EPI 3: the producer's z chunks this thread will need in the read-out are requested now, so that their latency
+        // hides behind the accumulator -> LDS transposition and its barrier
+        constexpr int CPRz = BN / 8;
+        constexpr int NCHz = BM * CPRz / NT;
+        uint4 zpre[EPI == 3 ? NCHz : 1];
+        if (EPI == 3) {
+#pragma unroll
+            for (int i = 0; i < NCHz; ++i) {
+                const int id = t + i * NT;
+                const int row = id / CPRz;
+                const int m = m0 + row;
+                const int n = n0 + (id - row * CPRz) * 8;
+                zpre[i] = make_uint4(0, 0, 0, 0);
+                if (m < p.M && n < d.N) {
+                    const size_t orow = p.cls ? (size_t)sPix[row] : (size_t)m;
+                    zpre[i] = *reinterpret_cast<const uint4*>(d.bnr_z + orow * d.bnr_ldz + n);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int c = wn * (TN * 32) + j * 32 + (lane & 31);
@@ -697,7 +716,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
                 } else {
                     *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
                     if (EPI == 3) {
-                        const uint4 zv = *reinterpret_cast<const uint4*>(d.bnr_z + orow * d.bnr_ldz + n);
+                        const uint4 zv = zpre[i];
                         float g[8], z[8];
                         unpack8(v, g);
                         unpack8(zv, z);
