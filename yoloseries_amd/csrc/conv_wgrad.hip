@@ -120,6 +120,17 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // pixel of this thread's row in the first k-step, and the (row, column) advance of one k-step of TK pixels
+    int pim, pho, pwo;
+    {
+        const int m = mbeg + row;
+        pim = m / HoWo;
+        const int rem = m - pim * HoWo;
+        pho = rem / d.Wo;
+        pwo = rem - pho * d.Wo;
+    }
+    const int stepH = TK / d.Wo, stepW = TK - stepH * d.Wo;
+
     u32x4_t ra[ACH], rb[BCH];
     auto load_tile = [&](int kt) {
         const int mb = mbeg + kt * TK;             // scalar
@@ -132,15 +143,13 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
 #pragma unroll
             for (int j = 0; j < BCH; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsx, mv ? bcoff[j] : OOB, sx, 2 /* nt: last reader of the layer input */);
         } else {
-            const int m = mb + row;
-            int im = 0, hb = -(1 << 28), wb = -(1 << 28);
-            if (mv) {
-                im = m / HoWo;
-                const int rem = m - im * HoWo;
-                const int ho = rem / d.Wo;
-                hb = ho * d.stride - d.pad;
-                wb = (rem - ho * d.Wo) * d.stride - d.pad;
-            }
+            // this thread's pixel (im, ho, wo) is carried from k-step to k-step (tiles are visited in order): no divisions
+            const int im = pim;
+            const int hb = mv ? pho * d.stride - d.pad : -(1 << 28);
+            const int wb = mv ? pwo * d.stride - d.pad : -(1 << 28);
+            pwo += stepW; pho += stepH;
+            if (pwo >= d.Wo) { pwo -= d.Wo; ++pho; }
+            while (pho >= d.Ho) { pho -= d.Ho; ++pim; }          // tiny grids: a k-step may span several images
 #pragma unroll
             for (int j = 0; j < BCH; ++j) {
                 const int hi = hb + bkh[j], wi = wb + bkw[j];
@@ -247,7 +256,11 @@ const char* const wg_names[7] = {
 }  // namespace
 
 /* name of the kernel instantiation yh_conv_wgrad launches for a layer, as profilers print it */
-extern "C" const char* yh_conv_wgrad_kernel_name(int N, int Kseg) { return wg_names[wg_config(N, Kseg)]; }
+extern "C" const char* yh_conv_wgrad_kernel_name(int N, int Kseg)
+{
+    const int c = wg_config(N, Kseg);
+    return (c == 0 && Kseg <= 160) ? "conv_wgrad_kernel<1, 5, 1, 1, 32, 3>" : wg_names[c];
+}
 
 /* tile the kernel will use for a layer: rows (out channels) x im2col columns per block; used by the host to size `splits` */
 extern "C" int yh_conv_wgrad_tiles(int N, int Kseg)
@@ -300,7 +313,10 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     } while (0)
     k.ctiles = wide ? 1 : (k.Kseg + 127) / 128;
     switch (wg_config(d->N, k.Kseg)) {
-    case 0: YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32); break;
+    case 0:
+        if (k.Kseg <= 160) YH_WG(1, 5, 1, 1, 32, 3, (d->N + 31) / 32);        // stem: 5 waves x one 32-column tile (144 of 160 used)
+        else               YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32);
+        break;
     case 1: YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32); break;
     case 2: YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64); break;
     case 3: YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64); break;
