@@ -39,6 +39,9 @@ CASES = [
     (3, 12, 20, 16, 32, 3, 1, 1),        # stem-like (K tile spans two taps), rows not multiple of 128
     (2, 8, 8, 256, 512, 3, 2, 1),        # several N tiles
     (1, 40, 40, 64, 128, 3, 1, 1),
+    (2, 24, 24, 80, 160, 3, 1, 1),       # YOLOv5x / v5m widths: channel counts that are not multiples of 32 (ragged last block)
+    (2, 24, 24, 48, 96, 3, 2, 1),
+    (2, 16, 16, 80, 80, 1, 1, 0),
 ]
 
 

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
     const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
     const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
     const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
-    const int ncb = p.Ctot / BKT;
+    const int ncb = (p.Ctot + BKT - 1) / BKT;       // a ragged last channel block is masked to zero on the activation side
     const int nkt = nkh * nkw * ncb;
     const int HcWc = p.Hc * p.Wc;
     const int C0 = d.seg[0].C;
@@ -509,6 +509,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
             if (ld_cb == 0) tap_setup(ld_tap);
             const int c = ld_cb * BKT;
             const bool s1 = d.nseg > 1 && c >= C0;           // wave-uniform
+            // channels of this thread's chunk that lie past the segment (last block of a channel count that is not a
+            // multiple of the k-step) read as zero; the weight columns they meet are finite, so they add nothing
+            const bool cok = c + kc * 8 < (s1 ? p.Ctot : C0);
 #if YH_CONV_ABLATE
             if (YH_CONV_ABLATE & 1) {
 #pragma unroll
@@ -518,11 +521,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
             if (s1) {
                 const int so = (c - C0) * 2;
 #pragma unroll
-                for (int i = 0; i < NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs1, voff1[i], so, 0);
+                for (int i = 0; i < NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs1, cok ? voff1[i] : OOB, so, 0);
             } else {
                 const int so = c * 2;
 #pragma unroll
-                for (int i = 0; i < NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, voff0[i], so, 0);
+                for (int i = 0; i < NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, cok ? voff0[i] : OOB, so, 0);
             }
             const int sw = (kcol_base + c) * 2;
 #if YH_CONV_ABLATE
@@ -1029,7 +1032,9 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (k.d.nsplit > k.d.N) k.d.nsplit = k.d.N + 8;   // everything goes to out0
     k.fast = 1;
     { const char* e = getenv("YH_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
-    for (int s2 = 0; s2 < d->nseg; ++s2) if (d->seg[s2].C % 32) k.fast = 0;
+    // the buffer-load kernel walks 32-channel blocks: a first segment must end on a block boundary, the last may be ragged
+    if (d->nseg > 1 && d->seg[0].C % 32) k.fast = 0;
+    const bool ragged = (d->seg[d->nseg - 1].C % 32) != 0;
     if ((long)d->B * d->Hi * d->Wi >= (1L << 31)) k.fast = 0;
     k.cls = 0; k.Hc = d->Ho; k.Wc = d->Wo;
     if (d->mode == YH_CONV_DGRAD && d->stride == 2 && d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->KH >= 2 && d->KW >= 2 && !d->stats) {
@@ -1077,6 +1082,7 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     }
     const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || k.d.nsplit < d->N;
     if (generic && d->stats) k.v2 = 0;            // statistics of an affine/activated output: generic kernel only
+    if (ragged && !k.v2) k.fast = 0;              // the generic kernel's fast loader needs whole 32-channel blocks
     if (d->bnr_part) {
         YH_CHECK_ARG(k.v2 && !generic && !d->stats && d->mode == YH_CONV_DGRAD && !stem_eligible(d),
                      "yh_conv_igemm: the fused BatchNorm-backward reduction needs the plain buffer-load data-gradient path");
@@ -1140,7 +1146,7 @@ extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream) { return c
  * cannot take the fused path (the caller keeps the separate yh_bn_silu_bwd_reduce pass). */
 extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
 {
-    if (!d || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 32 || d->seg[0].ups || d->N % 8) return 0;
+    if (!d || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 8 || d->seg[0].ups || d->N % 8) return 0;
     if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || d->nsplit < d->N || d->stats) return 0;
     { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 16)) return 0; }
     const unsigned long M = (unsigned long)d->B * d->Ho * d->Wo;
