@@ -375,7 +375,9 @@ class Program:
         self.dev = dev
         self.L = lib()
         for b in self.bufs:
-            b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=dev)
+            # raw conv outputs (".y") are training-only and allocated by _build_train(); head buffers are fresh per forward
+            if not b.name.endswith(".y") and not getattr(b, "is_head", False):
+                b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=dev)
         self.generation = 0
         self.profile = None             # {(kernel family, algorithmic flops): [(start_event, end_event)]} when profiling
         self.bwd_ready = False
@@ -450,30 +452,71 @@ class Program:
         _tune_cache.dirty = True
 
     def _build_forward(self):
+        """inference program (folded BatchNorm + SiLU in the conv epilogue).  The training program — raw conv outputs,
+        statistics, BatchNorm work buffers, pool arg-max — is built by _build_train() at the first training forward, so an
+        evaluation-only model never allocates the pre-activation tensors (half of the activation memory)."""
         B, pk, L = self.B, self.pack, self.L
-        self.cmd_train, self.cmd_eval = [], []
+        self.cmd_train, self.cmd_eval = None, []
         self.op_state = {}
         for op in self.ops:
             if isinstance(op, PoolOp):
-                op.idx = torch.zeros(B, op.src.buf.H, op.src.buf.W, op.src.C, dtype=torch.int8, device=self.dev)
                 s, dd = op.src.sl(), op.dst.sl()
-                args = (s.ptr(), s.ld, B, op.src.buf.H, op.src.buf.W, s.C, dd.ptr(), dd.ld, op.idx.data_ptr())
-                self.cmd_train.append((L.yh_maxpool5_fwd, args, op.name, ('yh_maxpool5_fwd', 0)))
-                self.cmd_eval.append((L.yh_maxpool5_fwd, args[:-1] + (None,), op.name, ('yh_maxpool5_fwd', 0)))
+                args = (s.ptr(), s.ld, B, op.src.buf.H, op.src.buf.W, s.C, dd.ptr(), dd.ld, None)
+                self.cmd_eval.append((L.yh_maxpool5_fwd, args, op.name, ('yh_maxpool5_fwd', 0)))
                 continue
-            M = B * op.Ho * op.Wo
             st = {}
             self.op_state[op.name] = st
             if op.kind == 'plain':
                 d = self._conv_desc(op, True)
                 d.bias = pk.fpack.data_ptr() + 4 * pk.bias_loc[op.name]
                 d.act = YH_ACT_NONE
-                d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
+                d.out0, d.ld0, d.nsplit = pk.wpack.data_ptr(), op.y.C, op.N   # placeholder: head buffers are fresh tensors per forward
                 st['desc'] = d
-                self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op, d)))
-                self.cmd_eval.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op, d)))
+                st['fam'] = self._fam_conv(op, d)
+                self.cmd_eval.append((L.yh_conv_igemm, (C.byref(d),), op.name, st['fam']))
                 continue
-            # ---- ConvBnAct, training: conv(+stats) -> finalize -> apply
+            # folded BN + SiLU (+ residual) in the conv epilogue
+            de = self._conv_desc(op, False)
+            st['fold'] = torch.zeros(2, op.N, dtype=torch.float32, device=self.dev)
+            c0 = 0
+            for (conv, bn), n in zip(op.parts, op.part_N):
+                self.cmd_eval.append((L.yh_bn_fold, (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                                     bn.running_var.data_ptr(), float(bn.eps), n,
+                                                     st['fold'].data_ptr() + 4 * c0, st['fold'].data_ptr() + 4 * (op.N + c0)), op.name, ('yh_bn_fold', 0)))
+                c0 += n
+            de.scale, de.shift = st['fold'].data_ptr(), st['fold'].data_ptr() + 4 * op.N
+            de.act = YH_ACT_SILU
+            o0 = op.outs[0].sl()
+            de.out0, de.ld0, de.nsplit = o0.ptr(), o0.ld, op.part_N[0] if len(op.outs) > 1 else op.N
+            if len(op.outs) > 1:
+                o1 = op.outs[1].sl()
+                de.out1, de.ld1 = o1.ptr(), o1.ld
+                assert len(op.outs) == 2
+            if op.res is not None:
+                r = op.res.sl()
+                de.res, de.ldr = r.ptr(), r.ld
+            st['desc_eval'] = de
+            self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name, self._fam_conv(op, de)))
+
+    def _build_train(self):
+        """training program: conv (+ per-block BatchNorm partial sums) -> finalize -> BN+SiLU apply (+ residual)"""
+        B, pk, L = self.B, self.pack, self.L
+        for b in self.bufs:
+            if b.t is None and not getattr(b, "is_head", False):
+                b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=self.dev)
+        self.cmd_train = []
+        for op in self.ops:
+            if isinstance(op, PoolOp):
+                op.idx = torch.zeros(B, op.src.buf.H, op.src.buf.W, op.src.C, dtype=torch.int8, device=self.dev)
+                s, dd = op.src.sl(), op.dst.sl()
+                args = (s.ptr(), s.ld, B, op.src.buf.H, op.src.buf.W, s.C, dd.ptr(), dd.ld, op.idx.data_ptr())
+                self.cmd_train.append((L.yh_maxpool5_fwd, args, op.name, ('yh_maxpool5_fwd', 0)))
+                continue
+            M = B * op.Ho * op.Wo
+            st = self.op_state[op.name]
+            if op.kind == 'plain':
+                self.cmd_train.append((L.yh_conv_igemm, (C.byref(st['desc']),), op.name, st['fam']))
+                continue
             d = self._conv_desc(op, True)
             d.act = YH_ACT_NONE
             d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
@@ -499,28 +542,6 @@ class Program:
                     op.y.t.data_ptr() + 2 * c0, op.y.C, ws.data_ptr(), n, M, dst.ptr(), dst.ld,
                     res.ptr() if res else None, res.ld if res else 0), op.name, ('yh_bn_silu_apply', 0)))
                 c0 += n
-            # ---- inference: folded BN + SiLU (+ residual) in the conv epilogue
-            de = self._conv_desc(op, False)
-            st['fold'] = torch.zeros(2, op.N, dtype=torch.float32, device=self.dev)
-            c0 = 0
-            for (conv, bn), n in zip(op.parts, op.part_N):
-                self.cmd_eval.append((L.yh_bn_fold, (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
-                                                     bn.running_var.data_ptr(), float(bn.eps), n,
-                                                     st['fold'].data_ptr() + 4 * c0, st['fold'].data_ptr() + 4 * (op.N + c0)), op.name, ('yh_bn_fold', 0)))
-                c0 += n
-            de.scale, de.shift = st['fold'].data_ptr(), st['fold'].data_ptr() + 4 * op.N
-            de.act = YH_ACT_SILU
-            o0 = op.outs[0].sl()
-            de.out0, de.ld0, de.nsplit = o0.ptr(), o0.ld, op.part_N[0] if len(op.outs) > 1 else op.N
-            if len(op.outs) > 1:
-                o1 = op.outs[1].sl()
-                de.out1, de.ld1 = o1.ptr(), o1.ld
-                assert len(op.outs) == 2
-            if op.res is not None:
-                r = op.res.sl()
-                de.res, de.ldr = r.ptr(), r.ld
-            st['desc_eval'] = de
-            self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name, self._fam_conv(op, de)))
 
     # -- forward ---------------------------------------------------------------------------
     def _kernel_name(self, d):
@@ -559,6 +580,8 @@ class Program:
             if isinstance(o, ConvOp):
                 o.y.t = torch.empty(self.B, o.y.H, o.y.W, o.y.C, dtype=torch.bfloat16, device=self.dev)
                 self.op_state[o.name]['desc'].out0 = o.y.t.data_ptr()
+        if train and self.cmd_train is None:
+            self._build_train()
         self._run(self.cmd_train if train else self.cmd_eval)
         return self.generation
 
