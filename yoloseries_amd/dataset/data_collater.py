@@ -1,8 +1,12 @@
-"""Collate functions — mirror of dataset/data_collater.py:16-82.
+"""Batch assembly — the tensor format between a dataset and the hot path, as the reference's
+dataset/data_collater.py:16-82 produces it:
 
-A batch is ``{'img': (B,3,H,W) float32 in [0,1] (channel order as loaded), 'ann': (B,maxbox,6) float32
-[xmin,ymin,xmax,ymax,cls,img_idx] padded with -1, 'resize_info': [letterbox dict per image], 'img_id': [...]}``:
-exactly what ``YOLOV5Loss`` / the evaluators of this package consume (loss/yolov5_loss.py:30-60)."""
+    'img'          (B, 3, H, W) float32 in [0, 1], channel order as loaded
+    'ann'          (B, maxbox, 6) float32 rows [xmin, ymin, xmax, ymax, cls, index of the image in the batch], -1 padded
+    'resize_info'  one letterbox record per image (utils/letterbox.py)
+    'img_id'       the dataset's ids
+
+`YOLOV5Loss` / `YOLOXLoss` and the evaluators of this package consume exactly this (loss/yolov5_loss.py:30-60)."""
 import numpy as np
 import torch
 
@@ -12,47 +16,42 @@ __all__ = ['fixed_imgsize_collate_fn', 'test_dataset_collate_fn', 'normal_normal
 
 
 def normal_normalization(img):
-    """(h,w,3) uint8 -> (3,h,w) float64 tensor in [0,1] (dataset/data_collater.py:16-17; the batch tensor it is
-    written into is float32)"""
+    """uint8 HWC image -> CHW tensor scaled to [0, 1] (float64 like the reference; the batch tensor is float32)"""
     return torch.from_numpy(img / 255.0).permute(2, 0, 1).contiguous()
 
 
+def _annotation_rows(ann, info, index):
+    """(n, 6) float32 rows of one image, boxes moved into the letterboxed frame"""
+    n = len(ann['classes'])
+    if len(ann['bboxes']) != n:
+        raise AssertionError("every box needs a class")
+    rows = torch.empty(n, 6)
+    if n:
+        rows[:, :4] = torch.from_numpy(np.asarray(letter_resize_bbox(ann['bboxes'], info), dtype=np.float64)).float()
+        rows[:, 4] = torch.as_tensor([float(c) for c in ann['classes']])
+        rows[:, 5] = float(index)
+    return rows
+
+
 def fixed_imgsize_collate_fn(data_in, dst_size):
-    """:param data_in: sequence of (image (h,w,3) uint8, {'bboxes': [[xmin,ymin,xmax,ymax]...], 'classes': [...]}, image id)
-    :param dst_size: [h, w] of the batch (dataset/data_collater.py:20-64)"""
-    assert data_in[0][0].ndim == 3 and data_in[0][0].shape[-1] == 3, \
-        f"data's formate should be (h, w, 3), but got {data_in[0][0].shape}"
-    batch_size = len(data_in)
-    imgs = [d[0] for d in data_in]
-    anns = [d[1] for d in data_in]
-    img_ids = [d[2] for d in data_in]
-    imgs_out = torch.zeros(batch_size, 3, dst_size[0], dst_size[1])
-    boxes_num = [len(ann['bboxes']) for ann in anns]
-    # -1 marks padding rows; the last column is the image index inside the batch (used by the target assignment)
-    anns_out = torch.ones(batch_size, max(boxes_num), 6) * -1
-    resize_infos = []
-    for b in range(batch_size):
-        ann_bboxes, ann_classes = anns[b]['bboxes'], anns[b]['classes']
-        assert len(ann_bboxes) == len(ann_classes)
-        img, resize_info = letter_resize_img(imgs[b], dst_size)
-        imgs_out[b] = normal_normalization(img)
-        resize_infos.append(resize_info)
-        if len(ann_classes) > 0:
-            boxes = letter_resize_bbox(ann_bboxes, resize_info)
-            n = len(ann_classes)
-            anns_out[b, :n, :4] = torch.from_numpy(np.asarray(boxes, dtype=np.float64)).float()
-            anns_out[b, :n, 4] = torch.as_tensor([float(c) for c in ann_classes])
-            anns_out[b, :n, 5] = b
-    return {'img': imgs_out, 'ann': anns_out, 'resize_info': resize_infos, 'img_id': img_ids}
+    """data_in: sequence of (image (h,w,3) uint8, {'bboxes': (n,4) xyxy, 'classes': n}, image id); dst_size: [h, w]"""
+    first = data_in[0][0]
+    assert first.ndim == 3 and first.shape[-1] == 3, f"data's formate should be (h, w, 3), but got {first.shape}"
+    batch = torch.zeros(len(data_in), 3, dst_size[0], dst_size[1])
+    infos, rows, ids = [], [], []
+    for index, (img, ann, img_id) in enumerate(data_in):
+        boxed, info = letter_resize_img(img, dst_size)
+        batch[index] = normal_normalization(boxed)
+        infos.append(info)
+        rows.append(_annotation_rows(ann, info, index))
+        ids.append(img_id)
+    ann_out = torch.full((len(data_in), max(len(r) for r in rows), 6), -1.0)      # -1 rows = padding
+    for index, r in enumerate(rows):
+        ann_out[index, :len(r)] = r
+    return {'img': batch, 'ann': ann_out, 'resize_info': infos, 'img_id': ids}
 
 
 def test_dataset_collate_fn(data_in):
-    """items are (tensor (3,h,w) already letterboxed, resize_info) — dataset/data_collater.py:67-82"""
-    batch_size = len(data_in)
-    imgs = [d[0] for d in data_in]
-    infoes = [d[1] for d in data_in]
-    h, w = imgs[0].shape[1:]
-    img_out = torch.ones(batch_size, 3, h, w)
-    for i in range(batch_size):
-        img_out[i] = imgs[i]
-    return {'img': img_out, 'resize_info': list(infoes)}
+    """items: (already letterboxed (3,h,w) tensor, letterbox record)"""
+    img = torch.stack([item[0].to(torch.float32) for item in data_in])
+    return {'img': img, 'resize_info': [item[1] for item in data_in]}

@@ -1,62 +1,46 @@
-"""Host->device prefetcher — mirror of dataset/data_prefetcher.py:6-106: the next batch is copied on a side HIP
-stream while the current step computes; `next()` makes the compute stream wait for that copy."""
+"""Host -> device prefetch on a side HIP stream (the role of dataset/data_prefetcher.py:6-106 in the reference's
+training loop, train_yolov5.py:458-497): while a step computes, the next batch is already being copied; `next()`
+orders the compute stream behind that copy and marks the tensors as used on it."""
 import torch
 
 __all__ = ["DataPrefetcher", "TestDataPrefetcher"]
 
 
-class DataPrefetcher:
+class _Prefetcher:
+    """keys in `tensor_keys` are moved to the device, every other entry of the batch dict is passed through"""
+    tensor_keys = ()
+    all_keys = ()
 
     def __init__(self, loader):
-        self.loader = iter(loader)
+        self._it = iter(loader)
         self.stream = torch.cuda.Stream()
+        self._staged = None
         self.preload()
 
     def preload(self):
-        try:
-            out = next(self.loader)
-        except StopIteration:
-            self.next_input = self.next_target = self.next_resize_info = self.next_img_id = None
+        batch = next(self._it, None)
+        if batch is None:
+            self._staged = None
             return
-        self.next_input, self.next_target = out["img"], out["ann"]
-        self.next_resize_info, self.next_img_id = out['resize_info'], out['img_id']
         with torch.cuda.stream(self.stream):
-            self.next_input = self.next_input.cuda(non_blocking=True)
-            self.next_target = self.next_target.cuda(non_blocking=True)
+            self._staged = {k: (batch[k].cuda(non_blocking=True) if k in self.tensor_keys else batch[k]) for k in self.all_keys}
 
     def next(self):
-        torch.cuda.current_stream().wait_stream(self.stream)
-        inp, target = self.next_input, self.next_target
-        resize_info, img_id = self.next_resize_info, self.next_img_id
-        if inp is not None:
-            inp.record_stream(torch.cuda.current_stream())
-        if target is not None:
-            target.record_stream(torch.cuda.current_stream())
+        current = torch.cuda.current_stream()
+        current.wait_stream(self.stream)
+        out = self._staged if self._staged is not None else {k: None for k in self.all_keys}
+        for k in self.tensor_keys:
+            if out[k] is not None:
+                out[k].record_stream(current)
         self.preload()
-        return {'img': inp, 'ann': target, 'resize_info': resize_info, 'img_id': img_id}
+        return out
 
 
-class TestDataPrefetcher:
+class DataPrefetcher(_Prefetcher):
+    tensor_keys = ('img', 'ann')
+    all_keys = ('img', 'ann', 'resize_info', 'img_id')
 
-    def __init__(self, loader):
-        self.loader = iter(loader)
-        self.stream = torch.cuda.Stream()
-        self.preload()
 
-    def preload(self):
-        try:
-            out = next(self.loader)
-        except StopIteration:
-            self.next_input = self.next_resize_info = None
-            return
-        self.next_input, self.next_resize_info = out["img"], out["resize_info"]
-        with torch.cuda.stream(self.stream):
-            self.next_input = self.next_input.cuda(non_blocking=True)
-
-    def next(self):
-        torch.cuda.current_stream().wait_stream(self.stream)
-        inp, info = self.next_input, self.next_resize_info
-        if inp is not None:
-            inp.record_stream(torch.cuda.current_stream())
-        self.preload()
-        return {'img': inp, 'resize_info': info}
+class TestDataPrefetcher(_Prefetcher):
+    tensor_keys = ('img',)
+    all_keys = ('img', 'resize_info')
