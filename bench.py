@@ -108,11 +108,18 @@ def main():
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
     import torch.distributed as dist
-    if world > 1:
+    # YH_FORCE_DP=1: run the data-parallel path (RCCL communicator, overlapped gradient buckets) on a single rank too
+    force_dp = world == 1 and os.environ.get("YH_FORCE_DP") == "1"
+    if force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dp:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from yoloseries_amd import models
     from yoloseries_amd.loss import YOLOV5Loss
@@ -190,7 +197,7 @@ def main():
         lr = 0.000625 * B                       # basic_lr_per_img x per-rank batch (train_yolov5.py:184)
         opt = FlatSGD(model, lr=lr, momentum=0.937, weight_decay=1e-4, nesterov=True)
         ema = ExponentialMovingAverageModel(model)
-        dp = DataParallelGrads(model) if world > 1 else None
+        dp = DataParallelGrads(model) if (world > 1 or force_dp) else None
 
         def step():
             # YOLOXLoss converts the target boxes to xywh IN PLACE like the reference (loss/yolox_loss.py:70-75): every step
@@ -242,14 +249,14 @@ def main():
             "metric": metric, "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": workload, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "global_batch": B * world, "parallelism": f"dp{world}" + (" (forced RCCL path)" if force_dp else "")},
             "train_tflops": round(ips * gflop_img / 1000.0, 2),
             "mfma_frac_step": round(ips * gflop_img / 1000.0 / (MFMA_PEAK_TFLOPS * world), 4),
             "final_loss": round(loss_val, 4), **extra,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh clone has no libyolohip.so (built artefacts are git-ignored): build it once, in-tree, before any test loads it
+    from yoloseries_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
 
 
 @pytest.fixture(scope="session")

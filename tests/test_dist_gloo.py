@@ -37,6 +37,13 @@ def _worker(rank, world, port, q):
     with dp.no_sync():
         fm._yh_grad_hook(g3)
     res["nosync_ok"] = bool(torch.allclose(g3, torch.full((5,), float(rank))))
+    # gradient accumulation (train_yolov5.py:327-337): the backward after un-exchanged ones is the boundary; what is
+    # averaged is the ACCUMULATED gradient (DDP semantics) and the bucket hooks stand back for that backward
+    res["boundary_skips_buckets"] = fm._yh_bucket_hook(torch.zeros(4)) is None and not dp.buckets_active
+    g4 = torch.full((5,), 10.0 * (rank + 1))
+    fm._yh_grad_hook(g4, bucketed=True)
+    # local sums: rank0 0+10, rank1 1+20 -> mean 15.5; handed on = mean - local un-exchanged part
+    res["accum_ok"] = bool(torch.allclose(g3 + g4, torch.full((5,), 15.5))) and dp.buckets_active
     # overlapped exchange: the engine hands over contiguous slices of the packed gradient arena in backward order
     from yoloseries_amd.engine import plan_grad_buckets
     arena = torch.arange(1000, dtype=torch.float32) * (rank + 1)

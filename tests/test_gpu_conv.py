@@ -158,3 +158,141 @@ def test_conv_wgrad_segment_upsampled(dev):
     (ref,) = torch.autograd.grad(F.conv2d(xin, w), w, _nchw(gy))
     ref = ref.reshape(Cout, -1)
     _close(dw, ref, 2e-3, 2e-3 * ref.abs().max().item())
+
+
+# ---- kernel families: the register-staged kernel (algo 1) and the LDS-DMA ring kernel with its three tiles (algo 2..4)
+V3_CASES = [
+    # B, H, W, Cin, Cout, k, s, p
+    (2, 40, 40, 128, 128, 3, 1, 1),
+    (1, 24, 24, 64, 256, 3, 2, 1),
+    (2, 16, 16, 256, 128, 1, 1, 0),
+    (2, 20, 20, 96, 160, 3, 1, 1),       # 32-channel k-steps (96 % 64 != 0), ragged N tile
+    (1, 33, 17, 64, 64, 3, 1, 1),        # odd sizes, rows past M in the last tile
+    (3, 8, 8, 512, 256, 1, 1, 0),
+]
+
+
+def _kname(d):
+    import ctypes as C
+    from yoloseries_amd._lib import lib
+    buf = C.create_string_buffer(96)
+    assert lib().yh_conv_kernel_name(C.byref(d), buf, 96) == 0
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", V3_CASES)
+def test_conv_fwd_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
+    """plain store + BatchNorm partial sums (EPI 1) and the generic epilogue (bias, EPI 2) on every kernel family"""
+    from yoloseries_amd import hipk
+    x = _nhwc(B, H, W, Cin, dev, 21)
+    g = torch.Generator().manual_seed(22)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(torch.bfloat16).float().to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    wp = hipk.pack_weight_fwd(w)
+    ref = F.conv2d(_nchw(x), w, None, stride=s, padding=p).permute(0, 2, 3, 1)
+    for with_bias in (False, True):
+        out = torch.full((B, Ho, Wo, Cout), 7.0, dtype=torch.bfloat16, device=dev)
+        d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, Ho, Wo, H, W, k, s, p, wp, Cout, hipk.full(out),
+                           bias=bias if with_bias else None)
+        d.algo = algo
+        if algo >= 2:
+            assert "conv_v3_kernel" in _kname(d), _kname(d)
+        stats = None
+        if not with_bias:
+            stats = torch.zeros(hipk.conv_stat_blocks(d), 2, wp.shape[0], device=dev)
+            d.stats = stats.data_ptr()
+        hipk.conv_launch(d)
+        torch.cuda.synchronize()
+        _close(out, ref + (bias if with_bias else 0.0), 8e-3, 2e-2)
+        if stats is not None:
+            # the sums are taken over the fp32 accumulators, the comparison over the stored bf16 values: allow 4 sigma of
+            # the accumulated rounding noise (per element <= 2^-9 |o|)
+            o = out.float().reshape(-1, Cout).double()
+            tol1 = 1e-2 + 4 * 2.0 ** -9 * (o ** 2).sum(0).sqrt()
+            tol2 = 1e-2 + 4 * 2.0 ** -8 * (o ** 4).sum(0).sqrt()
+            assert ((stats[:, 0, :Cout].double().sum(0) - o.sum(0)).abs() <= tol1).all()
+            assert ((stats[:, 1, :Cout].double().sum(0) - (o ** 2).sum(0)).abs() <= tol2).all()
+
+
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [c for c in V3_CASES if c[3] > 32])
+def test_conv_dgrad_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
+    """data gradient (stride-2 layers run as four parity classes), plain and accumulating, plus the fused
+    BatchNorm+SiLU backward reduction of the producer layer (EPI 3) against a torch reference"""
+    from yoloseries_amd import hipk
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    gy = _nhwc(B, Ho, Wo, Cout, dev, 27)
+    g = torch.Generator().manual_seed(28)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cout * k * k) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wd = hipk.pack_weight_dgrad(w)
+    x = torch.zeros(B, Cin, H, W, device=dev, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, stride=s, padding=p), x, _nchw(gy))
+    ref = ref.permute(0, 2, 3, 1)
+    # accumulate on top of an existing gradient (generic epilogue)
+    gx = _nhwc(B, H, W, Cin, dev, 29)
+    gx0 = gx.clone()
+    d = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, Ho, Wo, k, s, p, wd, Cin, hipk.full(gx), accumulate=1)
+    d.algo = algo
+    if algo >= 2:
+        assert "conv_v3_kernel" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(gx, ref.to(torch.bfloat16).float() + gx0.float(), 1e-2, 4e-2)
+    # plain store + fused reduction: dz = g * silu'(z*scale + shift); partial sums of dz and dz*z per channel
+    import ctypes as C
+    from yoloseries_amd._lib import lib
+    z = _nhwc(B, H, W, Cin, dev, 30)
+    ws = torch.cat([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)]).to(dev)
+    gx2 = torch.zeros(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
+    d2 = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, Ho, Wo, k, s, p, wd, Cin, hipk.full(gx2))
+    d2.algo = algo
+    rows = lib().yh_conv_bnr_rows(C.byref(d2))
+    assert rows > 0
+    slab = torch.zeros(rows, 2, Cin, device=dev)
+    d2.bnr_z, d2.bnr_ldz, d2.bnr_C, d2.bnr_ws, d2.bnr_part = z.data_ptr(), Cin, Cin, ws.data_ptr(), slab.data_ptr()
+    assert lib().yh_conv_bnr_rows(C.byref(d2)) == rows
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    _close(gx2, ref, 1e-2, 4e-2)
+    gq = gx2.float().reshape(-1, Cin).double()
+    zz = z.float().reshape(-1, Cin).double()
+    a = zz * ws[:Cin].double() + ws[Cin:].double()
+    sg = torch.sigmoid(a)
+    dz = gq * (sg * (1 + a * (1 - sg)))
+    got = slab.double().sum(0)
+    assert torch.allclose(got[0], dz.sum(0), rtol=2e-3, atol=2e-3 * dz.abs().sum(0).max().item())
+    assert torch.allclose(got[1], (dz * zz).sum(0), rtol=2e-3, atol=2e-3 * (dz * zz).abs().sum(0).max().item())
+
+
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
+def test_conv_concat_upsample_algos(dev, algo):
+    """two-segment input, the first read through the nearest-2x upsample, folded BN + SiLU, residual, split destination"""
+    from yoloseries_amd import hipk
+    B, H, W = 2, 24, 24
+    lo = _nhwc(B, H // 2, W // 2, 64, dev, 33)
+    skip_buf = _nhwc(B, H, W, 160, dev, 34)       # channels [32, 160) of a wider buffer
+    g = torch.Generator().manual_seed(35)
+    Cin, Cout = 192, 128
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(torch.bfloat16).float().to(dev)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=g).to(dev)
+    res = _nhwc(B, H, W, 64, dev, 36)
+    out0 = torch.zeros(B, H, W, 64, dtype=torch.bfloat16, device=dev)
+    out1 = torch.zeros(B, H, W, 96, dtype=torch.bfloat16, device=dev)   # write into channels [32,96)
+    wp = hipk.pack_weight_fwd(w)
+    d = hipk.conv_desc([hipk.Slice(lo, 0, 64, ups=1), hipk.Slice(skip_buf, 32, 128)], hipk.YH_CONV_FWD,
+                       B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.full(out0), nsplit=64,
+                       out1=hipk.Slice(out1, 32, 64), scale=scale, shift=shift, act=hipk.YH_ACT_SILU, res=hipk.full(res))
+    d.algo = algo
+    if algo >= 2:
+        assert "conv_v3_kernel" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    xin = torch.cat([F.interpolate(_nchw(lo), scale_factor=2, mode="nearest"), _nchw(skip_buf[..., 32:160])], 1)
+    zc = F.conv2d(xin, w, padding=1) * scale[None, :, None, None] + shift[None, :, None, None]
+    a = F.silu(zc).permute(0, 2, 3, 1)
+    _close(out0, a[..., :64].to(torch.bfloat16).float() + res.float(), 1e-2, 3e-2)
+    _close(out1[..., 32:], a[..., 64:], 8e-3, 2e-2)
+    assert (out1[..., :32] == 0).all()

@@ -49,6 +49,7 @@ def _worker(rank, world, port, q):
         fresh_loss()(model(x), t)["tot_loss"].backward()
     g_local = model._yh_last_flat_grad.clone()
     opt.zero_grad()
+    dp.reset()                       # that gradient was only measured: it is not part of an accumulation cycle
     fresh_loss()(model(x), t)["tot_loss"].backward()
     g_dp = model._yh_last_flat_grad.clone()
     gathered = [torch.zeros_like(g_local).cpu() for _ in range(world)]
@@ -64,6 +65,28 @@ def _worker(rank, world, port, q):
         lossf(model(x), t)["tot_loss"].backward()
         opt.step()
         opt.zero_grad()
+    # gradient accumulation over two micro-batches (train_yolov5.py:327-337; the stock config has accumulate = 2): the first
+    # backward runs under no_sync, the boundary one synchronises; every rank must step with mean_r(g1_r + g2_r)
+    x2 = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(30 + rank)).to(dev)
+    t2 = torch.from_numpy(synth_targets(B, img, 80, 6, seed=40 + rank)).to(dev)
+    locs = []
+    for xx, tt in ((x, t), (x2, t2)):
+        with dp.no_sync():
+            fresh_loss()(model(xx), tt)["tot_loss"].backward()
+        locs.append(model._yh_last_flat_grad.clone())
+        opt.zero_grad()
+        dp.reset()
+    with dp.no_sync():
+        fresh_loss()(model(x), t)["tot_loss"].backward()
+    fresh_loss()(model(x2), t2)["tot_loss"].backward()
+    g_acc = opt._grad().clone()
+    tot_local = (locs[0] + locs[1]).cpu()
+    gathered = [torch.zeros_like(tot_local) for _ in range(world)]
+    dist.all_gather(gathered, tot_local)
+    g_want = (sum(gathered) / world).to(dev)
+    res["accum_err"] = float((g_acc - g_want).abs().max().item() / g_want.abs().max().item())
+    opt.step()
+    opt.zero_grad()
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
     others = [torch.zeros_like(flat) for _ in range(world)]
@@ -90,3 +113,79 @@ def test_overlapped_bucket_allreduce_two_ranks(dev):
         assert res["finite"] and res["replicas_identical"], (rank, res)
         assert res["mean_err"] < 1e-3, (rank, res)              # averaged gradient == mean of the local ones
         assert res["differs_from_local"] > 1e-2, (rank, res)    # ... and is not just the local gradient
+        assert res["accum_err"] < 1e-3, (rank, res)             # accumulation boundary: mean of the ACCUMULATED gradients
+
+
+def _rccl_worker(q):
+    """one rank, backend nccl (= RCCL): the communicator, the bucket hook issued from the side stream's context, the
+    finishers and no_sync run exactly as in the multi-GPU job (YH_FORCE_DP keeps the collectives for world size 1)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", YH_FORCE_DP="1")
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from yoloseries_amd import models
+    from yoloseries_amd.loss import YOLOV5Loss
+    from yoloseries_amd.utils import FlatSGD
+    from yoloseries_amd.utils.dist import DataParallelGrads
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
+    import bench
+    res = {}
+    torch.manual_seed(0)
+    B, img = 2, 128
+    model = models.YOLOV5Small(3, 80).to(dev).train()
+    opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=0.0, nesterov=True)
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(10)).to(dev)
+    t = torch.from_numpy(synth_targets(B, img, 80, 6, seed=20)).to(dev)
+
+    def fresh_loss():
+        return YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), bench.make_hyp(dev, img, B))
+    fresh_loss()(model(x), t)["tot_loss"].backward()
+    g_plain = model._yh_last_flat_grad.clone()
+    opt.zero_grad()
+    calls = {"n": 0}
+    for dtype in (None, torch.bfloat16):
+        dp = DataParallelGrads(model, bucket_dtype=dtype)
+        inner = dp._bucket
+
+        def counting(part, inner=inner):
+            f = inner(part)
+            calls["n"] += f is not None
+            return f
+        model._yh_bucket_hook = counting
+        fresh_loss()(model(x), t)["tot_loss"].backward()
+        g = model._yh_last_flat_grad.clone()
+        opt.zero_grad()
+        scale = g_plain.abs().max().item()
+        res["err_" + ("fp32" if dtype is None else "bf16")] = float((g - g_plain).abs().max().item() / scale)
+        with dp.no_sync():
+            before = calls["n"]
+            fresh_loss()(model(x), t)["tot_loss"].backward()
+            res["nosync_" + ("fp32" if dtype is None else "bf16")] = calls["n"] == before
+        opt.zero_grad()
+        dp.reset()
+    res["bucket_collectives"] = calls["n"]
+    from yoloseries_amd.utils.dist import all_reduce_norm
+    all_reduce_norm(model)
+    torch.cuda.synchronize()
+    res["backend"] = dist.get_backend()
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_bucket_path(dev):
+    """the `nccl` (RCCL) branch on the one GPU of the test box: world size 1 communicator, overlapped buckets"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert res["backend"] == "nccl"
+    assert res["bucket_collectives"] >= 4, res               # >= 2 buckets per backward, two exchanged backwards
+    assert res["err_fp32"] < 1e-3, res                       # sum over one rank / 1 == the plain gradient (atomics noise only)
+    assert res["err_bf16"] < 2e-2, res                       # bf16 buckets: one rounding of every element
+    assert res["nosync_fp32"] and res["nosync_bf16"], res

@@ -28,6 +28,15 @@ def test_training_driver_smoke(dev, tmp_path, monkeypatch):
     assert t2.start_epoch == 2
     for (k, a), (_, b2) in zip(t.model.state_dict().items(), t2.model.state_dict().items()):
         assert torch.equal(a.cpu(), b2.cpu()), k
+    # ... and the optimizer state: the momentum buffer is loaded before the parameter arena exists and must be in place
+    # once the first forward has built it (FlatSGD.load_state_dict defers the copy)
+    mb = ck["optim_state_dict"]["momentum_buffer"]
+    assert mb is not None and float(mb.abs().sum()) > 0
+    assert t2.optimizer.steps == ck["optim_state_dict"]["steps"] > 0
+    t2.model.train()
+    t2.model(torch.rand(4, 3, 128, 128, device=dev))
+    t2.optimizer._pack()
+    assert torch.equal(t2.optimizer.buf.cpu(), mb.cpu())
 
 
 def test_training_driver_dataset_path(dev, tmp_path, monkeypatch):

@@ -120,8 +120,14 @@ def test_loss_vs_oracle_bf16_layout(dev, focal):
         ref = og.numpy()
         # gradient is stored in bf16: half-ulp relative 2^-9 plus absolute floor
         np.testing.assert_allclose(gr.float().cpu().numpy(), ref, rtol=6e-3, atol=1e-3 * np.abs(ref).max())
-    # the padding column (channel 255) of the gradient buffer must be zero
-    assert True
+    # the padding column (channel 255) of the gradient buffers must be zero: the head's data / weight gradient kernels
+    # read all ld = 256 columns of every cell
+    for gr in grads:
+        Bn, Ct, hh, ww = gr.shape
+        ld = gr.stride(3)
+        assert ld == 256 and Ct == 255
+        whole = gr.as_strided((Bn, hh, ww, ld), (hh * ww * ld, ww * ld, ld, 1))
+        assert (whole[..., Ct:] == 0).all()
 
 
 def test_ciou_and_iou_utils(dev):

@@ -155,10 +155,12 @@ class Training:
         step_in_total = self.start_epoch * len(self.train_dataloader)
         for epoch in range(self.start_epoch, hyp['total_epoch']):
             self.model.train()
+            # LambdaLR semantics (train_yolov5.py:152-164): 'initial_lr' stays the base learning rate, the per-epoch factor only
+            # scales 'lr'; the warm-up interpolates towards the unscheduled 'initial_lr' (train_yolov5.py:437-456)
             base = self.lr_scheduler_fn(epoch)
             for g in self.optimizer.param_groups:
-                g['initial_lr'] = hyp['lr'] * base
-                g['lr'] = g['initial_lr']
+                g['initial_lr'] = hyp['lr']
+                g['lr'] = g['initial_lr'] * base
             for i, x in enumerate(self.train_dataloader):
                 step_in_total += 1
                 self.warmup(step_in_total)

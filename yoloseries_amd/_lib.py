@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
         ("out1", C.c_void_p), ("ld1", C.c_int32),
         ("res", C.c_void_p), ("ldr", C.c_int32),
         ("stats", C.c_void_p),
-        ("tile_n", C.c_int32), ("grid_cap", C.c_int32), ("tile_k", C.c_int32), ("reserved0", C.c_int32),
+        ("tile_n", C.c_int32), ("grid_cap", C.c_int32), ("tile_k", C.c_int32), ("algo", C.c_int32),
         ("bnr_z", C.c_void_p), ("bnr_ldz", C.c_int32), ("bnr_C", C.c_int32), ("bnr_ws", C.c_void_p), ("bnr_part", C.c_void_p),
     ]
 

@@ -781,6 +781,385 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
 }
 
 // ------------------------------------------------------------------------------------------------
+// v3: the main loop restructured around LDS-DMA.  A/B tiles go global -> LDS directly (buffer_load ... lds, 1 KiB per
+// wave instruction, no VGPR staging and no ds_write phase) into a ring of STG stages; a wave waits only for ITS OWN
+// transfers of the stage it is about to read (counted s_waitcnt vmcnt(N): the younger stages stay in flight across the
+// barrier), then ONE raw s_barrier per k-step both publishes that stage and frees the stage consumed one step earlier,
+// which is refilled at once.  Wave tile 64 x 64 (four MFMAs per four fragment reads: half the LDS read traffic per
+// MFMA of the 32 x 64 wave tile of v2), block tile BMT x BN = 256 x 128 (8 waves) or 128 x 128 / 128 x 64 (4 waves).
+// LDS rows are unpadded (an LDS-DMA instruction writes 1 KiB contiguously: lane l -> base + 16 l); bank conflicts are
+// avoided by an XOR swizzle of the 16-byte chunks applied on the SOURCE side (the lane that fills LDS chunk position q
+// of row r fetches global chunk q ^ f(r)) and again on the fragment reads.  Padding taps / rows past M carry an
+// out-of-range offset: the range check of the buffer descriptor makes the DMA write zeros.
+// Eligible when every segment has a multiple of BKT channels (host check); everything else runs on v2.
+template <int CHR> __device__ __forceinline__ int swz_f(int row) { return CHR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+
+#define YH_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+
+// one LDS-DMA wave instruction: 64 lanes x 16 bytes from (rsrc, per-lane voff + scalar soff) to lds .. lds + 1024
+__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voff, int soff)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void lds_void;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
+template <int BMT, int BN, int WM, int WN, int BKT, int STG, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
+{
+    constexpr int NWV = WM * WN;
+    constexpr int NT = NWV * 64;
+    constexpr int TM = BMT / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr int ROWB = BKT * 2;                   // bytes per tile row
+    constexpr int CHR = BKT / 8;                    // 16-byte chunks per tile row
+    constexpr int RPI = 1024 / ROWB;                // tile rows one LDS-DMA wave instruction fills
+    constexpr int NA = BMT / (RPI * NWV);           // A instructions per wave and stage
+    constexpr int NB = BN / (RPI * NWV);            // B instructions per wave and stage
+    constexpr int LPS = NA + NB;                    // LDS-DMA instructions per wave and stage
+    constexpr int STAGE_BYTES = (BMT + BN) * ROWB;
+    constexpr int CP = BN + 8;
+    constexpr int RING_BYTES = STG * STAGE_BYTES;
+    constexpr int MAIN_BYTES = RING_BYTES > (BMT * CP * 2) ? RING_BYTES : (BMT * CP * 2);
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(NA >= 1 && NB >= 1 && BMT % (RPI * NWV) == 0 && BN % (RPI * NWV) == 0, "tile / wave count mismatch");
+    static_assert(STG >= 2 && STG <= 4, "2..4 stages");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* sC = reinterpret_cast<uint16_t*>(smem);
+    float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    int* sPix = reinterpret_cast<int*>(smem + MAIN_BYTES + WM * 2 * BN * 4);
+
+    const yh_conv_desc& d = p.d;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int n0 = blockIdx.y * BN;
+    const int HoWo = d.Ho * d.Wo;
+    const int sdmask = (1 << p.sdshift) - 1;
+    const int ph = p.cls ? (blockIdx.z >> 1) : 0, pw = p.cls ? (blockIdx.z & 1) : 0;
+    const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
+    const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
+    const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
+    const int ncb = p.Ctot / BKT;
+    const int nkt = nkh * nkw * ncb;
+    const int HcWc = p.Hc * p.Wc;
+    const int C0 = d.seg[0].C;
+    const int mtiles = (p.M + BMT - 1) / BMT;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg[0].ptr, 0, p.segbytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d.nseg > 1 ? d.seg[1].ptr : d.seg[0].ptr), 0,
+                                                                          d.nseg > 1 ? p.segbytes[1] : p.segbytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, p.wbytes, 0x00020000);
+
+    // loader geometry: instruction i of this wave fills tile rows (i*NWV + wave)*RPI .. +RPI; this lane's row / chunk
+    const int lrow = lane / CHR, lq = lane % CHR;
+    unsigned voffB[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = (j * NWV + wave) * RPI + lrow;
+        voffB[j] = (unsigned)(((n0 + row) * p.Ktot + ((lq ^ swz_f<CHR>(row)) * 8)) * 2);
+    }
+    unsigned chA[NA];                                // byte offset of this lane's (swizzled) source chunk inside the k-block
+#pragma unroll
+    for (int i = 0; i < NA; ++i) chA[i] = (unsigned)((lq ^ swz_f<CHR>((i * NWV + wave) * RPI + lrow)) * 16);
+
+    // fragment reads: rows of a wave tile differ by multiples of 32, so the swizzle term depends on the lane only
+    const int fx = swz_f<CHR>(lane & 31);
+    int koff[BKT / 16];
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) koff[ks] = ((ks * 2 + (lane >> 5)) ^ fx) * 16;
+    const int rdA0 = (wm * (TM * 32) + (lane & 31)) * ROWB;                 // + i*32*ROWB
+    const int rdB0 = BMT * ROWB + (wn * (TN * 32) + (lane & 31)) * ROWB;    // + j*32*ROWB
+
+    float run_s = 0.f, run_q = 0.f;
+    float bs_[8], bq_[8];
+    if (EPI == 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bs_[e] = 0.f; bq_[e] = 0.f; }
+        for (int i = t; i < 2 * BN; i += NT) {
+            const int which = i / BN, c = i - which * BN;
+            sStat[i] = (n0 + c < d.N) ? d.bnr_ws[(size_t)which * d.bnr_C + n0 + c] : 0.f;
+        }
+        __syncthreads();
+    }
+
+    for (int mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
+        const int m0 = mt * BMT;
+        int hb[NA], wb[NA], img[NA];
+        unsigned voff0[NA], voff1[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = (i * NWV + wave) * RPI + lrow;
+            const int m = m0 + row;
+            voff0[i] = OOB; voff1[i] = OOB;
+            img[i] = 0; hb[i] = -(1 << 28); wb[i] = -(1 << 28);
+            if (m < p.M) {
+                if (p.pointwise) {
+                    voff0[i] = (unsigned)m * (unsigned)(d.seg[0].ld * 2) + chA[i];
+                    voff1[i] = (unsigned)m * (unsigned)(d.seg[1].ld * 2) + chA[i];
+                } else {
+                    int im, ho, wo;
+                    if (p.cls) {
+                        im = m / HcWc;
+                        const int rem = m - im * HcWc;
+                        const int ii = rem / p.Wc;
+                        ho = 2 * ii + ph; wo = 2 * (rem - ii * p.Wc) + pw;
+                    } else {
+                        im = m / HoWo;
+                        const int rem = m - im * HoWo;
+                        ho = rem / d.Wo;
+                        wo = rem - ho * d.Wo;
+                    }
+                    img[i] = im; hb[i] = ho * p.sa + p.sc; wb[i] = wo * p.sa + p.sc;
+                    if (p.cls && lq == 0) sPix[row] = (im * d.Ho + ho) * d.Wo + wo;
+                }
+            }
+        }
+
+        f32x16_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        int ld_tap = 0, ld_cb = 0, kcol_base = 0;
+        auto tap_setup = [&](int tapl) {
+            int kh = tapl / nkw;
+            int kw = tapl - kh * nkw;
+            if (p.cls) { kh = kh0 + 2 * kh; kw = kw0 + 2 * kw; }
+            kcol_base = (kh * d.KW + kw) * p.Ctot;
+            if (p.pointwise) return;
+            const int u0 = d.seg[0].ups, u1 = d.seg[1].ups;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int hn = hb[i] + kh * p.sb;
+                const int wn_ = wb[i] + kw * p.sb;
+                bool ok = hn >= 0 && wn_ >= 0 && (((hn | wn_) & sdmask) == 0);
+                const int hs = hn >> p.sdshift, ws = wn_ >> p.sdshift;
+                ok = ok && hs < d.Hi && ws < d.Wi;
+                const unsigned pix0 = (unsigned)((img[i] * (d.Hi >> u0) + (hs >> u0)) * (d.Wi >> u0) + (ws >> u0));
+                const unsigned pix1 = (unsigned)((img[i] * (d.Hi >> u1) + (hs >> u1)) * (d.Wi >> u1) + (ws >> u1));
+                voff0[i] = ok ? pix0 * (unsigned)(d.seg[0].ld * 2) + chA[i] : OOB;
+                voff1[i] = ok ? pix1 * (unsigned)(d.seg[1].ld * 2) + chA[i] : OOB;
+            }
+        };
+        // one stage = NA + NB LDS-DMA instructions of this wave
+        auto issue = [&](int slot) {
+            if (ld_cb == 0) tap_setup(ld_tap);
+            const int c = ld_cb * BKT;
+            const bool s1 = d.nseg > 1 && c >= C0;           // wave-uniform
+            unsigned char* sa = smem + slot * STAGE_BYTES + wave * (RPI * ROWB);
+            if (s1) {
+                const int so = (c - C0) * 2;
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+                    lds_dma16(rs1, sa + i * (NWV * RPI * ROWB), voff1[i], so);
+            } else {
+                const int so = c * 2;
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+                    lds_dma16(rs0, sa + i * (NWV * RPI * ROWB), voff0[i], so);
+            }
+            const int sw = (kcol_base + c) * 2;
+            unsigned char* sb = sa + BMT * ROWB;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                lds_dma16(rsw, sb + j * (NWV * RPI * ROWB), voffB[j], sw);
+            if (++ld_cb == ncb) { ld_cb = 0; ++ld_tap; }
+        };
+
+#pragma unroll
+        for (int s = 0; s < STG - 1; ++s)
+            if (s < nkt) issue(s);
+        int slot = 0, islot = STG - 1;
+        for (int kt = 0; kt < nkt; ++kt) {
+            // this wave's transfers of stage kt have landed when at most the younger stages are outstanding
+            const int younger = nkt - 1 - kt;
+            if (STG == 2 || younger == 0) YH_VMCNT(0);
+            else if (STG == 3 || younger == 1) YH_VMCNT(LPS);
+            else YH_VMCNT(2 * LPS);
+            __builtin_amdgcn_s_barrier();          // stage kt complete for every wave; stage kt-1 no longer read by anyone
+            if (kt + STG - 1 < nkt) issue(islot);
+            const unsigned char* sbase = smem + slot * STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < BKT / 16; ++ks) {
+                bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sbase + rdA0 + i * (32 * ROWB) + koff[ks]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(sbase + rdB0 + j * (32 * ROWB) + koff[ks]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            slot = slot + 1 == STG ? 0 : slot + 1;
+            islot = islot + 1 == STG ? 0 : islot + 1;
+        }
+        __syncthreads();                           // nothing in flight (last wait was vmcnt(0)); ring -> epilogue buffer
+
+        // ---- epilogue (as v2): accumulators -> LDS (bf16, row-major) -> 16-byte global stores
+        constexpr int CPRz = BN / 8;
+        constexpr int NCHz = BMT * CPRz / NT;
+        uint4 zpre[EPI == 3 ? NCHz : 1];
+        if (EPI == 3) {
+#pragma unroll
+            for (int i = 0; i < NCHz; ++i) {
+                const int id = t + i * NT;
+                const int row = id / CPRz;
+                const int m = m0 + row;
+                const int n = n0 + (id - row * CPRz) * 8;
+                zpre[i] = make_uint4(0, 0, 0, 0);
+                if (m < p.M && n < d.N) {
+                    const size_t orow = p.cls ? (size_t)sPix[row] : (size_t)m;
+                    zpre[i] = *reinterpret_cast<const uint4*>(d.bnr_z + orow * d.bnr_ldz + n);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = wn * (TN * 32) + j * 32 + (lane & 31);
+            float bs = 0.f, scl = 1.f, sft = 0.f;
+            if (EPI == 2) {
+                const int n = n0 + c;
+                const bool nv = n < d.N;
+                bs = (d.bias && nv) ? d.bias[n] : 0.f;
+                scl = (d.scale && nv) ? d.scale[n] : 1.f;
+                sft = (d.shift && nv) ? d.shift[n] : 0.f;
+            }
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                uint16_t* dst = sC + (wm * (TM * 32) + i * 32 + 4 * (lane >> 5)) * CP + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (EPI == 2) {
+                        v = (v + bs) * scl + sft;
+                        if (d.act == YH_ACT_SILU) v = silu_fast(v);
+                    }
+                    dst[((r & 3) + 8 * (r >> 2)) * CP] = f2bf(v);
+                    if (EPI == 1) { s += v; q += v * v; }
+                }
+            }
+            if (EPI == 1) {
+                s += __shfl_xor(s, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (lane < 32) {
+                    sStat[(wm * 2 + 0) * BN + c] = s;
+                    sStat[(wm * 2 + 1) * BN + c] = q;
+                }
+            }
+        }
+        __syncthreads();
+
+        constexpr int CPR = BN / 8;
+        constexpr int NCH = BMT * CPR / NT;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = t + i * NT;
+            const int row = id / CPR;
+            const int cch = id - row * CPR;
+            const int m = m0 + row;
+            const int n = n0 + cch * 8;
+            if (m < p.M && n < d.N) {
+                uint4 v = *reinterpret_cast<const uint4*>(sC + row * CP + cch * 8);
+                const size_t orow = p.cls ? (size_t)sPix[row] : (size_t)m;
+                if (EPI == 2) {
+                    uint16_t* dst;
+                    const bool first = n < d.nsplit;
+                    if (first) dst = d.out0 + orow * d.ld0 + n;
+                    else       dst = d.out1 + orow * d.ld1 + (n - d.nsplit);
+                    const bool addres = (d.res != nullptr) && first;
+                    if (addres || d.accumulate) {
+                        float f[8];
+                        unpack8(v, f);
+                        if (addres) {
+                            uint4 rv = *reinterpret_cast<const uint4*>(d.res + orow * d.ldr + n);
+                            float g[8]; unpack8(rv, g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        }
+                        if (d.accumulate) {
+                            uint4 ov = *reinterpret_cast<const uint4*>(dst);
+                            float g[8]; unpack8(ov, g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        }
+                        v = pack8(f);
+                    }
+                    *reinterpret_cast<uint4*>(dst) = v;
+                } else {
+                    *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
+                    if (EPI == 3) {
+                        const uint4 zv = zpre[i];
+                        float g[8], z[8];
+                        unpack8(v, g);
+                        unpack8(zv, z);
+                        const float4 s0 = *reinterpret_cast<const float4*>(sStat + cch * 8);
+                        const float4 s1 = *reinterpret_cast<const float4*>(sStat + cch * 8 + 4);
+                        const float4 h0 = *reinterpret_cast<const float4*>(sStat + BN + cch * 8);
+                        const float4 h1 = *reinterpret_cast<const float4*>(sStat + BN + cch * 8 + 4);
+                        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = z[e] * sc[e] + sh[e];
+                            const float sg = sigmoid_fast(a);
+                            const float dz = g[e] * (sg * (1.f + a * (1.f - sg)));
+                            bs_[e] += dz; bq_[e] += dz * z[e];
+                        }
+                    }
+                }
+            }
+        }
+        if (EPI == 1 && t < BN) {
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                run_s += sStat[(w * 2 + 0) * BN + t];
+                run_q += sStat[(w * 2 + 1) * BN + t];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (EPI == 1 && t < BN) {
+        d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
+        d.stats[((size_t)blockIdx.x * 2 + 1) * d.Npad + n0 + t] = run_q;
+    }
+    if (EPI == 3) {
+        constexpr int CPR2 = BN / 8;
+        float* sRed = reinterpret_cast<float*>(smem);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sRed[t * 16 + e] = bs_[e]; sRed[t * 16 + 8 + e] = bq_[e]; }
+        __syncthreads();
+        const size_t rowi = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+        for (int i = t; i < 2 * BN; i += NT) {
+            const int which = i / BN, c = i - which * BN;
+            float v = 0.f;
+            for (int j = c / 8; j < NT; j += CPR2) v += sRed[j * 16 + which * 8 + (c & 7)];
+            if (n0 + c < d.N) d.bnr_part[(rowi * 2 + which) * d.N + n0 + c] = v;
+        }
+    }
+}
+
+template <int BMT, int BN, int WM, int BKT, int STG>
+constexpr size_t conv3_smem_bytes() {
+    size_t a = (size_t)STG * (BMT + BN) * BKT * 2;
+    size_t c = (size_t)BMT * (BN + 8) * 2;
+    return (a > c ? a : c) + WM * 2 * BN * 4 + BMT * 4;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stem ("focus") kernel: 3x3 / stride 1 / pad 1 on the 16-channel space-to-depth image, 32 output channels
 // (utils/layer_tools.py:82-94 applied to models/normal/yolov5s.py's 6x6/s2 stem).  K per tap is exactly one
 // v_mfma_f32_32x32x16_bf16, the whole weight matrix (9 fragments) lives in registers, and a WAVE works alone on strips
@@ -976,11 +1355,54 @@ int pick_bkt(const yh_conv_desc* d, int bn) {
     return 64;
 }
 
+// LDS-DMA kernel (conv_v3_kernel) variant for this descriptor: 0 = none (v2 / generic kernel), 1 = 256 x 128 tile (8 waves),
+// 2 = 128 x 128 (4 waves), 3 = 128 x 64 (4 waves).  d->algo: 0 library default, 1 force v2, 2..4 = variant 1..3 when eligible.
+int conv_v3_variant(const yh_conv_desc* d)
+{
+    if (d->algo == 1 || stem_eligible(d) || !conv_v2_ok(d)) return 0;
+    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 512)) return 0; }
+    for (int s = 0; s < d->nseg; ++s) if (d->seg[s].C % 32) return 0;
+    if (d->N <= 32) return 0;
+    if (d->tile_n == 32) return 0;
+    const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || d->nsplit < d->N;
+    if (generic && d->stats) return 0;
+    if (d->algo >= 2 && d->algo <= 4) {
+        const int v = d->algo - 1;
+        return v;
+    }
+    // default: the big tile for K-heavy layers with enough pixel tiles to fill the chip, else v2
+    const long M = (long)d->B * d->Ho * d->Wo;
+    int Ctot = 0;
+    for (int s = 0; s < d->nseg; ++s) Ctot += d->seg[s].C;
+    const long K = (long)d->KH * d->KW * Ctot;
+    if (d->N > 64 && K >= 512 && M >= 256L * 192) return 1;
+    return 0;
+}
+int conv_v3_bkt(const yh_conv_desc* d) {
+    for (int s = 0; s < d->nseg; ++s) if (d->seg[s].C % 64) return 32;
+    return d->tile_k == 32 ? 32 : 64;
+}
+
 void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
     long M = (long)d->B * d->Ho * d->Wo;
     if (stem_eligible(d)) {
         const long blocks = (M / 32 + 3) / 4;
         *gx = (int)(blocks < STEM_BLOCKS ? blocks : STEM_BLOCKS); *gy = 1; *bn = 32;
+        return;
+    }
+    if (const int v3 = conv_v3_variant(d)) {
+        const int bmt = v3 == 1 ? 256 : 128;
+        const int b = v3 == 3 ? 64 : 128;
+        const int nt = (d->N + b - 1) / b;
+        const int bkt = conv_v3_bkt(d);
+        const int occ = v3 == 1 ? 1 : (v3 == 2 ? 2 : (bkt == 64 ? 2 : 3));
+        const bool cls = d->mode == YH_CONV_DGRAD && d->stride == 2 && d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->KH >= 2 && d->KW >= 2 && !d->stats;
+        const long Mc = cls ? M / 4 : M;
+        const int mt = (int)((Mc + bmt - 1) / bmt);
+        int cap = (256 * occ) / (nt * (cls ? 4 : 1));
+        if (cap < 1) cap = 1;
+        if (d->grid_cap > 0) cap = d->grid_cap;
+        *gx = mt < cap ? mt : cap; *gy = nt; *bn = b;
         return;
     }
     int mtiles = (int)((M + BM - 1) / BM);
@@ -1067,7 +1489,8 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     int gx, gy, bn;
     conv_grid(d, &gx, &gy, &bn);
     YH_CHECK_ARG(gy * bn <= d->Npad, "yh_conv_igemm: Npad too small for tile");
-    if (k.cls) { gx = (gx + 3) / 4; if (gx > k.mtiles) gx = k.mtiles; }
+    const int v3 = conv_v3_variant(d);
+    if (k.cls && !v3) { gx = (gx + 3) / 4; if (gx > k.mtiles) gx = k.mtiles; }
     dim3 grid(gx, gy, k.cls ? 4 : 1), block(256);
     // ---- lean buffer-load kernel
     const int bkt = pick_bkt(d, bn);
@@ -1109,6 +1532,41 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
                      "yh_conv_igemm: the fused BatchNorm-backward reduction needs the plain buffer-load data-gradient path");
         YH_CHECK_ARG(d->bnr_z && yh_aligned16(d->bnr_z) && d->bnr_ldz % 8 == 0 && d->bnr_ws && d->bnr_C >= d->N && d->N % 8 == 0,
                      "yh_conv_igemm: bad fused-reduction operands");
+    }
+    if (v3) {
+        YH_CHECK_ARG(k.v2, "yh_conv_igemm: the LDS-DMA kernel needs the buffer-load path");
+        const int bkt3 = conv_v3_bkt(d);
+        const int epi = d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0));
+        const int bmt = v3 == 1 ? 256 : 128;
+        const int stg = v3 == 1 ? (bkt3 == 64 ? 3 : 4) : (v3 == 2 ? (bkt3 == 64 ? 2 : 4) : (bkt3 == 64 ? 3 : 4));
+        if (name_out) {
+            snprintf(name_out, name_len, "conv_v3_kernel<%d, %d, %d, 2, %d, %d, %d>", bmt, bn, v3 == 1 ? 4 : 2, bkt3, stg, epi);
+            return YH_OK;
+        }
+        hipStream_t st3 = (hipStream_t)stream;
+#define YH_LAUNCH_V3(BMT_, BN_, WM_, BKT_, STG_)                                                                     \
+        do {                                                                                                         \
+            const size_t sm = conv3_smem_bytes<BMT_, BN_, WM_, BKT_, STG_>();                                        \
+            const dim3 blk(WM_ * 2 * 64);                                                                            \
+            static bool attr_set = false;                                                                            \
+            if (!attr_set) {                                                                                         \
+                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set = true;                                                                                     \
+            }                                                                                                        \
+            if (epi == 3)      conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3><<<grid, blk, sm, st3>>>(k);          \
+            else if (epi == 2) conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2><<<grid, blk, sm, st3>>>(k);          \
+            else if (epi == 1) conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1><<<grid, blk, sm, st3>>>(k);          \
+            else               conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0><<<grid, blk, sm, st3>>>(k);          \
+        } while (0)
+        if (v3 == 1) { if (bkt3 == 64) YH_LAUNCH_V3(256, 128, 4, 64, 3); else YH_LAUNCH_V3(256, 128, 4, 32, 4); }
+        else if (v3 == 2) { if (bkt3 == 64) YH_LAUNCH_V3(128, 128, 2, 64, 2); else YH_LAUNCH_V3(128, 128, 2, 32, 4); }
+        else { if (bkt3 == 64) YH_LAUNCH_V3(128, 64, 2, 64, 3); else YH_LAUNCH_V3(128, 64, 2, 32, 4); }
+#undef YH_LAUNCH_V3
+        YH_CHECK_LAUNCH("yh_conv_igemm(v3)");
+        return YH_OK;
     }
     if (name_out) {
         const int wm = bn == 128 ? 2 : 4, wn = bn == 128 ? 2 : 1, minw = bn == 32 ? 4 : (bn == 64 ? 3 : 2);
@@ -1178,6 +1636,7 @@ extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
     int gx, gy, bn;
     conv_grid(d, &gx, &gy, &bn);
     const bool cls = d->stride == 2 && d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->KH >= 2 && d->KW >= 2;
+    if (conv_v3_variant(d)) return cls ? gx * 4 : gx;
     if (cls) {
         const long mt = ((long)(M / 4) + BM - 1) / BM;
         gx = (gx + 3) / 4;

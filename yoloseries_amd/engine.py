@@ -400,55 +400,74 @@ class Program:
         return d
 
     def _tune_conv(self, d, kind, name, stats_ok=False):
-        """Launch parameters of one conv / dgrad launch (k-step width, cap on persistent blocks), timed once when the
-        program is built: the best setting differs per layer shape by 5-20 % (YH_CONV_TUNE=0: library defaults).
-        Results never change (identical math); only the number of BatchNorm partial-sum rows follows the grid."""
+        """Launch parameters of one conv / dgrad launch — kernel family (register-staged conv_v2 or LDS-DMA conv_v3 with one
+        of its tiles), k-step width, cap on persistent blocks — timed once when the program is built: the best setting
+        differs per layer shape by 5-40 % (YH_CONV_TUNE=0: library defaults).  Results never change (identical math);
+        only the number of BatchNorm partial-sum rows follows the grid."""
         if os.environ.get("YH_CONV_TUNE", "1") == "0":
             return
-        key = f"conv:{kind}:" + ",".join(str(int(v)) for v in (
+        key = f"conv3:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
             int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part))))
         cache = _tune_cache()
         if key in cache:
-            d.tile_k, d.grid_cap = (int(v) for v in cache[key])
+            d.tile_k, d.grid_cap, d.algo = (int(v) for v in cache[key])
             return
         L = self.L
         saved = (d.seg[0].ptr, d.stats)
         if not d.seg[0].ptr:
             d.seg[0].ptr = self.gy_scratch.data_ptr()
+        # candidates: (algo, tile_k, grid_cap)
         d.tile_k = d.grid_cap = 0
+        d.algo = 1
         base = L.yh_conv_stat_blocks(C.byref(d))
-        tmp_stats = None
-        if stats_ok:
-            tmp_stats = torch.zeros(2 * base + 8, 2, d.Npad, dtype=torch.float32, device=self.dev)
-            d.stats = tmp_stats.data_ptr()
-        saved_part, tmp_part = d.bnr_part, None
-        if d.bnr_part:                   # a slab big enough for every grid tried below
-            tmp_part = torch.zeros((2 * base + 8) * 4 * 2 * d.N, dtype=torch.float32, device=self.dev)
-            d.bnr_part = tmp_part.data_ptr()
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        best, best_ms = (0, 0), None
+        cands = []
         tks = (0, 32) if all(d.seg[i].C % 64 == 0 for i in range(d.nseg)) and d.N > 64 else (0,)
         for tk in tks:
             for cap in (0, 2 * base):
                 d.tile_k, d.grid_cap = tk, cap
                 if cap and L.yh_conv_stat_blocks(C.byref(d)) == base:
                     continue                       # fewer tiles than blocks: the cap changes nothing
-                check(L.yh_conv_igemm(C.byref(d), st), f"yh_conv_igemm tune [{name}]")
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    L.yh_conv_igemm(C.byref(d), st)
-                e1.record()
-                e1.synchronize()
-                ms = e0.elapsed_time(e1)
-                if best_ms is None or ms < best_ms * 0.97:       # keep the default unless clearly better
-                    best, best_ms = (tk, cap), ms
-        d.tile_k, d.grid_cap = best
+                cands.append((1, tk, cap))
+        d.tile_k = d.grid_cap = 0
+        if os.environ.get("YH_CONV_V3", "1") != "0":
+            for algo in (2, 3, 4):
+                d.algo = algo
+                if "conv_v3" in self._kernel_name(d):
+                    cands.append((algo, 0, 0))
+        rows_max, bnr_max = 1, 1
+        for algo, tk, cap in cands:
+            d.algo, d.tile_k, d.grid_cap = algo, tk, cap
+            rows_max = max(rows_max, L.yh_conv_stat_blocks(C.byref(d)))
+            if d.bnr_part:
+                bnr_max = max(bnr_max, L.yh_conv_bnr_rows(C.byref(d)))
+        tmp_stats = None
+        if stats_ok:
+            tmp_stats = torch.zeros(rows_max + 8, 2, d.Npad, dtype=torch.float32, device=self.dev)
+            d.stats = tmp_stats.data_ptr()
+        saved_part, tmp_part = d.bnr_part, None
+        if d.bnr_part:                   # a slab big enough for every grid tried below
+            tmp_part = torch.zeros((bnr_max + 8) * 2 * d.N, dtype=torch.float32, device=self.dev)
+            d.bnr_part = tmp_part.data_ptr()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        best, best_ms = (0, 0, 1), None
+        for algo, tk, cap in cands:
+            d.algo, d.tile_k, d.grid_cap = algo, tk, cap
+            check(L.yh_conv_igemm(C.byref(d), st), f"yh_conv_igemm tune [{name}]")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                L.yh_conv_igemm(C.byref(d), st)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if best_ms is None or ms < best_ms * 0.97:       # keep the earlier candidate unless clearly better
+                best, best_ms = (tk, cap, algo), ms
+        d.tile_k, d.grid_cap, d.algo = best
         d.seg[0].ptr, d.stats = saved
         d.bnr_part = saved_part
-        cache[key] = [int(best[0]), int(best[1])]
+        cache[key] = [int(best[0]), int(best[1]), int(best[2])]
         _tune_cache.dirty = True
 
     def _build_forward(self):
@@ -496,7 +515,9 @@ class Program:
                 r = op.res.sl()
                 de.res, de.ldr = r.ptr(), r.ld
             st['desc_eval'] = de
+            self._tune_conv(de, 'eval', op.name)
             self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name, self._fam_conv(op, de)))
+        _tune_cache_save()
 
     def _build_train(self):
         """training program: conv (+ per-block BatchNorm partial sums) -> finalize -> BN+SiLU apply (+ residual)"""
@@ -590,6 +611,15 @@ class Program:
         B, pk, L = self.B, self.pack, self.L
         cmds = []
         max_gy = 0
+        # yh_conv_wgrad addresses its operands with 32-bit buffer offsets: refuse before anything is allocated
+        for op in self.ops:
+            if isinstance(op, ConvOp):
+                gyb = B * op.Ho * op.Wo * (op.y.C if op.kind == 'plain' else op.N) * 2
+                xb = max(B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.buf.C * 2 for sg in op.segs)
+                if gyb >= 2 ** 31 or xb >= 2 ** 31:
+                    raise YoloHipError(f"{op.name}: training at this batch / resolution needs a >= 2 GiB operand in the weight-gradient "
+                                       f"kernel (gy {gyb / 2**30:.2f} GiB, x {xb / 2**30:.2f} GiB); lower the per-GPU batch "
+                                       f"(inference has no such limit)")
         for b in self.bufs:
             b.ginit = np.zeros(b.C, dtype=bool)
             if b.needs_grad and b.g is None and not b.name.endswith(".y") and not getattr(b, "is_head", False):
@@ -984,9 +1014,11 @@ class _NetFn(torch.autograd.Function):
         bucket_hook = getattr(ctx.host, "_yh_bucket_hook", None)   # data-parallel all-reduce, overlapped (utils/dist.py)
         flat_g, pgrads = prog.backward(head_grads, bucket_hook)
         ctx.host._yh_last_flat_grad = flat_g
-        hook = getattr(ctx.host, "_yh_grad_hook", None)        # whole-gradient exchange (when no bucket hook is installed)
-        if hook is not None and bucket_hook is None:
-            hook(flat_g)
+        # whole-gradient hook of the data-parallel exchange: all-reduces flat_g when no bucket hook ran, keeps the
+        # books of un-exchanged accumulation steps, and at an accumulation boundary swaps in the averaged total
+        hook = getattr(ctx.host, "_yh_grad_hook", None)
+        if hook is not None:
+            hook(flat_g, bucketed=bucket_hook is not None)
         hook = getattr(ctx.host, "_yh_grad_hook_opt", None)    # flat-arena optimizer
         if hook is not None:
             hook(flat_g)

@@ -56,6 +56,15 @@ class ExponentialMovingAverageModel:
             pack = st['pack'] if st else None
             if pack is not None and pack.valid_for(src):
                 from .. import hipk
+                est = self.ema.__dict__.get('_yh')
+                epack = est['pack'] if est else None
+                if epack is not None and epack.valid_for(self.ema) and epack.n == pack.n and epack.nbuf == pack.nbuf:
+                    # the EMA module has been evaluated: its parameters live in its own engine arenas (same layout as the
+                    # source's) — update those in place and keep its programs / activation buffers / tuned descriptors
+                    hipk.ema_update(epack.flat, pack.flat, decay_weight)
+                    if pack.nbuf:
+                        hipk.ema_update(epack.fbuf, pack.fbuf, decay_weight)
+                    return
                 fp, fb = self._flat_views(pack)
                 hipk.ema_update(fp, pack.flat, decay_weight)
                 if pack.nbuf:

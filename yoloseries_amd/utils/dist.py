@@ -56,7 +56,7 @@ def allreduce_flat_mean(flat, group=None, chunks=1):
     """in-place mean over ranks of one flat tensor; `chunks` > 1 issues several async collectives so that
     the tail of the buffer can overlap with whatever the caller still computes"""
     world = dist.get_world_size(group) if _on() else 1
-    if world == 1:
+    if world == 1 and not (_on() and os.environ.get("YH_FORCE_DP")):     # YH_FORCE_DP: run the 1-rank communicator too
         return []
     n = flat.numel()
     step = (n + chunks - 1) // chunks
@@ -71,34 +71,78 @@ def allreduce_flat_mean(flat, group=None, chunks=1):
 
 
 class DataParallelGrads:
-    """Averages the engine's flat gradient over the ranks right after each backward (DDP semantics:
-    mean of per-rank gradients; no_sync() skips the exchange on accumulation steps, train_yolov5.py:327)."""
+    """Averages the engine's flat gradient over the ranks during / right after each backward (DDP semantics:
+    mean of per-rank gradients; no_sync() skips the exchange on accumulation steps, train_yolov5.py:327).
 
-    def __init__(self, model, group=None, chunks=2, overlap=True):
+    Gradient accumulation (train_yolov5.py:327-337: non-boundary micro-steps run under no_sync, the boundary step
+    synchronises) follows DDP: what is averaged at the boundary is the ACCUMULATED gradient.  The engine produces one
+    fresh flat gradient per backward, so the un-exchanged ones are summed here (`_local_acc`); at the boundary the
+    bucket collectives are skipped, the total (local sum + this backward) is mean-all-reduced once, and the flat
+    gradient handed on to the optimizer / autograd is replaced by  mean(total) - local sum,  so that whatever
+    accumulates downstream (FlatSGD._on_grad or p.grad +=) ends at mean(total) on every rank.
+
+    bucket_dtype=torch.bfloat16 exchanges the buckets in bf16 (half the xGMI bytes; the sum of `world` bf16 values
+    is rounded once per hop — use for bandwidth-bound models such as YOLOv5l/x, keep fp32 for parity runs)."""
+
+    def __init__(self, model, group=None, chunks=2, overlap=True, bucket_dtype=None):
         self.model, self.group, self.chunks = model, group, chunks
         self.enabled = True
-        model._yh_grad_hook = self._hook
+        self.overlap = overlap
+        self.bucket_dtype = bucket_dtype
+        self._local_acc = None
+        model._yh_grad_hook = self._post
         if overlap:
             # the engine calls this per finished gradient bucket DURING the backward (engine.Program.backward):
             # the collective runs on RCCL's stream while the remaining dgrad/wgrad kernels keep the CUs busy
             model._yh_bucket_hook = self._bucket
 
-    def _hook(self, flat_g):
-        if self.enabled:
+    def _world(self):
+        return dist.get_world_size(self.group) if _on() else 1
+
+    def _post(self, flat_g, bucketed=False):
+        """called by the engine with the complete flat gradient of one backward (after the bucket finishers)"""
+        if not self.enabled:
+            self._local_acc = flat_g.clone() if self._local_acc is None else self._local_acc.add_(flat_g)
+            return
+        if self._local_acc is not None:
+            total = self._local_acc + flat_g
+            allreduce_flat_mean(total, self.group, self.chunks)
+            torch.sub(total, self._local_acc, out=flat_g)
+            self._local_acc = None
+            return
+        if not bucketed:
             allreduce_flat_mean(flat_g, self.group, self.chunks)
 
     def _bucket(self, part):
         """async all-reduce of one contiguous slice of the packed gradient arena; returns the finisher that
         makes the compute stream wait for it and turns the sum into the mean"""
-        world = dist.get_world_size(self.group) if _on() else 1
-        if not self.enabled or world == 1 or part.numel() == 0:
+        world = self._world()
+        if not self.enabled or self._local_acc is not None or world == 1 and not os.environ.get("YH_FORCE_DP") or part.numel() == 0:
             return None
+        if self.bucket_dtype is not None and self.bucket_dtype != part.dtype:
+            low = part.to(self.bucket_dtype)
+            work = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+            def finish_low():
+                work.wait()
+                part.copy_(low)
+                part.div_(world)
+            return finish_low
         work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
         def finish():
             work.wait()
             part.div_(world)
         return finish
+
+    def reset(self):
+        """forget un-exchanged accumulation steps (the caller dropped their gradients, e.g. optimizer.zero_grad() mid-cycle)"""
+        self._local_acc = None
+
+    @property
+    def buckets_active(self):
+        """True when the next backward exchanges its gradient bucket by bucket (engine.Program.backward asks)"""
+        return self.overlap and self.enabled and self._local_acc is None
 
     class _NoSync:
         def __init__(self, dp):
@@ -118,7 +162,7 @@ def all_reduce_norm(module):
     """average every BatchNorm state (weight, bias, running_mean, running_var) over the ranks before
     evaluation — utils/allreduce_norm.py:56-98.  With the engine's arenas this is one collective on the
     float-buffer arena plus one on the gathered affine parameters."""
-    if get_world_size() == 1:
+    if get_world_size() == 1 and not (_on() and os.environ.get("YH_FORCE_DP")):
         return
     states = []
     for m in module.modules():

@@ -26,6 +26,7 @@ class FlatSGD:
             {"name": "bias", "lr": lr, "initial_lr": lr, "momentum": momentum, "weight_decay": 0.0},
         ]
         self._built_for = None
+        self._pending_buf = None        # momentum buffer loaded before the parameter arena exists (resume)
         self.steps = 0
         self._gacc = None
         self._nacc = 0
@@ -48,6 +49,11 @@ class FlatSGD:
             o += p.numel()
         self.group = group
         self.buf = torch.zeros(pack.n, dtype=torch.float32, device=dev)
+        if self._pending_buf is not None:
+            if self._pending_buf.numel() != pack.n:
+                raise YoloHipError(f"FlatSGD: checkpointed momentum buffer has {self._pending_buf.numel()} elements, the model {pack.n}")
+            self.buf.copy_(self._pending_buf.to(dev))
+            self._pending_buf = None
         self.lr_t = torch.zeros(3, dtype=torch.float32, device=dev)
         self.wd_t = torch.zeros(3, dtype=torch.float32, device=dev)
         self.part = torch.zeros(4096, dtype=torch.float32, device=dev)
@@ -105,11 +111,22 @@ class FlatSGD:
         self.model._yh_last_flat_grad = None
 
     def state_dict(self):
-        return {"momentum_buffer": self.buf if self._built_for is not None else None, "steps": self.steps,
-                "param_groups": [dict(g) for g in self.param_groups]}
+        buf = self.buf if self._built_for is not None else self._pending_buf
+        return {"momentum_buffer": buf, "steps": self.steps, "param_groups": [dict(g) for g in self.param_groups]}
 
     def load_state_dict(self, sd):
+        """Training.load_model() runs before the first forward, i.e. before the flat parameter arena (and with it the
+        momentum buffer) exists: the loaded buffer is kept and copied in when the arena is built."""
         self.param_groups = [dict(g) for g in sd["param_groups"]]
         self.steps = sd["steps"]
-        if sd.get("momentum_buffer") is not None and self._built_for is not None:
-            self.buf.copy_(sd["momentum_buffer"])
+        mb = sd.get("momentum_buffer")
+        if mb is None:
+            if self.steps > 0:
+                raise YoloHipError("FlatSGD.load_state_dict: steps > 0 but the checkpoint holds no momentum buffer")
+            return
+        if self._built_for is not None:
+            if mb.numel() != self.buf.numel():
+                raise YoloHipError(f"FlatSGD: checkpointed momentum buffer has {mb.numel()} elements, the model {self.buf.numel()}")
+            self.buf.copy_(mb)
+        else:
+            self._pending_buf = mb.detach().clone()
