@@ -143,3 +143,27 @@ def test_tta_matches_oracle_composition(dev):
         assert (o is None) == (r is None)
         if r is not None:
             np.testing.assert_array_equal(o.numpy(), r)
+
+
+def test_gpu_nms_pairwise_kinds_and_soft_nms(dev):
+    """utils/nms.py:30-140 function level against the reference's own outputs (tests/golden/g11_round2.npz):
+    gpu_nms with giou / diou / ciou (exclusive threshold, pick order) and the two soft-NMS variants"""
+    import torch
+    from yoloseries_amd import utils as U
+    g = np.load(os.path.join(G, "g11_round2.npz"))
+    b = torch.from_numpy(g["nms_boxes"]).to(dev)
+    s = torch.from_numpy(g["nms_scores"]).to(dev)
+    for kind in ("giou", "diou", "ciou"):
+        assert U.gpu_nms(b, s, kind, 0.3) == g[f"nms_keep_{kind}_0.3"].tolist(), kind
+        assert U.gpu_nms(b, s, kind.upper(), 0.3) == g[f"nms_keep_{kind}_0.3"].tolist()
+    sb = torch.from_numpy(g["soft_boxes"]).to(dev)
+    ss = torch.from_numpy(g["soft_scores"]).to(dev)
+    for kind in ("giou", "diou", "ciou"):
+        got = U.gpu_linear_soft_nms(sb, ss.clone(), kind, 0.3, 0.001)
+        np.testing.assert_array_equal(got.cpu().numpy(), g[f"soft_linear_{kind}"])
+    eb = torch.from_numpy(g["softexp_boxes"]).to(dev)
+    es = torch.from_numpy(g["softexp_scores"]).to(dev)
+    got = U.gpu_exponential_soft_nms(eb, es.clone(), "giou", 0.3, 0.5, 0.001)
+    np.testing.assert_array_equal(got.cpu().numpy(), g["soft_exp_giou"])
+    with pytest.raises(ValueError):
+        U.gpu_nms(b, s, "siou", 0.3)

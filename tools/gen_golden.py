@@ -80,6 +80,9 @@ def main():
     if sys.argv[1:] == ["--only", "g10"]:
         gen_g10(ref_utils)
         return
+    if sys.argv[1:] == ["--only", "g11"]:
+        gen_g11(ref_utils, ref_models)
+        return
     from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_head_outputs, synth_targets
 
     os.makedirs(OUT, exist_ok=True)
@@ -457,8 +460,124 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g9_map.npz"), **g9)
 
     gen_g10(ref_utils)
+    gen_g11(ref_utils, ref_models)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden written:", sorted(os.listdir(OUT)), f"{total / 1e6:.2f} MB")
+
+
+def fill_state_rs(mod, seed):
+    """state_dict filled from a NumPy RandomState (reproducible on the test side without torch's RNG): same rule as
+    main()'s fill_state / tests/test_gpu_model.py::fill_state"""
+    import torch
+    r = np.random.RandomState(seed)
+    sd = mod.state_dict()
+    for k2, v in sd.items():
+        if k2.endswith("num_batches_tracked"):
+            continue
+        shape = tuple(v.shape)
+        if k2.endswith("running_var"):
+            a = r.uniform(0.5, 1.5, shape)
+        elif k2.endswith("bn.weight"):
+            a = r.uniform(0.7, 1.3, shape)
+        elif k2.endswith(("running_mean", "bn.bias", ".bias")):
+            a = r.randn(*shape) * 0.2
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+            a = r.randn(*shape) / np.sqrt(fan_in)
+        sd[k2] = torch.from_numpy(a.astype(np.float32))
+    mod.load_state_dict(sd)
+
+
+def gen_g11(ref_utils, ref_models):
+    """G11 (round 2): YOLOv5 m / l / x forward (BASELINE configs #4 / #5 widths and depths, models/normal/yolov5{m,l,x}.py),
+    full-model backward of YOLOv5s and YOLOXs (train_yolov5.py:334-337: gradients of every parameter and of the input from
+    a fixed output gradient), and the function-level NMS variants of utils/nms.py (gpu_nms with giou/diou/ciou, soft-NMS)."""
+    import torch
+    g = {}
+    # ---- models: eval forward at 64^2, train forward at 128^2, seeded state
+    for name, cls, seed in (("m", ref_models.YOLOV5Middle, 1101), ("l", ref_models.YOLOV5Large, 1102), ("x", ref_models.YOLOV5XLarge, 1103)):
+        torch.manual_seed(0)
+        m = cls(3, 80)
+        fill_state_rs(m, seed)
+        g[f"{name}_seed"] = np.array([seed])
+        g[f"{name}_nkeys"] = np.array([len(m.state_dict())])
+        x = torch.from_numpy(np.random.RandomState(seed + 10).rand(2, 3, 64, 64).astype(np.float32))
+        m.eval()
+        with torch.no_grad():
+            outs = m(x)
+        for i, o in enumerate(outs):
+            g[f"{name}_eval64_out{i}"] = o.numpy().astype(np.float16) if False else o.numpy()
+        m.train()
+        x2 = torch.from_numpy(np.random.RandomState(seed + 11).rand(2, 3, 128, 128).astype(np.float32))
+        outs = m(x2)
+        for i, o in enumerate(outs):
+            flat = o.detach().numpy().reshape(-1)
+            idx = np.random.RandomState(seed + 20 + i).randint(0, flat.size, 4096)
+            g[f"{name}_train128_idx{i}"] = idx.astype(np.int64)
+            g[f"{name}_train128_val{i}"] = flat[idx]
+            g[f"{name}_train128_shape{i}"] = np.array(o.shape)
+        g[f"{name}_train128_rv_last"] = m.head_stage4_bscp.cba3.bn.running_var.numpy().copy()
+        del m
+
+    # ---- full-model backward: per-parameter gradient signatures + input gradient
+    def backward_sig(key, m, x, outs_of):
+        m.train()
+        xt = torch.from_numpy(x.copy()).requires_grad_(True)
+        outs = outs_of(m(xt))
+        r = np.random.RandomState(1200 + len(key))
+        gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)) for o in outs]
+        for i, go in enumerate(gos):
+            g[f"{key}_gout_shape{i}"] = np.array(go.shape)
+        params = list(m.parameters())
+        grads = torch.autograd.grad(outs, [xt] + params, gos)
+        gx = grads[0].numpy().reshape(-1)
+        idx = np.random.RandomState(1300).randint(0, gx.size, 8192)
+        g[f"{key}_gx_idx"] = idx.astype(np.int64)
+        g[f"{key}_gx_val"] = gx[idx]
+        g[f"{key}_gx_sig"] = np.array([gx.astype(np.float64).sum(), np.abs(gx.astype(np.float64)).sum(), np.sqrt((gx.astype(np.float64) ** 2).sum())])
+        names, sig, samp = [], [], []
+        for (n, p), gr in zip(m.named_parameters(), grads[1:]):
+            gf = gr.double().reshape(-1)
+            names.append(n)
+            sig.append([gf.sum().item(), gf.abs().sum().item(), gf.norm().item(), float(gf.numel())])
+            si = np.random.RandomState(1400 + len(names)).randint(0, gf.numel(), 16)
+            samp.append(gf.numpy()[si])
+        g[f"{key}_pnames"] = np.array(names)
+        g[f"{key}_psig"] = np.array(sig)
+        g[f"{key}_psamp"] = np.array(samp)
+    torch.manual_seed(0)
+    ms = ref_models.YOLOV5Small(3, 80)
+    fill_state_rs(ms, 1111)
+    xs = np.random.RandomState(1112).rand(2, 3, 256, 256).astype(np.float32)
+    backward_sig("v5s_bwd", ms, xs, lambda o: list(o))
+    torch.manual_seed(0)
+    mx = ref_models.YOLOXSmall(1, 3, 80, 0.01)
+    fill_state_rs(mx, 1121)
+    xx = np.random.RandomState(1122).rand(2, 3, 256, 256).astype(np.float32)
+    backward_sig("yolox_bwd", mx, xx, lambda o: list(o.values()))
+
+    # ---- utils/nms.py function level: gpu_nms with the pairwise IoU kinds, soft-NMS
+    rs = np.random.RandomState(1131)
+    c = rs.uniform(20, 180, (12, 2)); wh = rs.uniform(20, 70, (12, 2))
+    rows = []
+    for k in range(12):
+        for _ in range(10):
+            cc = c[k] + rs.uniform(-8, 8, 2); ww = wh[k] * rs.uniform(0.8, 1.25, 2)
+            rows.append(np.concatenate([cc - ww / 2, cc + ww / 2]))
+    nb = np.array(rows, np.float32)
+    ns = rs.uniform(0.05, 1.0, len(nb)).astype(np.float32); ns[::13] = 0.0
+    g["nms_boxes"], g["nms_scores"] = nb, ns
+    for kind in ("giou", "diou", "ciou"):
+        g[f"nms_keep_{kind}_0.3"] = np.array(ref_utils.gpu_nms(torch.from_numpy(nb), torch.from_numpy(ns), kind, 0.3))
+    sb, ss = nb[:40], ns[:40].reshape(-1, 1).copy()
+    g["soft_boxes"], g["soft_scores"] = sb, ss
+    for kind in ("giou", "diou", "ciou"):
+        g[f"soft_linear_{kind}"] = ref_utils.gpu_linear_soft_nms(torch.from_numpy(sb), torch.from_numpy(ss.copy()), kind, 0.3, 0.001).numpy()
+    eb, es = nb[:12], ns[:12].reshape(-1, 1).copy()
+    g["softexp_boxes"], g["softexp_scores"] = eb, es
+    g["soft_exp_giou"] = ref_utils.gpu_exponential_soft_nms(torch.from_numpy(eb), torch.from_numpy(es.copy()), "giou", 0.3, 0.5, 0.001).numpy()
+    np.savez_compressed(os.path.join(OUT, "g11_round2.npz"), **g)
+    print("g11 written", os.path.getsize(os.path.join(OUT, "g11_round2.npz")) / 1e6, "MB")
 
 
 def gen_g10(ref_utils):

@@ -141,4 +141,6 @@ def gpu_CIoU(bbox1, bbox2):
     """pairwise CIoU, differentiable w.r.t. bbox1 with alpha held constant
     (utils/bbox_tools.py:286-339); returns (N,) squeezed like the reference."""
     _need_gpu(bbox1, "gpu_CIoU")
+    if bbox1.shape[0] == 1 and bbox2.shape[0] > 1:          # the reference's expressions broadcast one box against many
+        bbox1 = bbox1.expand(bbox2.shape[0], 4)
     return _PairwiseCIoU.apply(bbox1, bbox2).squeeze()

@@ -14,7 +14,7 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ['get_rank', 'get_world_size', 'get_local_rank', 'get_num_devices', 'synchronize', 'is_main_process',
+__all__ = ['get_rank', 'get_world_size', 'get_local_rank', 'get_local_size', 'get_num_devices', 'synchronize', 'is_main_process',
            'all_reduce_norm', 'DataParallelGrads', 'allreduce_flat_mean']
 
 
@@ -30,8 +30,20 @@ def get_rank():
     return dist.get_rank() if _on() else 0
 
 
+_LOCAL_PROCESS_GROUP = None      # set by utils.launch for the ranks of one machine (utils/dist.py:32, utils/launch.py:121-128)
+
+
 def get_local_rank():
+    """rank inside this machine: the local process group when launch() made one, else torchrun's LOCAL_RANK"""
+    if _LOCAL_PROCESS_GROUP is not None and _on():
+        return dist.get_rank(group=_LOCAL_PROCESS_GROUP)
     return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def get_local_size():
+    if _LOCAL_PROCESS_GROUP is not None and _on():
+        return dist.get_world_size(group=_LOCAL_PROCESS_GROUP)
+    return int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
 
 
 def is_main_process():
@@ -107,7 +119,15 @@ class DataParallelGrads:
         if self._local_acc is not None:
             total = self._local_acc + flat_g
             allreduce_flat_mean(total, self.group, self.chunks)
-            torch.sub(total, self._local_acc, out=flat_g)
+            opt = getattr(getattr(self.model, "_yh_grad_hook_opt", None), "__self__", None)
+            if opt is not None and hasattr(opt, "replace_accumulated"):
+                # flat-arena optimizer: its accumulator (== _local_acc) is REPLACED by the averaged total, so every rank
+                # steps with bit-identical gradients (replicas stay identical, as under DDP)
+                flat_g.copy_(total)
+                opt.replace_accumulated()
+            else:
+                # autograd accumulates into p.grad: hand on  mean(total) - local sum  (equal up to one rounding)
+                torch.sub(total, self._local_acc, out=flat_g)
             self._local_acc = None
             return
         if not bucketed:

@@ -79,6 +79,11 @@ class FlatSGD:
             self._gacc = self._gacc + flat_g
         self._nacc += 1
 
+    def replace_accumulated(self):
+        """the data-parallel exchange averaged the ACCUMULATED gradient at an accumulation boundary and hands it over as
+        the next flat gradient: drop the local sum so that _on_grad() takes the average as is (utils/dist.py)"""
+        self._gacc, self._nacc = None, 0
+
     def _grad(self):
         g = self._gacc if self._gacc is not None else getattr(self.model, "_yh_last_flat_grad", None)
         if g is None:
