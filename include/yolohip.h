@@ -98,7 +98,8 @@ typedef struct yh_conv_desc {
     int32_t  grid_cap;
     int32_t  tile_k;      /* channels per k-step, 32 or 64 (64 needs every segment C % 64 == 0 and the 128-wide tile) */
     int32_t  algo;        /* kernel family: 0 library default, 1 register-staged (conv_v2_kernel), 2..4 LDS-DMA ring
-                           * (conv_v3_kernel) with a 256x128 / 128x128 / 128x64 tile when the shape is eligible      */
+                           * (conv_v3_kernel) with a 256x128 / 128x128 / 128x64 tile, 5 the 3x3 halo kernel (conv_halo_kernel), when the shape
+                           * is eligible                                                                              */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the ONLY writer of that gradient: out0 covers exactly the producer's N channels, no accumulate):
      * bnr_z = the producer's raw conv output (same pixel grid / channels as out0), bnr_ws = its scale | shift (stride bnr_C),

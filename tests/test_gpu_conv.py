@@ -164,6 +164,8 @@ def test_conv_wgrad_segment_upsampled(dev):
 V3_CASES = [
     # B, H, W, Cin, Cout, k, s, p
     (2, 40, 40, 128, 128, 3, 1, 1),
+    (3, 20, 20, 256, 256, 3, 1, 1),      # halo kernel: two n-tiles, 20-wide map (ragged 2-D tiles), 4 channel blocks
+    (1, 80, 48, 64, 128, 3, 1, 1),
     (1, 24, 24, 64, 256, 3, 2, 1),
     (2, 16, 16, 256, 128, 1, 1, 0),
     (2, 20, 20, 96, 160, 3, 1, 1),       # 32-channel k-steps (96 % 64 != 0), ragged N tile
@@ -180,7 +182,16 @@ def _kname(d):
     return buf.value.decode()
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3, 4])
+def _expect_family(d, algo):
+    """algo 2..4 must land on the LDS-DMA ring kernel; algo 5 on the halo kernel where the shape is eligible (else skip)"""
+    kn = _kname(d)
+    if algo in (2, 3, 4):
+        assert "conv_v3_kernel" in kn, kn
+    if algo == 5 and "conv_halo_kernel" not in kn:
+        pytest.skip("shape not eligible for the halo kernel")
+
+
+@pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", V3_CASES)
 def test_conv_fwd_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
     """plain store + BatchNorm partial sums (EPI 1) and the generic epilogue (bias, EPI 2) on every kernel family"""
@@ -197,8 +208,7 @@ def test_conv_fwd_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
         d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, Ho, Wo, H, W, k, s, p, wp, Cout, hipk.full(out),
                            bias=bias if with_bias else None)
         d.algo = algo
-        if algo >= 2:
-            assert "conv_v3_kernel" in _kname(d), _kname(d)
+        _expect_family(d, algo)
         stats = None
         if not with_bias:
             stats = torch.zeros(hipk.conv_stat_blocks(d), 2, wp.shape[0], device=dev)
@@ -216,7 +226,7 @@ def test_conv_fwd_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
             assert ((stats[:, 1, :Cout].double().sum(0) - (o ** 2).sum(0)).abs() <= tol2).all()
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3, 4])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [c for c in V3_CASES if c[3] > 32])
 def test_conv_dgrad_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
     """data gradient (stride-2 layers run as four parity classes), plain and accumulating, plus the fused
@@ -235,8 +245,7 @@ def test_conv_dgrad_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
     gx0 = gx.clone()
     d = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, Ho, Wo, k, s, p, wd, Cin, hipk.full(gx), accumulate=1)
     d.algo = algo
-    if algo >= 2:
-        assert "conv_v3_kernel" in _kname(d), _kname(d)
+    _expect_family(d, algo)
     hipk.conv_launch(d)
     torch.cuda.synchronize()
     _close(gx, ref.to(torch.bfloat16).float() + gx0.float(), 1e-2, 4e-2)

@@ -175,3 +175,195 @@ def test_train_step_loss_decreases(dev):
         a = m(x); b2 = m2(x)
     for u, v in zip(a, b2):
         assert torch.equal(u, v)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: YOLOv5 m / l / x (BASELINE configs #4, #5) and full-model backward against tests/golden/g11_round2.npz
+# (reference run by tools/gen_golden.py::gen_g11).
+#
+# Conditioning.  A TRAIN-mode pass through 100-170 BatchNorm+SiLU layers at random init amplifies bf16 storage rounding
+# strongly: the reference ITSELF under torch bf16 autocast is 2-18 % of the elements outside a 6 % band in the forward
+# (m / l / x, 256x256) and 35-45 % RMS off in every parameter gradient of the backward, for any output gradient, batch
+# or image size (measured when the fixture was made; even rounding only the forward tensors gives 30 %).  Element-wise
+# parity of the bf16 path is therefore pinned where it is well conditioned — blocks (test_block_golden), eval-mode
+# forwards (running statistics), shallow-to-mid running statistics — and the full-graph train-mode checks use the
+# reference's own bf16 deviation, stored in the fixture as `*_cal*`, as the bar: the HIP path must be no further from the
+# fp32 reference than that, and bit-consistent between its two backward schedules.
+
+def _dev_stats(a, b):
+    a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
+    lim = 0.06 * np.abs(b).max() + 0.06 * np.abs(b)
+    return float((np.abs(a - b) > lim).mean()), float(np.sqrt(((a - b) ** 2).mean()) / (np.sqrt((b ** 2).mean()) + 1e-30))
+
+
+def test_model_mlx_state_dict_and_init():
+    """CPU-side: same keys and bit-identical seeded init as the reference for the m / l / x variants"""
+    from yoloseries_amd import models
+    g = np.load(os.path.join(G, "g11_round2.npz"))
+    for name, cls in (("m", models.YOLOV5Middle), ("l", models.YOLOV5Large), ("x", models.YOLOV5XLarge)):
+        torch.manual_seed(0)
+        sd = cls(3, 80).state_dict()
+        assert list(sd.keys()) == list(g[f"{name}_keys"])
+        np.testing.assert_allclose([v.double().sum().item() for v in sd.values()], g[f"{name}_psum"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose([v.double().abs().sum().item() for v in sd.values()], g[f"{name}_pabs"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["m", "l", "x"])
+def test_model_mlx_forward_golden(dev, name):
+    """widths / depths of models/normal/yolov5{m,l,x}.py: eval forward at 64x64 (folded BN, RandomState-filled state) and
+    train forward at 256x256 (batch statistics, running-stat update, seeded default init)"""
+    from yoloseries_amd import models
+    g = np.load(os.path.join(G, "g11_round2.npz"))
+    cls = {"m": models.YOLOV5Middle, "l": models.YOLOV5Large, "x": models.YOLOV5XLarge}[name]
+    seed = int(g[f"{name}_seed"][0])
+    torch.manual_seed(0)
+    m = cls(3, 80).to(dev).train()
+    x2 = torch.from_numpy(np.random.RandomState(seed + 11).rand(2, 3, 256, 256).astype(np.float32)).to(dev)
+    outs = m(x2)
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == tuple(g[f"{name}_train256_shape{i}"])
+        flat = o.detach().float().contiguous().cpu().numpy().reshape(-1)
+        frac, rms = _dev_stats(flat[g[f"{name}_train256_idx{i}"]], g[f"{name}_train256_val{i}"])
+        cfrac, crms = g[f"{name}_train256_cal{i}"]
+        print(f"v5{name} train256 out{i}: outside the 6% band {frac:.4f} (reference under bf16 autocast {cfrac:.4f}), rel rms {rms:.4f} ({crms:.4f})")
+        assert frac <= 1.25 * cfrac + 0.01 and rms <= 1.25 * crms + 0.01, f"v5{name} train out{i}: {frac:.4f}/{rms:.4f} vs calibration {cfrac:.4f}/{crms:.4f}"
+    # running statistics after one training forward: shallow layers tight, deep ones with the calibrated slack
+    mods = dict(m.named_modules())
+    for pn, tol in (("focus", 2e-2), ("backbone_stage2_conv", 2e-2), ("backbone_stage4_conv", 3e-2), ("head_stage4_bscp.cba3", 6e-2)):
+        _close(mods[pn].bn.running_mean.cpu().numpy(), g[f"{name}_rm_{pn}"], tol, f"v5{name} {pn} running_mean", outlier_frac=0.01)
+        _close(mods[pn].bn.running_var.cpu().numpy(), g[f"{name}_rv_{pn}"], tol, f"v5{name} {pn} running_var", outlier_frac=0.01)
+    m2 = cls(3, 80)
+    assert len(m2.state_dict()) == len(g[f"{name}_keys"])
+    fill_state(m2, seed)
+    m2 = m2.to(dev).eval()
+    x = torch.from_numpy(np.random.RandomState(seed + 10).rand(2, 3, 64, 64).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        outs = m2(x)
+    for i, o in enumerate(outs):
+        ref = g[f"{name}_eval64_out{i}"]
+        assert tuple(o.shape) == ref.shape
+        _close(o.float().cpu().numpy(), ref, 3e-2, f"v5{name} eval out{i}", outlier_frac=0.002)
+
+
+def _backward_check(dev, key, make, x_np, outs_of):
+    """gradients of every parameter and of the input from a fixed output gradient, under both backward schedules
+    (weight gradients on the side stream / everything on one stream)"""
+    g = np.load(os.path.join(G, "g11_round2.npz"))
+    torch.manual_seed(0)
+    model = make().to(dev).train()
+    names = [n for n, _ in model.named_parameters()]
+    assert names == list(g[f"{key}_pnames"])
+    sig, samp, cal = g[f"{key}_psig"], g[f"{key}_psamp"], g[f"{key}_pcal"]
+    results = {}
+    for streams in (1, 0):
+        # the image gradient is not produced on the HIP path (training never uses it: the stem has no data gradient,
+        # DESIGN.md section 3), so only the parameter gradients are compared
+        xt = torch.from_numpy(x_np.copy()).to(dev)
+        outs = outs_of(model(xt))
+        for prog in model._yh_state()['progs'].values():
+            if prog.bwd_ready:
+                prog.two_streams = bool(streams)
+        r = np.random.RandomState(1200 + len(key))
+        gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)).to(dev) for o in outs]
+        for i, go in enumerate(gos):
+            assert tuple(go.shape) == tuple(g[f"{key}_gout_shape{i}"])
+        grads = torch.autograd.grad(outs, list(model.parameters()), gos)
+        prog = next(iter(model._yh_state()['progs'].values()))
+        assert prog.bwd_ready and prog.two_streams == bool(streams)
+        torch.cuda.synchronize()
+        results[streams] = [gr.detach().double().cpu().numpy().reshape(-1) for gr in grads]
+    # (a) the two schedules compute the same thing: identical up to the fp32 atomics of the weight-gradient reduction
+    for a, b2 in zip(results[1], results[0]):
+        assert np.abs(a - b2).max() <= 2e-3 * (np.abs(a).max() + 1e-30)
+    # (b) against the fp32 reference, with the reference's own bf16 deviation as the bar (see the note above)
+    gr = [None] + results[1]
+    dev_norm, dev_samp, corr = [], [], []
+    for pi, n in enumerate(names):
+        gf = gr[1 + pi]
+        rsum, rabs, rnorm, numel = sig[pi]
+        assert gf.size == int(numel), n
+        si = np.random.RandomState(1400 + pi).randint(0, gf.size, 64)
+        dn = abs(float(np.sqrt((gf ** 2).sum())) - rnorm) / (rnorm + 1e-30)
+        ds = float(np.sqrt(((gf[si] - samp[pi]) ** 2).mean()) / (np.sqrt((samp[pi] ** 2).mean()) + 1e-30))
+        dev_norm.append(dn); dev_samp.append(ds)
+        if gf.size >= 64 and np.std(samp[pi]) > 0:
+            corr.append(float(np.corrcoef(gf[si], samp[pi])[0, 1]))
+        assert np.isfinite(gf).all(), n
+        # no parameter is grossly wrong (a dropped / doubled contribution shows as O(1) here)
+        assert dn <= max(3.0 * cal[pi, 0], 0.0) + 0.25, f"{key} grad-norm {n}: {dn:.3f} (calibration {cal[pi, 0]:.3f})"
+        assert ds <= 1.5 * cal[pi, 1] + 0.15, f"{key} grad samples {n}: rel rms {ds:.3f} (calibration {cal[pi, 1]:.3f})"
+    dev_norm, dev_samp = np.array(dev_norm), np.array(dev_samp)
+    print(f"{key}: per-parameter |norm| deviation median {np.median(dev_norm):.4f} (cal {np.median(cal[:, 0]):.4f}), sampled rel rms median "
+          f"{np.median(dev_samp):.3f} (cal {np.median(cal[:, 1]):.3f}), sample correlation median {np.median(corr):.3f}")
+    assert np.median(dev_norm) <= 1.25 * np.median(cal[:, 0]) + 0.01
+    assert np.median(dev_samp) <= 1.1 * np.median(cal[:, 1]) + 0.02
+    assert np.median(corr) >= 0.85
+
+
+def test_v5s_full_backward_golden(dev):
+    from yoloseries_amd import models
+    x = np.random.RandomState(1112).rand(2, 3, 256, 256).astype(np.float32)
+    _backward_check(dev, "v5s_bwd", lambda: models.YOLOV5Small(3, 80), x, lambda o: list(o))
+
+
+def test_yolox_full_backward_golden(dev):
+    from yoloseries_amd import models
+    x = np.random.RandomState(1122).rand(2, 3, 256, 256).astype(np.float32)
+    _backward_check(dev, "yolox_bwd", lambda: models.YOLOXSmall(1, 3, 80, 0.01), x, lambda o: list(o.values()))
+
+
+def test_v5x_1280_eval_through_evaluator(dev):
+    """BASELINE config #5 shape at batch 1: YOLOV5XLarge eval forward at 1280x1280 -> decode -> filter -> class-aware NMS
+    through YOLOV5Evaluator, against the CPU oracle (V5NetOracle fp32 forward, oracle decode) and, on the device-decoded
+    tensor, bit-exact post-processing against oracle.postproc.postprocess_v5"""
+    from oracle import postproc as opp
+    from oracle.v5net import V5NetOracle
+    from yoloseries_amd import models
+    from yoloseries_amd.trainer import YOLOV5Evaluator
+    from yoloseries_amd.utils.synth import COCO_ANCHORS
+    m = models.YOLOV5XLarge(3, 80)
+    fill_state(m, 1151)
+    # detect biases as the reference initialises them (objectness prior, models/normal/yolov5s.py:47-85), so that only a
+    # small share of the 100 800 anchors passes the confidence threshold
+    with torch.no_grad():
+        for det, s in ((m.detect.detect_small, 8), (m.detect.detect_mid, 16), (m.detect.detect_large, 32)):
+            b = det.bias.view(3, -1)
+            b[:, 4] = -2.0
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(dev).eval()
+    x = torch.from_numpy(np.random.RandomState(1152).rand(1, 3, 1280, 1280).astype(np.float32))
+    hyp = dict(device=dev, num_class=80, input_img_size=[1280, 1280], iou_threshold=0.2, conf_threshold=0.3, cls_threshold=0.3,
+               max_predictions_per_img=300, iou_type="iou", mutil_label=False, agnostic=True, postprocess_bbox=True, wfb=False,
+               use_tta=False, half=False, compute_metric_conf_threshold=0.001, compute_metric_iou_threshold=0.65,
+               compute_metric_cls_threshold=0.001)
+    ev = YOLOV5Evaluator(m, torch.from_numpy(COCO_ANCHORS).to(dev), hyp)
+    with torch.no_grad():
+        heads = m(x.to(dev))
+    assert [tuple(h.shape) for h in heads] == [(1, 255, 160, 160), (1, 255, 80, 80), (1, 255, 40, 40)]
+    dec = ev.decode(heads)
+    assert tuple(dec.shape) == (1, 100800, 85)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    with torch.no_grad():
+        oheads = V5NetOracle(sd, train=False)(x)
+    odec = opp.decode_v5([h.numpy() for h in oheads], COCO_ANCHORS, [8, 16, 32])
+    got = dec.cpu().numpy()
+    # head logits: bf16 conv chain (~100 layers) against fp32; decoded boxes / probabilities follow
+    for i, (h, oh) in enumerate(zip(heads, oheads)):
+        _close(h.float().cpu().numpy(), oh.numpy(), 5e-2, f"v5x 1280 head {i}", outlier_frac=0.01)
+    err = np.abs(got[..., 4:] - odec[..., 4:])
+    assert (err > 0.05).mean() < 0.01, f"decoded probabilities: {(err > 0.05).mean():.4f} of the entries differ by more than 0.05"
+    # post-processing on identical (device-decoded) input: bit exact, through both entry points
+    # thresholds placed on this random net's score distribution so that a few thousand of the 100 800 anchors become candidates
+    obj = np.sort(got[0, :, 4])[::-1]
+    conf_thr = float(obj[4000])
+    cls_thr = 0.25 * conf_thr
+    ev.conf_threshold, ev.cls_threshold = conf_thr, cls_thr
+    res_nms = ev.numba_nms(dec)
+    res_fused = ev._nms_from_heads(heads)
+    ref = opp.postprocess_v5(got, conf_thr, cls_thr, 0.2)
+    assert ref[0] is not None and len(ref[0]) > 0, "test input produced no detections"
+    for a in (res_nms[0], res_fused[0]):
+        np.testing.assert_array_equal(a, ref[0])
+    assert ev.last_ncand[0] >= 1000
+    out = ev(x.to(dev))
+    np.testing.assert_array_equal(out[0].numpy(), ref[0])

@@ -494,67 +494,99 @@ def gen_g11(ref_utils, ref_models):
     a fixed output gradient), and the function-level NMS variants of utils/nms.py (gpu_nms with giou/diou/ciou, soft-NMS)."""
     import torch
     g = {}
-    # ---- models: eval forward at 64^2, train forward at 128^2, seeded state
+    # ---- models: eval forward at 64^2 on a RandomState-filled state (running statistics: well conditioned), train forward
+    # at 256^2 on the seeded default init.  A train-mode forward through 100-170 BatchNorm layers with 128 samples per
+    # channel in the deepest stage amplifies bf16 rounding chaotically — the reference ITSELF under torch bf16 autocast
+    # deviates from its fp32 run by 2-18 % of the elements outside a 6 % band for these depths — so the fixture also stores
+    # that deviation (`*_cal_*`): the parity bar for the bf16 HIP path is "no further from the fp32 reference than the
+    # reference's own bf16 run" (tests/test_gpu_model.py).
+    def dev_stats(a, b):
+        a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
+        lim = 0.06 * np.abs(b).max() + 0.06 * np.abs(b)
+        return np.array([(np.abs(a - b) > lim).mean(), np.sqrt(((a - b) ** 2).mean()) / (np.sqrt((b ** 2).mean()) + 1e-30)])
+    bn_probes = ["focus", "backbone_stage2_conv", "backbone_stage4_conv", "head_stage4_bscp.cba3"]
     for name, cls, seed in (("m", ref_models.YOLOV5Middle, 1101), ("l", ref_models.YOLOV5Large, 1102), ("x", ref_models.YOLOV5XLarge, 1103)):
         torch.manual_seed(0)
         m = cls(3, 80)
+        sd = m.state_dict()
+        g[f"{name}_keys"] = np.array(list(sd.keys()))
+        g[f"{name}_psum"] = np.array([v.double().sum().item() for v in sd.values()])
+        g[f"{name}_pabs"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+        x2 = torch.from_numpy(np.random.RandomState(seed + 11).rand(2, 3, 256, 256).astype(np.float32))
+        m.train()
+        with torch.no_grad():
+            outs = m(x2)
+        probes = {pn: (dict(m.named_modules())[pn].bn.running_mean.numpy().copy(), dict(m.named_modules())[pn].bn.running_var.numpy().copy())
+                  for pn in bn_probes}
+        torch.manual_seed(0)
+        m2 = cls(3, 80).train()
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            outs_lo = [o.float() for o in m2(x2)]
+        for i, o in enumerate(outs):
+            flat = o.numpy().reshape(-1)
+            idx = np.random.RandomState(seed + 20 + i).randint(0, flat.size, 8192)
+            g[f"{name}_train256_idx{i}"] = idx.astype(np.int64)
+            g[f"{name}_train256_val{i}"] = flat[idx]
+            g[f"{name}_train256_shape{i}"] = np.array(o.shape)
+            g[f"{name}_train256_cal{i}"] = dev_stats(outs_lo[i].numpy().reshape(-1)[idx], flat[idx])
+        for pn, (rm, rv) in probes.items():
+            g[f"{name}_rm_{pn}"], g[f"{name}_rv_{pn}"] = rm, rv
+            bn2 = dict(m2.named_modules())[pn].bn
+            g[f"{name}_rvcal_{pn}"] = dev_stats(bn2.running_var.numpy(), rv)
+        del m2
         fill_state_rs(m, seed)
         g[f"{name}_seed"] = np.array([seed])
-        g[f"{name}_nkeys"] = np.array([len(m.state_dict())])
         x = torch.from_numpy(np.random.RandomState(seed + 10).rand(2, 3, 64, 64).astype(np.float32))
         m.eval()
         with torch.no_grad():
             outs = m(x)
         for i, o in enumerate(outs):
-            g[f"{name}_eval64_out{i}"] = o.numpy().astype(np.float16) if False else o.numpy()
-        m.train()
-        x2 = torch.from_numpy(np.random.RandomState(seed + 11).rand(2, 3, 128, 128).astype(np.float32))
-        outs = m(x2)
-        for i, o in enumerate(outs):
-            flat = o.detach().numpy().reshape(-1)
-            idx = np.random.RandomState(seed + 20 + i).randint(0, flat.size, 4096)
-            g[f"{name}_train128_idx{i}"] = idx.astype(np.int64)
-            g[f"{name}_train128_val{i}"] = flat[idx]
-            g[f"{name}_train128_shape{i}"] = np.array(o.shape)
-        g[f"{name}_train128_rv_last"] = m.head_stage4_bscp.cba3.bn.running_var.numpy().copy()
+            g[f"{name}_eval64_out{i}"] = o.numpy()
         del m
 
-    # ---- full-model backward: per-parameter gradient signatures + input gradient
-    def backward_sig(key, m, x, outs_of):
-        m.train()
-        xt = torch.from_numpy(x.copy()).requires_grad_(True)
-        outs = outs_of(m(xt))
-        r = np.random.RandomState(1200 + len(key))
-        gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)) for o in outs]
-        for i, go in enumerate(gos):
-            g[f"{key}_gout_shape{i}"] = np.array(go.shape)
-        params = list(m.parameters())
-        grads = torch.autograd.grad(outs, [xt] + params, gos)
-        gx = grads[0].numpy().reshape(-1)
+    # ---- full-model backward (seeded default init, 256^2): per-parameter gradient signatures + sampled input gradient, with the
+    # deviation of the reference's own bf16-autocast backward as calibration
+    def backward_sig(key, make, x, outs_of):
+        def run(lowp):
+            torch.manual_seed(0)
+            m = make().train()
+            xt = torch.from_numpy(x.copy()).requires_grad_(True)
+            if lowp:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    outs = [o.float() for o in outs_of(m(xt))]
+            else:
+                outs = outs_of(m(xt))
+            r = np.random.RandomState(1200 + len(key))
+            gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)) for o in outs]
+            grads = torch.autograd.grad(outs, [xt] + list(m.parameters()), gos)
+            return m, [o.shape for o in outs], [gr.detach().double().numpy().reshape(-1) for gr in grads]
+        m, shapes, gr = run(False)
+        _, _, gr_lo = run(True)
+        for i, sh in enumerate(shapes):
+            g[f"{key}_gout_shape{i}"] = np.array(sh)
+        gx = gr[0]
         idx = np.random.RandomState(1300).randint(0, gx.size, 8192)
         g[f"{key}_gx_idx"] = idx.astype(np.int64)
         g[f"{key}_gx_val"] = gx[idx]
-        g[f"{key}_gx_sig"] = np.array([gx.astype(np.float64).sum(), np.abs(gx.astype(np.float64)).sum(), np.sqrt((gx.astype(np.float64) ** 2).sum())])
-        names, sig, samp = [], [], []
-        for (n, p), gr in zip(m.named_parameters(), grads[1:]):
-            gf = gr.double().reshape(-1)
+        g[f"{key}_gx_norm"] = np.array([np.sqrt((gx ** 2).sum())])
+        g[f"{key}_gx_cal"] = dev_stats(gr_lo[0][idx], gx[idx])
+        names, sig, samp, cal = [], [], [], []
+        for pi, ((n, p), gf, gl) in enumerate(zip(m.named_parameters(), gr[1:], gr_lo[1:])):
             names.append(n)
-            sig.append([gf.sum().item(), gf.abs().sum().item(), gf.norm().item(), float(gf.numel())])
-            si = np.random.RandomState(1400 + len(names)).randint(0, gf.numel(), 16)
-            samp.append(gf.numpy()[si])
+            sig.append([gf.sum(), np.abs(gf).sum(), np.sqrt((gf ** 2).sum()), float(gf.size)])
+            si = np.random.RandomState(1400 + pi).randint(0, gf.size, 64)
+            samp.append(gf[si])
+            nr = np.sqrt((gf ** 2).sum()) + 1e-30
+            cal.append([abs(np.sqrt((gl ** 2).sum()) - nr) / nr, np.sqrt(((gl[si] - gf[si]) ** 2).mean()) / (np.sqrt((gf[si] ** 2).mean()) + 1e-30),
+                        np.sqrt(((gl - gf) ** 2).sum()) / nr])
         g[f"{key}_pnames"] = np.array(names)
         g[f"{key}_psig"] = np.array(sig)
         g[f"{key}_psamp"] = np.array(samp)
-    torch.manual_seed(0)
-    ms = ref_models.YOLOV5Small(3, 80)
-    fill_state_rs(ms, 1111)
+        g[f"{key}_pcal"] = np.array(cal)
     xs = np.random.RandomState(1112).rand(2, 3, 256, 256).astype(np.float32)
-    backward_sig("v5s_bwd", ms, xs, lambda o: list(o))
-    torch.manual_seed(0)
-    mx = ref_models.YOLOXSmall(1, 3, 80, 0.01)
-    fill_state_rs(mx, 1121)
+    backward_sig("v5s_bwd", lambda: ref_models.YOLOV5Small(3, 80), xs, lambda o: list(o))
     xx = np.random.RandomState(1122).rand(2, 3, 256, 256).astype(np.float32)
-    backward_sig("yolox_bwd", mx, xx, lambda o: list(o.values()))
+    backward_sig("yolox_bwd", lambda: ref_models.YOLOXSmall(1, 3, 80, 0.01), xx, lambda o: list(o.values()))
 
     # ---- utils/nms.py function level: gpu_nms with the pairwise IoU kinds, soft-NMS
     rs = np.random.RandomState(1131)

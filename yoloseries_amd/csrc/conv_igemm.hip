@@ -1152,6 +1152,400 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// halo kernel: 3x3 / stride 1 / pad 1 convolutions (forward and data gradient) without the im2col redundancy on the
+// global -> LDS path.  The CU's intake (LDS-DMA through the texture path, ~35-45 B/clk in practice) is what bounds the
+// tiles of conv_v3: a 256 x 128 tile needs 48 KB per 64-channel k-step.  Here a block owns a 2-D tile of TH x TW output
+// pixels (TH*TW <= 256) of ONE image and stages, per 64-channel block, the (TH+2) x (TW+2) input patch ONCE; the nine taps
+// are nine k-steps that read their A fragments from the same patch at a shifted pixel (patch row + dy*(TW+2) + dx), so only
+// the weight tile (16 KB) is streamed per k-step: ~22 KB per k-step instead of 48.  Patch rows are 128 bytes, chunk-swizzled
+// by the patch row index on the source side of the DMA (as in conv_v3); the patch of the next channel block is prefetched
+// in six parts behind the taps 0..5 of the current one; weight tiles go through a 3-stage ring.  MFMA rows that are not an
+// output pixel of the tile (ragged tiles) read a zero line, so their accumulators are exact zeros for the statistics.
+struct HaloGeom { int TH, TW, PW, NP, tiles_x, tiles_y; };
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const HaloGeom hg)
+{
+    constexpr int BMT = 256, WM = 4, WN = 2, BKT = 64, STG = 3;
+    constexpr int NWV = WM * WN, NT = NWV * 64;
+    constexpr int TM = 2, TN = BN / (WN * 32);
+    constexpr int ROWB = BKT * 2, CHR = 8, RPI = 8;
+    constexpr int NB = BN / (RPI * NWV);             // weight-tile DMA instructions per wave and k-step (2 | 1)
+    constexpr int NPW = 6;                           // patch DMA instructions per wave and channel block (<= 6*8*8 = 384 patch rows)
+    constexpr int PATCH_ROWS = 352;                  // >= NP*8, see conv_halo_geom
+    constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;   // 45056
+    constexpr int BST_BYTES = BN * ROWB;
+    constexpr int ZERO_OFF = 2 * PATCH_BYTES + STG * BST_BYTES;       // 128 zero bytes
+    constexpr int CP = BN + 8;
+    constexpr int RING_BYTES = ZERO_OFF + 128;
+    constexpr int MAIN_BYTES = RING_BYTES > (BMT * CP * 2) ? RING_BYTES : (BMT * CP * 2);
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* sC = reinterpret_cast<uint16_t*>(smem);
+    float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    int* sPix = reinterpret_cast<int*>(smem + MAIN_BYTES + WM * 2 * BN * 4);
+
+    const yh_conv_desc& d = p.d;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.y * BN;
+    const int ncb = p.Ctot / BKT;
+    const int nkt = 9 * ncb;
+    const int H = d.Ho, W = d.Wo;                    // stride 1, pad 1: input grid == output grid
+    const int TH = hg.TH, TW = hg.TW, PW = hg.PW, NP = hg.NP;
+    const int tiles_per_img = hg.tiles_x * hg.tiles_y;
+    const int ntiles = d.B * tiles_per_img;
+    const int ldx2 = d.seg[0].ld * 2;
+    const bool dgrad = d.mode == YH_CONV_DGRAD;
+#if YH_CONV_ABLATE & 1
+    const bool mtile_never = d.B < 0;               // timing build: DMA issue compiled in but never taken
+#endif
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg[0].ptr, 0, p.segbytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, p.wbytes, 0x00020000);
+
+    const int lrow = lane >> 3, lq = lane & 7;
+    unsigned voffB[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = (j * NWV + wave) * RPI + lrow;
+        voffB[j] = (unsigned)(((n0 + row) * p.Ktot + ((lq ^ swz_f<CHR>(row)) * 8)) * 2);
+    }
+    const int rdB0 = 2 * PATCH_BYTES + (wn * (TN * 32) + (lane & 31)) * ROWB;
+    const int fxB = swz_f<CHR>(lane & 31);
+    const int hsel = lane >> 5;
+
+    if (t < 32) reinterpret_cast<unsigned*>(smem + ZERO_OFF)[t] = 0u;
+
+    float run_s = 0.f, run_q = 0.f;
+    float bs_[8], bq_[8];
+    if (EPI == 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bs_[e] = 0.f; bq_[e] = 0.f; }
+        for (int i = t; i < 2 * BN; i += NT) {
+            const int which = i / BN, c = i - which * BN;
+            sStat[i] = (n0 + c < d.N) ? d.bnr_ws[(size_t)which * d.bnr_C + n0 + c] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / tiles_per_img;
+        const int trem = tile - img * tiles_per_img;
+        const int tyi = trem / hg.tiles_x;
+        const int y0 = tyi * TH, x0 = (trem - tyi * hg.tiles_x) * TW;
+
+        // patch loader: instruction i of this wave fills patch rows (i*8 + wave)*8 .. +8
+        unsigned voffP[NPW];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int pr = (i * NWV + wave) * RPI + lrow;
+            const int py = pr / PW, px = pr - py * PW;
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            const bool ok = pr < (TH + 2) * PW && y >= 0 && y < H && x >= 0 && x < W;
+            voffP[i] = ok ? (unsigned)((img * H + y) * W + x) * (unsigned)ldx2 + (unsigned)((lq ^ swz_f<CHR>(pr)) * 16) : OOB;
+        }
+        // fragment rows of this lane: MFMA row -> tile pixel -> patch row of the tile's centre tap position (dy = dx = 0)
+        int pr0[TM];
+        bool inv[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * (TM * 32) + i * 32 + (lane & 31);
+            const int ty = r / TW, tx = r - ty * TW;
+            inv[i] = !(ty < TH && y0 + ty < H && x0 + tx < W);
+            pr0[i] = ty * PW + tx;
+        }
+        for (int r = t; r < BMT; r += NT) {
+            const int ty = r / TW, tx = r - ty * TW;
+            sPix[r] = (ty < TH && y0 + ty < H && x0 + tx < W) ? ((img * H + y0 + ty) * W + x0 + tx) : -1;
+        }
+
+        f32x16_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        auto issue_patch_part = [&](int part, int cblk, int pbuf) {          // one instruction of this wave (part = 0..NPW-1)
+            const int inst = part * NWV + wave;
+            if (inst < NP) {
+                unsigned char* dst = smem + pbuf * PATCH_BYTES + inst * (RPI * ROWB);
+#pragma unroll
+                for (int i = 0; i < NPW; ++i)
+                    if (i == part) lds_dma16(rs0, dst, voffP[i], cblk * (BKT * 2));
+            }
+        };
+        auto issue_B = [&](int kt2, int slot) {
+            const int cblk = kt2 / 9, tap = kt2 - cblk * 9;
+            const int sw = (tap * p.Ctot + cblk * BKT) * 2;
+            unsigned char* sb = smem + 2 * PATCH_BYTES + slot * BST_BYTES + wave * (RPI * ROWB);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) lds_dma16(rsw, sb + j * (NWV * RPI * ROWB), voffB[j], sw);
+        };
+        // DMA instructions of this wave in the group issued at step kt (weights of step kt+2, patch part of the next block)
+        auto group_size = [&](int kt2) -> int {
+            const int cblk = kt2 / 9, tap = kt2 - cblk * 9;
+            int n = (kt2 + STG - 1 < nkt) ? NB : 0;
+            if (tap < NPW && cblk + 1 < ncb && tap * NWV + wave < NP) n += 1;
+            return n;
+        };
+
+        // prologue: whole patch of channel block 0, weight tiles of steps 0 and 1
+#pragma unroll
+        for (int part = 0; part < NPW; ++part) issue_patch_part(part, 0, 0);
+        issue_B(0, 0);
+        if (1 < nkt) issue_B(1, 1);
+        int slot = 0, islot = STG - 1;
+        int cblk = 0, tap = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            // everything older than the youngest group (the one issued at step kt-1; at kt == 0 the weights of step 1) must have landed
+            const int young = kt == 0 ? ((1 < nkt) ? NB : 0) : group_size(kt - 1);
+#if YH_CONV_ABLATE & 1
+            YH_VMCNT(0);
+#else
+            if (young == 0) YH_VMCNT(0);
+            else if (young == 1) YH_VMCNT(1);
+            else if (young == 2) YH_VMCNT(2);
+            else YH_VMCNT(3);
+#endif
+#if !(YH_CONV_ABLATE & 256)
+            __builtin_amdgcn_s_barrier();
+#endif
+#if YH_CONV_ABLATE & 1
+            if (kt + STG - 1 < nkt && mtile_never) issue_B(kt + STG - 1, islot);
+            if (tap < NPW && cblk + 1 < ncb && mtile_never) issue_patch_part(tap, cblk + 1, (cblk + 1) & 1);
+#else
+            if (kt + STG - 1 < nkt) issue_B(kt + STG - 1, islot);
+            if (tap < NPW && cblk + 1 < ncb) issue_patch_part(tap, cblk + 1, (cblk + 1) & 1);
+#endif
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int dy = dgrad ? 2 - kh : kh, dx = dgrad ? 2 - kw : kw;
+            const int tapoff = dy * PW + dx;                                   // scalar
+            const unsigned char* pbase = smem + (cblk & 1) * PATCH_BYTES;
+            const unsigned char* bbase = smem + slot * BST_BYTES;
+            int arow[TM], afx[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int pr = pr0[i] + tapoff;
+                arow[i] = pr * ROWB;
+                afx[i] = swz_f<CHR>(pr);
+            }
+#pragma unroll
+            for (int ks = 0; ks < BKT / 16; ++ks) {
+                bf16x8_t af[TM], bfr[TN];
+                const int kc = ks * 2 + hsel;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned char* ap = inv[i] ? (smem + ZERO_OFF + hsel * 16) : (pbase + arow[i] + ((kc ^ afx[i]) << 4));
+#if YH_CONV_ABLATE & 64
+                    { uint4 fake = make_uint4((unsigned)(size_t)ap, kc, i, 0x3f803f80u); af[i] = __builtin_bit_cast(bf16x8_t, fake); }
+#else
+                    af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ap));
+#endif
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#if YH_CONV_ABLATE & 64
+                    { uint4 fake = make_uint4((unsigned)(size_t)bbase, kc, j, 0x3f803f80u); bfr[j] = __builtin_bit_cast(bf16x8_t, fake); }
+#else
+                    bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bbase + rdB0 + j * (32 * ROWB) + ((kc ^ fxB) << 4)));
+#endif
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#if YH_CONV_ABLATE & 4
+                        acc[i][j][0] += (float)af[i][0] * (float)bfr[j][0];
+#else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#endif
+            }
+            slot = slot + 1 == STG ? 0 : slot + 1;
+            islot = islot + 1 == STG ? 0 : islot + 1;
+            if (++tap == 9) { tap = 0; ++cblk; }
+        }
+        __syncthreads();                           // nothing in flight; patch / ring -> epilogue buffer
+
+        // ---- epilogue (as conv_v3, output rows through the tile's pixel table)
+        constexpr int CPRz = BN / 8;
+        constexpr int NCHz = BMT * CPRz / NT;
+        uint4 zpre[EPI == 3 ? NCHz : 1];
+        if (EPI == 3) {
+#pragma unroll
+            for (int i = 0; i < NCHz; ++i) {
+                const int id = t + i * NT;
+                const int row = id / CPRz;
+                const int n = n0 + (id - row * CPRz) * 8;
+                const int orow = sPix[row];
+                zpre[i] = make_uint4(0, 0, 0, 0);
+                if (orow >= 0 && n < d.N) zpre[i] = *reinterpret_cast<const uint4*>(d.bnr_z + (size_t)orow * d.bnr_ldz + n);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = wn * (TN * 32) + j * 32 + (lane & 31);
+            float bs = 0.f, scl = 1.f, sft = 0.f;
+            if (EPI == 2) {
+                const int n = n0 + c;
+                const bool nv = n < d.N;
+                bs = (d.bias && nv) ? d.bias[n] : 0.f;
+                scl = (d.scale && nv) ? d.scale[n] : 1.f;
+                sft = (d.shift && nv) ? d.shift[n] : 0.f;
+            }
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                uint16_t* dst = sC + (wm * (TM * 32) + i * 32 + 4 * (lane >> 5)) * CP + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (EPI == 2) {
+                        v = (v + bs) * scl + sft;
+                        if (d.act == YH_ACT_SILU) v = silu_fast(v);
+                    }
+                    dst[((r & 3) + 8 * (r >> 2)) * CP] = f2bf(v);
+                    if (EPI == 1) { s += v; q += v * v; }      // rows outside the tile and padded channels are exact zeros
+                }
+            }
+            if (EPI == 1) {
+                s += __shfl_xor(s, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                if (lane < 32) {
+                    sStat[(wm * 2 + 0) * BN + c] = s;
+                    sStat[(wm * 2 + 1) * BN + c] = q;
+                }
+            }
+        }
+        __syncthreads();
+
+        constexpr int CPR = BN / 8;
+        constexpr int NCH = BMT * CPR / NT;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = t + i * NT;
+            const int row = id / CPR;
+            const int cch = id - row * CPR;
+            const int n = n0 + cch * 8;
+            const int orow_i = sPix[row];
+            if (orow_i >= 0 && n < d.N) {
+                const size_t orow = (size_t)orow_i;
+                uint4 v = *reinterpret_cast<const uint4*>(sC + row * CP + cch * 8);
+                if (EPI == 2) {
+                    uint16_t* dst;
+                    const bool first = n < d.nsplit;
+                    if (first) dst = d.out0 + orow * d.ld0 + n;
+                    else       dst = d.out1 + orow * d.ld1 + (n - d.nsplit);
+                    const bool addres = (d.res != nullptr) && first;
+                    if (addres || d.accumulate) {
+                        float f[8];
+                        unpack8(v, f);
+                        if (addres) {
+                            uint4 rv = *reinterpret_cast<const uint4*>(d.res + orow * d.ldr + n);
+                            float g[8]; unpack8(rv, g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        }
+                        if (d.accumulate) {
+                            uint4 ov = *reinterpret_cast<const uint4*>(dst);
+                            float g[8]; unpack8(ov, g);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        }
+                        v = pack8(f);
+                    }
+                    *reinterpret_cast<uint4*>(dst) = v;
+                } else {
+                    *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
+                    if (EPI == 3) {
+                        const uint4 zv = zpre[i];
+                        float g[8], z[8];
+                        unpack8(v, g);
+                        unpack8(zv, z);
+                        const float4 s0 = *reinterpret_cast<const float4*>(sStat + cch * 8);
+                        const float4 s1 = *reinterpret_cast<const float4*>(sStat + cch * 8 + 4);
+                        const float4 h0 = *reinterpret_cast<const float4*>(sStat + BN + cch * 8);
+                        const float4 h1 = *reinterpret_cast<const float4*>(sStat + BN + cch * 8 + 4);
+                        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float a = z[e] * sc[e] + sh[e];
+                            const float sg = sigmoid_fast(a);
+                            const float dz = g[e] * (sg * (1.f + a * (1.f - sg)));
+                            bs_[e] += dz; bq_[e] += dz * z[e];
+                        }
+                    }
+                }
+            }
+        }
+        if (EPI == 1 && t < BN) {
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                run_s += sStat[(w * 2 + 0) * BN + t];
+                run_q += sStat[(w * 2 + 1) * BN + t];
+            }
+        }
+        __syncthreads();
+        if (t < 32) reinterpret_cast<unsigned*>(smem + ZERO_OFF)[t] = 0u;      // the epilogue buffer may have covered the zero line
+    }
+
+    if (EPI == 1 && t < BN) {
+        d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
+        d.stats[((size_t)blockIdx.x * 2 + 1) * d.Npad + n0 + t] = run_q;
+    }
+    if (EPI == 3) {
+        constexpr int CPR2 = BN / 8;
+        float* sRed = reinterpret_cast<float*>(smem);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sRed[t * 16 + e] = bs_[e]; sRed[t * 16 + 8 + e] = bq_[e]; }
+        __syncthreads();
+        for (int i = t; i < 2 * BN; i += NT) {
+            const int which = i / BN, c = i - which * BN;
+            float v = 0.f;
+            for (int j = c / 8; j < NT; j += CPR2) v += sRed[j * 16 + which * 8 + (c & 7)];
+            if (n0 + c < d.N) d.bnr_part[((size_t)blockIdx.x * 2 + which) * d.N + n0 + c] = v;
+        }
+    }
+}
+
+template <int BN>
+constexpr size_t conv_halo_smem_bytes() {
+    size_t a = 2 * 352 * 128 + 3 * (size_t)BN * 128 + 128;
+    size_t c = (size_t)256 * (BN + 8) * 2;
+    return (a > c ? a : c) + 4 * 2 * BN * 4 + 256 * 4;
+}
+
+// tile geometry of the halo kernel for an H x W map: TH x TW output pixels (<= 256) whose (TH+2) x (TW+2) patch fits 352 rows,
+// chosen to waste the fewest MFMA rows (ragged tiles and TH*TW < 256)
+bool conv_halo_geom(int H, int W, HaloGeom* g)
+{
+    double best = 0.0;
+    bool found = false;
+    for (int tw = 4; tw <= 64; ++tw) {
+        if (tw > W + 3) break;
+        const int th = 256 / tw;
+        if (th < 1) continue;
+        for (int th2 = th; th2 >= (th > 2 ? th - 2 : 1); --th2) {
+            const int pw = tw + 2, ph = th2 + 2;
+            if (pw * ph > 352) continue;
+            const int tx = (W + tw - 1) / tw, ty = (H + th2 - 1) / th2;
+            const double eff = (double)H * W / ((double)tx * ty * 256.0);
+            if (eff > best + 1e-9) {
+                best = eff; found = true;
+                g->TH = th2; g->TW = tw; g->PW = pw; g->NP = (pw * ph + 7) / 8; g->tiles_x = tx; g->tiles_y = ty;
+            }
+        }
+    }
+    return found && best >= 0.6;
+}
+
 template <int BMT, int BN, int WM, int BKT, int STG>
 constexpr size_t conv3_smem_bytes() {
     size_t a = (size_t)STG * (BMT + BN) * BKT * 2;
@@ -1359,7 +1753,7 @@ int pick_bkt(const yh_conv_desc* d, int bn) {
 // 2 = 128 x 128 (4 waves), 3 = 128 x 64 (4 waves).  d->algo: 0 library default, 1 force v2, 2..4 = variant 1..3 when eligible.
 int conv_v3_variant(const yh_conv_desc* d)
 {
-    if (d->algo == 1 || stem_eligible(d) || !conv_v2_ok(d)) return 0;
+    if (d->algo == 1 || d->algo == 5 || stem_eligible(d) || !conv_v2_ok(d)) return 0;
     { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 512)) return 0; }
     for (int s = 0; s < d->nseg; ++s) if (d->seg[s].C % 32) return 0;
     if (d->N <= 32) return 0;
@@ -1378,6 +1772,29 @@ int conv_v3_variant(const yh_conv_desc* d)
     if (d->N > 64 && K >= 512 && M >= 256L * 192) return 1;
     return 0;
 }
+// halo kernel (conv_halo_kernel): 3x3 / stride 1 / pad 1, one input segment with a multiple of 64 channels, N > 32.
+// d->algo: 5 forces it when eligible; 0 (library default) takes it when the tile geometry wastes < 25 % of the MFMA rows
+bool conv_halo_ok(const yh_conv_desc* d, HaloGeom* g)
+{
+    if (d->algo != 0 && d->algo != 5) return false;
+    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 1024)) return false; }
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->nseg != 1 || d->seg[0].ups) return false;
+    if (d->seg[0].C % 64 || d->N <= 32 || d->tile_n == 32) return false;
+    if (d->Ho != d->Hi || d->Wo != d->Wi) return false;
+    if (!conv_v2_ok(d)) return false;
+    const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || d->nsplit < d->N;
+    if (generic && d->stats) return false;
+    if ((long)d->B * d->Ho * d->Wo >= (1L << 31)) return false;
+    HaloGeom gg;
+    if (!conv_halo_geom(d->Ho, d->Wo, &gg)) return false;
+    if (d->algo == 0) {
+        const double eff = (double)d->Ho * d->Wo / ((double)gg.tiles_x * gg.tiles_y * 256.0);
+        if (eff < 0.75 || (long)d->B * gg.tiles_x * gg.tiles_y < 128) return false;
+    }
+    if (g) *g = gg;
+    return true;
+}
+
 int conv_v3_bkt(const yh_conv_desc* d) {
     for (int s = 0; s < d->nseg; ++s) if (d->seg[s].C % 64) return 32;
     return d->tile_k == 32 ? 32 : 64;
@@ -1388,6 +1805,17 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
     if (stem_eligible(d)) {
         const long blocks = (M / 32 + 3) / 4;
         *gx = (int)(blocks < STEM_BLOCKS ? blocks : STEM_BLOCKS); *gy = 1; *bn = 32;
+        return;
+    }
+    HaloGeom hgm;
+    if (!stem_eligible(d) && conv_halo_ok(d, &hgm)) {
+        const int b = d->N <= 64 ? 64 : 128;
+        const int nt = (d->N + b - 1) / b;
+        const long ntiles = (long)d->B * hgm.tiles_x * hgm.tiles_y;
+        int cap = 256 / nt;
+        if (cap < 1) cap = 1;
+        if (d->grid_cap > 0) cap = d->grid_cap;
+        *gx = (int)(ntiles < cap ? ntiles : cap); *gy = nt; *bn = b;
         return;
     }
     if (const int v3 = conv_v3_variant(d)) {
@@ -1489,7 +1917,9 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     int gx, gy, bn;
     conv_grid(d, &gx, &gy, &bn);
     YH_CHECK_ARG(gy * bn <= d->Npad, "yh_conv_igemm: Npad too small for tile");
-    const int v3 = conv_v3_variant(d);
+    HaloGeom hgeo;
+    const bool halo = !stem_eligible(d) && conv_halo_ok(d, &hgeo);
+    const int v3 = halo ? 0 : conv_v3_variant(d);
     if (k.cls && !v3) { gx = (gx + 3) / 4; if (gx > k.mtiles) gx = k.mtiles; }
     dim3 grid(gx, gy, k.cls ? 4 : 1), block(256);
     // ---- lean buffer-load kernel
@@ -1532,6 +1962,33 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
                      "yh_conv_igemm: the fused BatchNorm-backward reduction needs the plain buffer-load data-gradient path");
         YH_CHECK_ARG(d->bnr_z && yh_aligned16(d->bnr_z) && d->bnr_ldz % 8 == 0 && d->bnr_ws && d->bnr_C >= d->N && d->N % 8 == 0,
                      "yh_conv_igemm: bad fused-reduction operands");
+    }
+    if (halo) {
+        YH_CHECK_ARG(k.v2 && !k.cls, "yh_conv_igemm: the halo kernel needs the buffer-load path");
+        const int epi = d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0));
+        if (name_out) { snprintf(name_out, name_len, "conv_halo_kernel<%d, %d>", bn, epi); return YH_OK; }
+        hipStream_t sth = (hipStream_t)stream;
+        const dim3 gridh(gx, gy), blkh(512);
+#define YH_LAUNCH_HALO(BN_)                                                                                          \
+        do {                                                                                                         \
+            const size_t sm = conv_halo_smem_bytes<BN_>();                                                           \
+            static bool attr_set = false;                                                                            \
+            if (!attr_set) {                                                                                         \
+                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set = true;                                                                                     \
+            }                                                                                                        \
+            if (epi == 3)      conv_halo_kernel<BN_, 3><<<gridh, blkh, sm, sth>>>(k, hgeo);                          \
+            else if (epi == 2) conv_halo_kernel<BN_, 2><<<gridh, blkh, sm, sth>>>(k, hgeo);                          \
+            else if (epi == 1) conv_halo_kernel<BN_, 1><<<gridh, blkh, sm, sth>>>(k, hgeo);                          \
+            else               conv_halo_kernel<BN_, 0><<<gridh, blkh, sm, sth>>>(k, hgeo);                          \
+        } while (0)
+        if (bn == 64) YH_LAUNCH_HALO(64); else YH_LAUNCH_HALO(128);
+#undef YH_LAUNCH_HALO
+        YH_CHECK_LAUNCH("yh_conv_igemm(halo)");
+        return YH_OK;
     }
     if (v3) {
         YH_CHECK_ARG(k.v2, "yh_conv_igemm: the LDS-DMA kernel needs the buffer-load path");
@@ -1636,6 +2093,7 @@ extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
     int gx, gy, bn;
     conv_grid(d, &gx, &gy, &bn);
     const bool cls = d->stride == 2 && d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->KH >= 2 && d->KW >= 2;
+    if (!stem_eligible(d) && conv_halo_ok(d, nullptr)) return gx;
     if (conv_v3_variant(d)) return cls ? gx * 4 : gx;
     if (cls) {
         const long mt = ((long)(M / 4) + BM - 1) / BM;

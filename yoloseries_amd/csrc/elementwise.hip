@@ -17,42 +17,53 @@ __device__ __forceinline__ uint4 ld_nt(const uint16_t* p) {
 }
 
 // ---------------------------------------------------------------- BN finalize
-// Deterministic column sums of a [nblk][nwhich][ld] partial slab: one block = 64 channels (lane = channel,
-// coalesced rows), 16 waves stride over the partial rows, fixed-order combine through LDS in fp64.
+// Deterministic column sums of a [nblk][nwhich][ld] partial slab.  These kernels sit on the layer chain's critical path
+// (conv -> finalize -> apply) and move little data, so they are built for latency: one block = FIN_CPB channels
+// (a quarter wave reads 64 contiguous bytes of a slab row), 64 row groups (16 waves x 4 quarter waves) with 8 independent
+// row loads in flight per lane, fixed-order combine through LDS in fp64.  C / 16 blocks spread the slab over the CUs
+// (the 64-channel, 4-in-flight version took 7-24 us per launch, 114 launches per train step).
+constexpr int FIN_CPB = 16;
+constexpr int FIN_RG = 64;
+
 template <int NW>
 __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int nblk, int ld, int C, int c, double* out /*NW*/)
 {
-    __shared__ double sred[16][NW][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ double sred[FIN_RG][NW][FIN_CPB];
+    const int lc = threadIdx.x & (FIN_CPB - 1), rg = threadIdx.x / FIN_CPB;
     double acc[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) acc[w] = 0.0;
     if (c < C) {
-        int b = wv;
-        for (; b + 48 < nblk; b += 64) {      // 4 independent row loads in flight per lane
-            float v[4][NW];
+        int b = rg;
+        for (; b + 7 * FIN_RG < nblk; b += 8 * FIN_RG) {
+            float v[8][NW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
-                for (int w = 0; w < NW; ++w) v[u][w] = slab[((size_t)(b + 16 * u) * NW + w) * ld + c];
+                for (int w = 0; w < NW; ++w) v[u][w] = slab[((size_t)(b + FIN_RG * u) * NW + w) * ld + c];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int w = 0; w < NW; ++w) acc[w] += (double)v[u][w];
         }
-        for (; b < nblk; b += 16) {
+        float t[8][NW];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) acc[w] += (double)slab[((size_t)b * NW + w) * ld + c];
-        }
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t[u][w] = (b + FIN_RG * u < nblk) ? slab[((size_t)(b + FIN_RG * u) * NW + w) * ld + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc[w] += (double)t[u][w];
     }
 #pragma unroll
-    for (int w = 0; w < NW; ++w) sred[wv][w][lane] = acc[w];
+    for (int w = 0; w < NW; ++w) sred[rg][w][lc] = acc[w];
     __syncthreads();
-    if (wv == 0) {
+    if (rg == 0) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             double s = 0.0;
-            for (int i = 0; i < 16; ++i) s += sred[i][w][lane];
+            for (int i = 0; i < FIN_RG; ++i) s += sred[i][w][lc];
             out[w] = s;
         }
     }
@@ -63,10 +74,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                    float* running_mean, float* running_var, int64_t* num_batches,
                                    float eps, float momentum, float* ws)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
     double sq[2];
     slab_colsum<2>(stats, nblk, ldstat, C, c, sq);
-    if (threadIdx.x >= 64) return;
+    if (threadIdx.x >= FIN_CPB) return;
     if (c == 0 && num_batches) *num_batches += 1;
     if (c >= C) return;
     double mean = sq[0] / count;
@@ -232,10 +243,10 @@ __global__ __launch_bounds__(RED_THREADS, 4) void col_reduce_kernel(const uint16
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
                                        const float* __restrict__ ws, float* dgamma, float* dbeta, float* coef)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
     double s[2];
     slab_colsum<2>(part, nblk, C, C, c, s);
-    if (threadIdx.x >= 64 || c >= C) return;
+    if (threadIdx.x >= FIN_CPB || c >= C) return;
     s[1] = (double)ws[3 * C + c] * (s[1] - (double)ws[2 * C + c] * s[0]);      // sum(dz*y) -> sum(dz*xhat)
     if (dbeta) dbeta[c] = (float)s[0];
     if (dgamma) dgamma[c] = (float)s[1];
@@ -244,10 +255,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 
 __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
     double s[2];
     slab_colsum<2>(part, nblk, C, C, c, s);
-    if (threadIdx.x >= 64 || c >= C) return;
+    if (threadIdx.x >= FIN_CPB || c >= C) return;
     out[c] = (float)s[0];
 }
 
@@ -486,7 +497,7 @@ extern "C" int yh_bn_finalize(const float* stats, int nblk, int ldstat, int C, i
                               int64_t* num_batches, float eps, float momentum, float* ws, yh_stream stream)
 {
     YH_CHECK_ARG(stats && gamma && beta && ws && nblk > 0 && C > 0 && count > 0 && ldstat >= C, "yh_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(1024), 0, (hipStream_t)stream,
                        stats, nblk, ldstat, C, (double)count, gamma, beta, running_mean, running_var, num_batches, eps, momentum, ws);
     YH_CHECK_LAUNCH("yh_bn_finalize");
     return YH_OK;
@@ -537,7 +548,7 @@ extern "C" int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M,
                                   float* dgamma, float* dbeta, float* coef, yh_stream stream)
 {
     YH_CHECK_ARG(part && ws && nblk > 0 && C > 0 && M > 0, "yh_bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(1024), 0, (hipStream_t)stream,
                        part, nblk, C, (double)M, ws, dgamma, dbeta, coef);
     YH_CHECK_LAUNCH("yh_bn_bwd_finalize");
     return YH_OK;
@@ -569,7 +580,7 @@ extern "C" int yh_colsum(const yh_bf16* g, int ldg, int C, int64_t M, float* par
     long rpb = (M + nblk - 1) / nblk;
     hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
                        g, ldg, (const uint16_t*)nullptr, 0, (const float*)nullptr, C, C / 8, (long)M, rpb, part);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, nblk, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(1024), 0, (hipStream_t)stream, part, nblk, C, out);
     YH_CHECK_LAUNCH("yh_colsum");
     return YH_OK;
 }

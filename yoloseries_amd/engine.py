@@ -406,7 +406,7 @@ class Program:
         only the number of BatchNorm partial-sum rows follows the grid."""
         if os.environ.get("YH_CONV_TUNE", "1") == "0":
             return
-        key = f"conv3:{kind}:" + ",".join(str(int(v)) for v in (
+        key = f"conv4:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
             int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part))))
@@ -432,9 +432,10 @@ class Program:
                 cands.append((1, tk, cap))
         d.tile_k = d.grid_cap = 0
         if os.environ.get("YH_CONV_V3", "1") != "0":
-            for algo in (2, 3, 4):
+            for algo in (2, 3, 4, 5):
                 d.algo = algo
-                if "conv_v3" in self._kernel_name(d):
+                kn = self._kernel_name(d)
+                if ("conv_v3" in kn and algo < 5) or ("conv_halo" in kn and algo == 5):
                     cands.append((algo, 0, 0))
         rows_max, bnr_max = 1, 1
         for algo, tk, cap in cands:
