@@ -795,6 +795,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
 template <int CHR> __device__ __forceinline__ int swz_f(int row) { return CHR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
 #define YH_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+// workgroup barrier that orders LDS accesses only: unlike __syncthreads() it does not drain LDS-DMA transfers in flight
+#define YH_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 
 // one LDS-DMA wave instruction: 64 lanes x 16 bytes from (rsrc, per-lane voff + scalar soff) to lds .. lds + 1024
 __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voff, int soff)
@@ -1167,7 +1169,7 @@ struct HaloGeom { int TH, TW, PW, NP, tiles_x, tiles_y; };
 template <int BN, int EPI>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const HaloGeom hg)
 {
-    constexpr int BMT = 256, WM = 4, WN = 2, BKT = 64, STG = 3;
+    constexpr int BMT = 256, WM = 4, WN = 2, BKT = 64, STG = 4;
     constexpr int NWV = WM * WN, NT = NWV * 64;
     constexpr int TM = 2, TN = BN / (WN * 32);
     constexpr int ROWB = BKT * 2, CHR = 8, RPI = 8;
@@ -1177,15 +1179,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
     constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;   // 45056
     constexpr int BST_BYTES = BN * ROWB;
     constexpr int ZERO_OFF = 2 * PATCH_BYTES + STG * BST_BYTES;       // 128 zero bytes
-    constexpr int CP = BN + 8;
-    constexpr int RING_BYTES = ZERO_OFF + 128;
-    constexpr int MAIN_BYTES = RING_BYTES > (BMT * CP * 2) ? RING_BYTES : (BMT * CP * 2);
+    constexpr int MAIN_BYTES = ZERO_OFF + 128;
+    constexpr int CP = BN + 8;                       // epilogue buffer: 128 rows x CP bf16 inside the idle patch buffer
+    static_assert(128 * CP * 2 <= PATCH_BYTES, "epilogue half tile must fit a patch buffer");
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t* sC = reinterpret_cast<uint16_t*>(smem);
-    float* sStat = reinterpret_cast<float*>(smem + MAIN_BYTES);
-    int* sPix = reinterpret_cast<int*>(smem + MAIN_BYTES + WM * 2 * BN * 4);
+    float* sConst = reinterpret_cast<float*>(smem + MAIN_BYTES);            // [3][BN]: bias | scale | shift (EPI 2), scale | shift (EPI 3)
+    int* sPix = reinterpret_cast<int*>(smem + MAIN_BYTES + 3 * BN * 4);     // [BMT] output pixel of each tile row, -1 = none
 
     const yh_conv_desc& d = p.d;
     const int t = threadIdx.x;
@@ -1215,41 +1216,84 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
         const int row = (j * NWV + wave) * RPI + lrow;
         voffB[j] = (unsigned)(((n0 + row) * p.Ktot + ((lq ^ swz_f<CHR>(row)) * 8)) * 2);
     }
-    const int rdB0 = 2 * PATCH_BYTES + (wn * (TN * 32) + (lane & 31)) * ROWB;
-    const int fxB = swz_f<CHR>(lane & 31);
     const int hsel = lane >> 5;
+    int rdBk[BKT / 16];                               // weight fragment offsets inside a ring slot, per 16-channel sub-step
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks)
+        rdBk[ks] = 2 * PATCH_BYTES + (wn * (TN * 32) + (lane & 31)) * ROWB + (((ks * 2 + hsel) ^ swz_f<CHR>(lane & 31)) << 4);
 
     if (t < 32) reinterpret_cast<unsigned*>(smem + ZERO_OFF)[t] = 0u;
-
-    float run_s = 0.f, run_q = 0.f;
-    float bs_[8], bq_[8];
-    if (EPI == 3) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { bs_[e] = 0.f; bq_[e] = 0.f; }
-        for (int i = t; i < 2 * BN; i += NT) {
+    if (EPI == 2) {
+        for (int i = t; i < 3 * BN; i += NT) {
             const int which = i / BN, c = i - which * BN;
-            sStat[i] = (n0 + c < d.N) ? d.bnr_ws[(size_t)which * d.bnr_C + n0 + c] : 0.f;
+            const float* src = which == 0 ? d.bias : (which == 1 ? d.scale : d.shift);
+            sConst[i] = (src && n0 + c < d.N) ? src[n0 + c] : (which == 1 ? 1.f : 0.f);
         }
     }
+    if (EPI == 3) {
+        for (int i = t; i < 2 * BN; i += NT) {
+            const int which = i / BN, c = i - which * BN;
+            sConst[i] = (n0 + c < d.N) ? d.bnr_ws[(size_t)which * d.bnr_C + n0 + c] : 0.f;
+        }
+    }
+    // per-thread running sums over the 8 channels of the chunk this thread stores (EPI 1: sum, sum of squares of the stored
+    // bf16 values; EPI 3: sum dz, sum dz*z): a thread always handles the same channel chunk (NT % (BN/8) == 0)
+    float bs_[8], bq_[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs_[e] = 0.f; bq_[e] = 0.f; }
     __syncthreads();
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // tile -> origin, patch-loader offsets (instruction i of this wave fills patch rows (i*8 + wave)*8 .. +8)
+    auto patch_offsets = [&](int tile, unsigned (&vo)[NPW]) {
         const int img = tile / tiles_per_img;
         const int trem = tile - img * tiles_per_img;
         const int tyi = trem / hg.tiles_x;
         const int y0 = tyi * TH, x0 = (trem - tyi * hg.tiles_x) * TW;
-
-        // patch loader: instruction i of this wave fills patch rows (i*8 + wave)*8 .. +8
-        unsigned voffP[NPW];
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pr = (i * NWV + wave) * RPI + lrow;
             const int py = pr / PW, px = pr - py * PW;
             const int y = y0 - 1 + py, x = x0 - 1 + px;
             const bool ok = pr < (TH + 2) * PW && y >= 0 && y < H && x >= 0 && x < W;
-            voffP[i] = ok ? (unsigned)((img * H + y) * W + x) * (unsigned)ldx2 + (unsigned)((lq ^ swz_f<CHR>(pr)) * 16) : OOB;
+            vo[i] = ok ? (unsigned)((img * H + y) * W + x) * (unsigned)ldx2 + (unsigned)((lq ^ swz_f<CHR>(pr)) * 16) : OOB;
         }
-        // fragment rows of this lane: MFMA row -> tile pixel -> patch row of the tile's centre tap position (dy = dx = 0)
+    };
+    auto issue_patch_part = [&](const unsigned (&vo)[NPW], int part, int cblk, int pbuf) -> int {   // one instruction of this wave
+        const int inst = part * NWV + wave;
+        if (inst >= NP) return 0;
+        unsigned char* dst = smem + pbuf * PATCH_BYTES + inst * (RPI * ROWB);
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+            if (i == part) lds_dma16(rs0, dst, vo[i], cblk * (BKT * 2));
+        return 1;
+    };
+    auto issue_B = [&](int kt2, int slot) {           // weight tile of k-step kt2 (the stream repeats every nkt steps: tile independent)
+        const int cblk = kt2 / 9, tap = kt2 - cblk * 9;
+        const int sw = (tap * p.Ctot + cblk * BKT) * 2;
+        unsigned char* sb = smem + 2 * PATCH_BYTES + slot * BST_BYTES + wave * (RPI * ROWB);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) lds_dma16(rsw, sb + j * (NWV * RPI * ROWB), voffB[j], sw);
+    };
+
+    int tile = blockIdx.x;
+    unsigned voffP[NPW], voffN[NPW];
+    int slot = 0, islot = STG - 1, pb = 0;
+    if (tile < ntiles) {
+        patch_offsets(tile, voffP);
+#pragma unroll
+        for (int part = 0; part < NPW; ++part) issue_patch_part(voffP, part, 0, 0);
+        issue_B(0, 0);
+        issue_B(1, 1);                               // nkt >= 9
+        issue_B(2, 2);
+        YH_VMCNT(NB);                                // patch and the weight tiles of steps 0, 1 have landed; the third stays in flight
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        const int img = tile / tiles_per_img;
+        const int trem = tile - img * tiles_per_img;
+        const int tyi = trem / hg.tiles_x;
+        const int y0 = tyi * TH, x0 = (trem - tyi * hg.tiles_x) * TW;
+        // fragment rows of this lane: MFMA row -> tile pixel -> patch row of the tap (dy, dx) = (0, 0)
         int pr0[TM];
         bool inv[TM];
 #pragma unroll
@@ -1272,236 +1316,256 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        auto issue_patch_part = [&](int part, int cblk, int pbuf) {          // one instruction of this wave (part = 0..NPW-1)
-            const int inst = part * NWV + wave;
-            if (inst < NP) {
-                unsigned char* dst = smem + pbuf * PATCH_BYTES + inst * (RPI * ROWB);
+        // k loop: channel blocks outside, the nine taps fully unrolled inside (tap, its (dy, dx), the patch part and the weight
+        // column of the step two ahead are compile-time: the per-step scalar / vector overhead is what bounds this loop, not MFMA)
+        int prev_group = 0;
+        bf16x8_t afN[TM], bfN[TN];
+        for (int cblk = 0; cblk < ncb; ++cblk) {
+            const bool last_blk = cblk + 1 == ncb;
+            if (last_blk && has_next) patch_offsets(tile + gridDim.x, voffN);
+            const unsigned char* pbase = smem + pb * PATCH_BYTES;
 #pragma unroll
-                for (int i = 0; i < NPW; ++i)
-                    if (i == part) lds_dma16(rs0, dst, voffP[i], cblk * (BKT * 2));
-            }
-        };
-        auto issue_B = [&](int kt2, int slot) {
-            const int cblk = kt2 / 9, tap = kt2 - cblk * 9;
-            const int sw = (tap * p.Ctot + cblk * BKT) * 2;
-            unsigned char* sb = smem + 2 * PATCH_BYTES + slot * BST_BYTES + wave * (RPI * ROWB);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) lds_dma16(rsw, sb + j * (NWV * RPI * ROWB), voffB[j], sw);
-        };
-        // DMA instructions of this wave in the group issued at step kt (weights of step kt+2, patch part of the next block)
-        auto group_size = [&](int kt2) -> int {
-            const int cblk = kt2 / 9, tap = kt2 - cblk * 9;
-            int n = (kt2 + STG - 1 < nkt) ? NB : 0;
-            if (tap < NPW && cblk + 1 < ncb && tap * NWV + wave < NP) n += 1;
-            return n;
-        };
-
-        // prologue: whole patch of channel block 0, weight tiles of steps 0 and 1
-#pragma unroll
-        for (int part = 0; part < NPW; ++part) issue_patch_part(part, 0, 0);
-        issue_B(0, 0);
-        if (1 < nkt) issue_B(1, 1);
-        int slot = 0, islot = STG - 1;
-        int cblk = 0, tap = 0;
-        for (int kt = 0; kt < nkt; ++kt) {
-            // everything older than the youngest group (the one issued at step kt-1; at kt == 0 the weights of step 1) must have landed
-            const int young = kt == 0 ? ((1 < nkt) ? NB : 0) : group_size(kt - 1);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kt = cblk * 9 + tap;
+                // all DMA groups except the one issued at the previous step must have landed (step 0: waited before the tile)
 #if YH_CONV_ABLATE & 1
-            YH_VMCNT(0);
+                YH_VMCNT(0);
 #else
-            if (young == 0) YH_VMCNT(0);
-            else if (young == 1) YH_VMCNT(1);
-            else if (young == 2) YH_VMCNT(2);
-            else YH_VMCNT(3);
+                if (kt > 0) {
+                    if (prev_group == 0) YH_VMCNT(0);
+                    else if (prev_group == 1) YH_VMCNT(1);
+                    else if (prev_group == 2) YH_VMCNT(2);
+                    else YH_VMCNT(3);
+                }
 #endif
 #if !(YH_CONV_ABLATE & 256)
-            __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
 #endif
+                prev_group = 0;
 #if YH_CONV_ABLATE & 1
-            if (kt + STG - 1 < nkt && mtile_never) issue_B(kt + STG - 1, islot);
-            if (tap < NPW && cblk + 1 < ncb && mtile_never) issue_patch_part(tap, cblk + 1, (cblk + 1) & 1);
-#else
-            if (kt + STG - 1 < nkt) issue_B(kt + STG - 1, islot);
-            if (tap < NPW && cblk + 1 < ncb) issue_patch_part(tap, cblk + 1, (cblk + 1) & 1);
+                if (mtile_never)
 #endif
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const int dy = dgrad ? 2 - kh : kh, dx = dgrad ? 2 - kw : kw;
-            const int tapoff = dy * PW + dx;                                   // scalar
-            const unsigned char* pbase = smem + (cblk & 1) * PATCH_BYTES;
-            const unsigned char* bbase = smem + slot * BST_BYTES;
-            int arow[TM], afx[TM];
+                {
+                    // weight tile of step kt + 2 (wrapping into the next tile's stream)
+                    const int tapB = (tap + STG - 1) % 9;
+                    const int cblkB = cblk + ((tap + STG - 1) >= 9 ? 1 : 0);
+                    if (cblkB < ncb || has_next) {
+                        const int cb2 = cblkB < ncb ? cblkB : 0;
+                        const int sw = (tapB * p.Ctot + cb2 * BKT) * 2;
+                        unsigned char* sb = smem + 2 * PATCH_BYTES + islot * BST_BYTES + wave * (RPI * ROWB);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int pr = pr0[i] + tapoff;
-                arow[i] = pr * ROWB;
-                afx[i] = swz_f<CHR>(pr);
-            }
-#pragma unroll
-            for (int ks = 0; ks < BKT / 16; ++ks) {
-                bf16x8_t af[TM], bfr[TN];
-                const int kc = ks * 2 + hsel;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const unsigned char* ap = inv[i] ? (smem + ZERO_OFF + hsel * 16) : (pbase + arow[i] + ((kc ^ afx[i]) << 4));
-#if YH_CONV_ABLATE & 64
-                    { uint4 fake = make_uint4((unsigned)(size_t)ap, kc, i, 0x3f803f80u); af[i] = __builtin_bit_cast(bf16x8_t, fake); }
-#else
-                    af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ap));
-#endif
+                        for (int j = 0; j < NB; ++j) lds_dma16(rsw, sb + j * (NWV * RPI * ROWB), voffB[j], sw);
+                        prev_group = NB;
+                    }
+                    if (tap < NPW) {
+                        if (!last_blk) prev_group += issue_patch_part(voffP, tap, cblk + 1, pb ^ 1);
+                        else if (has_next) prev_group += issue_patch_part(voffN, tap, 0, pb ^ 1);
+                    }
                 }
+                // fragments of this step: sub-step 0 was requested during the previous step (A from the resident patch, B from a ring
+                // slot that had landed one barrier earlier: the ring is one stage deeper than the steps in flight need), so the
+                // MFMAs start right behind the barrier; only the first step of a tile loads them here
+                bf16x8_t af[TM], bfr[TN];
+                if (tap == 0 && cblk == 0) {
+                    int tapoff0 = dgrad ? 2 * PW + 2 : 0;
+                    asm volatile("" : "+s"(tapoff0));
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#if YH_CONV_ABLATE & 64
-                    { uint4 fake = make_uint4((unsigned)(size_t)bbase, kc, j, 0x3f803f80u); bfr[j] = __builtin_bit_cast(bf16x8_t, fake); }
-#else
-                    bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bbase + rdB0 + j * (32 * ROWB) + ((kc ^ fxB) << 4)));
-#endif
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) {
+                        const int pr = pr0[i] + tapoff0;
+                        const int fx = swz_f<CHR>(pr);
+                        const int ab = inv[i] ? ZERO_OFF : pb * PATCH_BYTES + pr * ROWB + (((fx & 1) ^ hsel) << 4);
+                        afN[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + ab + ((inv[i] ? 0 : (fx >> 1)) << 5)));
+                    }
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-#if YH_CONV_ABLATE & 4
-                        acc[i][j][0] += (float)af[i][0] * (float)bfr[j][0];
-#else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-#endif
-            }
-            slot = slot + 1 == STG ? 0 : slot + 1;
-            islot = islot + 1 == STG ? 0 : islot + 1;
-            if (++tap == 9) { tap = 0; ++cblk; }
-        }
-        __syncthreads();                           // nothing in flight; patch / ring -> epilogue buffer
-
-        // ---- epilogue (as conv_v3, output rows through the tile's pixel table)
-        constexpr int CPRz = BN / 8;
-        constexpr int NCHz = BMT * CPRz / NT;
-        uint4 zpre[EPI == 3 ? NCHz : 1];
-        if (EPI == 3) {
+                        bfN[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + slot * BST_BYTES + rdBk[0] + j * (32 * ROWB)));
+                }
+                const int kh = tap / 3, kw = tap % 3;
+                int tapoff = dgrad ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;            // scalar
+                // keep this step's address arithmetic inside the step: hoisted to the top of the unrolled block it costs 36 live VGPRs
+                asm volatile("" : "+s"(tapoff));
+                const int sbase = slot * BST_BYTES;
+                // A: patch row of this lane's pixel for this tap; rows outside the tile read the 128-byte zero line.  The chunk
+                // swizzle (kc ^ f(row)) << 4 with kc = 2 ks + h splits into a per-step term (h ^ f0) << 4 and ((ks ^ f12) << 5)
+                int abase[TM], af12[TM];
 #pragma unroll
-            for (int i = 0; i < NCHz; ++i) {
-                const int id = t + i * NT;
-                const int row = id / CPRz;
-                const int n = n0 + (id - row * CPRz) * 8;
-                const int orow = sPix[row];
-                zpre[i] = make_uint4(0, 0, 0, 0);
-                if (orow >= 0 && n < d.N) zpre[i] = *reinterpret_cast<const uint4*>(d.bnr_z + (size_t)orow * d.bnr_ldz + n);
-            }
-        }
+                for (int i = 0; i < TM; ++i) {
+                    const int pr = pr0[i] + tapoff;
+                    const int fx = swz_f<CHR>(pr);
+                    abase[i] = inv[i] ? ZERO_OFF : pb * PATCH_BYTES + pr * ROWB + (((fx & 1) ^ hsel) << 4);
+                    af12[i] = inv[i] ? 0 : (fx >> 1);
+                }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int c = wn * (TN * 32) + j * 32 + (lane & 31);
-            float bs = 0.f, scl = 1.f, sft = 0.f;
-            if (EPI == 2) {
-                const int n = n0 + c;
-                const bool nv = n < d.N;
-                bs = (d.bias && nv) ? d.bias[n] : 0.f;
-                scl = (d.scale && nv) ? d.scale[n] : 1.f;
-                sft = (d.shift && nv) ? d.shift[n] : 0.f;
-            }
-            float s = 0.f, q = 0.f;
+                for (int ks = 0; ks < BKT / 16; ++ks) {
+                    if (ks == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                uint16_t* dst = sC + (wm * (TM * 32) + i * 32 + 4 * (lane >> 5)) * CP + c;
+                        for (int i = 0; i < TM; ++i) af[i] = afN[i];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r];
-                    if (EPI == 2) {
-                        v = (v + bs) * scl + sft;
-                        if (d.act == YH_ACT_SILU) v = silu_fast(v);
+                        for (int j = 0; j < TN; ++j) bfr[j] = bfN[j];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + abase[i] + ((ks ^ af12[i]) << 5)));
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + sbase + rdBk[ks] + j * (32 * ROWB)));
                     }
-                    dst[((r & 3) + 8 * (r >> 2)) * CP] = f2bf(v);
-                    if (EPI == 1) { s += v; q += v * v; }      // rows outside the tile and padded channels are exact zeros
+                    if (ks == BKT / 16 - 2 && !(tap == 8 && last_blk)) {
+                        // request sub-step 0 of the NEXT step (next tap of this channel block, or tap 0 of the next block in the other
+                        // patch buffer, whose parts landed before this step's barrier)
+                        const int ntap = tap == 8 ? 0 : tap + 1;
+                        const int nkh = ntap / 3, nkw = ntap % 3;
+                        int ntapoff = dgrad ? (2 - nkh) * PW + (2 - nkw) : nkh * PW + nkw;
+                        asm volatile("" : "+s"(ntapoff));
+                        const int npb = tap == 8 ? (pb ^ 1) : pb;
+                        const int nslot = slot + 1 == STG ? 0 : slot + 1;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const int pr = pr0[i] + ntapoff;
+                            const int fx = swz_f<CHR>(pr);
+                            const int ab = inv[i] ? ZERO_OFF : npb * PATCH_BYTES + pr * ROWB + (((fx & 1) ^ hsel) << 4);
+                            afN[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + ab + ((inv[i] ? 0 : (fx >> 1)) << 5)));
+                        }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            bfN[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + nslot * BST_BYTES + rdBk[0] + j * (32 * ROWB)));
+                    }
+                    // operands swapped (D = W x X^T): a lane then holds ONE pixel (lane & 31) and, per register group, four
+                    // consecutive channels: the accumulators pack to 8-byte LDS stores in the epilogue
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 }
+                slot = slot + 1 == STG ? 0 : slot + 1;
+                islot = islot + 1 == STG ? 0 : islot + 1;
             }
-            if (EPI == 1) {
-                s += __shfl_xor(s, 32, 64);
-                q += __shfl_xor(q, 32, 64);
-                if (lane < 32) {
-                    sStat[(wm * 2 + 0) * BN + c] = s;
-                    sStat[(wm * 2 + 1) * BN + c] = q;
-                }
-            }
+            pb ^= 1;
         }
-        __syncthreads();
-
+        // the next tile's patch and first weight tile must have landed before its step 0 (its second weight tile stays in flight);
+        // the epilogue works in the patch buffer the next tile does NOT use
+        if (has_next) { YH_VMCNT(NB); } else { YH_VMCNT(0); }
+        uint16_t* sC = reinterpret_cast<uint16_t*>(smem + (pb ^ 1) * PATCH_BYTES);
         constexpr int CPR = BN / 8;
-        constexpr int NCH = BMT * CPR / NT;
+        constexpr int NCH = 128 * CPR / NT;
+        static_assert((128 * CPR) % NT == 0, "chunks must divide over the threads");
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int id = t + i * NT;
-            const int row = id / CPR;
-            const int cch = id - row * CPR;
-            const int n = n0 + cch * 8;
-            const int orow_i = sPix[row];
-            if (orow_i >= 0 && n < d.N) {
-                const size_t orow = (size_t)orow_i;
-                uint4 v = *reinterpret_cast<const uint4*>(sC + row * CP + cch * 8);
-                if (EPI == 2) {
-                    uint16_t* dst;
-                    const bool first = n < d.nsplit;
-                    if (first) dst = d.out0 + orow * d.ld0 + n;
-                    else       dst = d.out1 + orow * d.ld1 + (n - d.nsplit);
-                    const bool addres = (d.res != nullptr) && first;
-                    if (addres || d.accumulate) {
-                        float f[8];
-                        unpack8(v, f);
-                        if (addres) {
-                            uint4 rv = *reinterpret_cast<const uint4*>(d.res + orow * d.ldr + n);
-                            float g[8]; unpack8(rv, g);
+        for (int ph = 0; ph < 2; ++ph) {
+            YH_LDS_BARRIER();                         // previous phase's readers done (ph 0: every wave is out of the k loop)
+            if ((wm >> 1) == ph) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int cc = wn * (TN * 32) + j * 32 + 8 * g + 4 * hsel;
+                        float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f), ct = cb;
+                        if (EPI == 2) {
+                            cb = *reinterpret_cast<const float4*>(sConst + cc);
+                            cs = *reinterpret_cast<const float4*>(sConst + BN + cc);
+                            ct = *reinterpret_cast<const float4*>(sConst + 2 * BN + cc);
                         }
-                        if (d.accumulate) {
-                            uint4 ov = *reinterpret_cast<const uint4*>(dst);
-                            float g[8]; unpack8(ov, g);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) f[e] += g[e];
+                        for (int i = 0; i < TM; ++i) {
+                            float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                            if (EPI == 2) {
+                                v0 = (v0 + cb.x) * cs.x + ct.x; v1 = (v1 + cb.y) * cs.y + ct.y;
+                                v2 = (v2 + cb.z) * cs.z + ct.z; v3 = (v3 + cb.w) * cs.w + ct.w;
+                                if (d.act == YH_ACT_SILU) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                            }
+                            const int row = (wm & 1) * (TM * 32) + i * 32 + (lane & 31);
+                            *reinterpret_cast<uint2*>(sC + row * CP + cc) = make_uint2(pack2(v0, v1), pack2(v2, v3));
                         }
-                        v = pack8(f);
                     }
-                    *reinterpret_cast<uint4*>(dst) = v;
-                } else {
-                    *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
-                    if (EPI == 3) {
-                        const uint4 zv = zpre[i];
-                        float g[8], z[8];
-                        unpack8(v, g);
-                        unpack8(zv, z);
-                        const float4 s0 = *reinterpret_cast<const float4*>(sStat + cch * 8);
-                        const float4 s1 = *reinterpret_cast<const float4*>(sStat + cch * 8 + 4);
-                        const float4 h0 = *reinterpret_cast<const float4*>(sStat + BN + cch * 8);
-                        const float4 h1 = *reinterpret_cast<const float4*>(sStat + BN + cch * 8 + 4);
-                        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            }
+            YH_LDS_BARRIER();
+            uint4 zpre[EPI == 3 ? NCH : 1];
+            if (EPI == 3) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float a = z[e] * sc[e] + sh[e];
-                            const float sg = sigmoid_fast(a);
-                            const float dz = g[e] * (sg * (1.f + a * (1.f - sg)));
-                            bs_[e] += dz; bq_[e] += dz * z[e];
+                for (int i = 0; i < NCH; ++i) {
+                    const int id = t + i * NT;
+                    const int row = id / CPR;
+                    const int n = n0 + (id - row * CPR) * 8;
+                    const int orow = sPix[ph * 128 + row];
+                    zpre[i] = make_uint4(0, 0, 0, 0);
+                    if (orow >= 0 && n < d.N) zpre[i] = *reinterpret_cast<const uint4*>(d.bnr_z + (size_t)orow * d.bnr_ldz + n);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int id = t + i * NT;
+                const int row = id / CPR;
+                const int cch = id - row * CPR;
+                const int n = n0 + cch * 8;
+                const int orow_i = sPix[ph * 128 + row];
+                if (orow_i >= 0 && n < d.N) {
+                    const size_t orow = (size_t)orow_i;
+                    uint4 v = *reinterpret_cast<const uint4*>(sC + row * CP + cch * 8);
+                    if (EPI == 2) {
+                        uint16_t* dst;
+                        const bool first = n < d.nsplit;
+                        if (first) dst = d.out0 + orow * d.ld0 + n;
+                        else       dst = d.out1 + orow * d.ld1 + (n - d.nsplit);
+                        const bool addres = (d.res != nullptr) && first;
+                        if (addres || d.accumulate) {
+                            float f[8];
+                            unpack8(v, f);
+                            if (addres) {
+                                uint4 rv = *reinterpret_cast<const uint4*>(d.res + orow * d.ldr + n);
+                                float g2[8]; unpack8(rv, g2);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += g2[e];
+                            }
+                            if (d.accumulate) {
+                                uint4 ov = *reinterpret_cast<const uint4*>(dst);
+                                float g2[8]; unpack8(ov, g2);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += g2[e];
+                            }
+                            v = pack8(f);
+                        }
+                        *reinterpret_cast<uint4*>(dst) = v;
+                    } else {
+                        *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
+                        if (EPI == 1) {
+                            float f[8];
+                            unpack8(v, f);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { bs_[e] += f[e]; bq_[e] += f[e] * f[e]; }
+                        }
+                        if (EPI == 3) {
+                            const uint4 zv = zpre[i];
+                            float g2[8], z[8];
+                            unpack8(v, g2);
+                            unpack8(zv, z);
+                            const float4 s0 = *reinterpret_cast<const float4*>(sConst + cch * 8);
+                            const float4 s1 = *reinterpret_cast<const float4*>(sConst + cch * 8 + 4);
+                            const float4 h0 = *reinterpret_cast<const float4*>(sConst + BN + cch * 8);
+                            const float4 h1 = *reinterpret_cast<const float4*>(sConst + BN + cch * 8 + 4);
+                            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                            const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float a = z[e] * sc[e] + sh[e];
+                                const float sg = sigmoid_fast(a);
+                                const float dz = g2[e] * (sg * (1.f + a * (1.f - sg)));
+                                bs_[e] += dz; bq_[e] += dz * z[e];
+                            }
                         }
                     }
                 }
             }
         }
-        if (EPI == 1 && t < BN) {
+        YH_LDS_BARRIER();                             // epilogue buffer and pixel table free for the next tile
 #pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                run_s += sStat[(w * 2 + 0) * BN + t];
-                run_q += sStat[(w * 2 + 1) * BN + t];
-            }
-        }
-        __syncthreads();
-        if (t < 32) reinterpret_cast<unsigned*>(smem + ZERO_OFF)[t] = 0u;      // the epilogue buffer may have covered the zero line
+        for (int i = 0; i < NPW; ++i) voffP[i] = voffN[i];
     }
 
-    if (EPI == 1 && t < BN) {
-        d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
-        d.stats[((size_t)blockIdx.x * 2 + 1) * d.Npad + n0 + t] = run_q;
-    }
-    if (EPI == 3) {
+    // per-block partial sums (EPI 1: statistics row of this block; EPI 3: BatchNorm-backward slab row)
+    if (EPI == 1 || EPI == 3) {
         constexpr int CPR2 = BN / 8;
-        float* sRed = reinterpret_cast<float*>(smem);
+        YH_VMCNT(0);
+        float* sRed = reinterpret_cast<float*>(smem);          // [NT][16]
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sRed[t * 16 + e] = bs_[e]; sRed[t * 16 + 8 + e] = bq_[e]; }
@@ -1510,16 +1574,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
             const int which = i / BN, c = i - which * BN;
             float v = 0.f;
             for (int j = c / 8; j < NT; j += CPR2) v += sRed[j * 16 + which * 8 + (c & 7)];
-            if (n0 + c < d.N) d.bnr_part[((size_t)blockIdx.x * 2 + which) * d.N + n0 + c] = v;
+            if (EPI == 1) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + n0 + c] = v;
+            else if (n0 + c < d.N) d.bnr_part[((size_t)blockIdx.x * 2 + which) * d.N + n0 + c] = v;
         }
     }
 }
 
 template <int BN>
 constexpr size_t conv_halo_smem_bytes() {
-    size_t a = 2 * 352 * 128 + 3 * (size_t)BN * 128 + 128;
-    size_t c = (size_t)256 * (BN + 8) * 2;
-    return (a > c ? a : c) + 4 * 2 * BN * 4 + 256 * 4;
+    return 2 * 352 * 128 + 4 * (size_t)BN * 128 + 128 + 3 * BN * 4 + 256 * 4;
 }
 
 // tile geometry of the halo kernel for an H x W map: TH x TW output pixels (<= 256) whose (TH+2) x (TW+2) patch fits 352 rows,
