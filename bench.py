@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--img", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the train step once into a hipGraph and replay it (utils/graph.py). "
+                    "Off by default: measured on MI355X / ROCm 7.2 the replay is no faster than the eager two-stream schedule "
+                    "(the step is bound by the ~700 dependent kernel boundaries, not by host launch time; DESIGN.md section 7)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--model", default="small", choices=["small", "middle", "large", "xlarge"])
     ap.add_argument("--workload", default="train", choices=["train", "yolox", "infer"],
@@ -215,7 +218,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the train step is captured once into a hipGraph (forward, loss, backward incl. its side-stream branch, clip, SGD, EMA)
+    # and replayed: one launch per step instead of ~700; the warm-up steps run eagerly (they build and tune the programs)
+    eager_step = step
+    stepper = None
+    if args.workload != "infer" and dp is None and (args.graph or os.environ.get("YH_GRAPH", "0") == "1"):
+        from yoloseries_amd.utils.graph import GraphedStep
+        stepper = GraphedStep(eager_step, pre_replay=[opt.graph_pre_replay, ema.graph_pre_replay], warmup=max(2, min(args.warmup, 3)))
+        step = stepper
+    for _ in range(max(args.warmup, 4 if stepper is not None else 0)):
         out = step()
     sync_all()
     t0 = time.perf_counter()
@@ -230,6 +241,10 @@ def main():
     loss_val = float(out["tot_loss"].item())
     ips = world * B * args.steps / dt
 
+    launch_mode = stepper.mode if stepper is not None else "eager"
+    if stepper is not None and stepper.failed:
+        print(f"# hipGraph capture failed, ran eagerly: {stepper.failed}", file=sys.stderr)
+    step = eager_step                        # the instrumented roofline steps below time individual launches
     roof = None
     if rank == 0 and not args.no_roofline:
         # rank 0 alone instruments a few extra steps: no gradient exchange in them (the other ranks wait below)
@@ -252,7 +267,7 @@ def main():
             "config": {"workload": workload, "global_batch": B * world, "parallelism": f"dp{world}" + (" (forced RCCL path)" if force_dp else "")},
             "train_tflops": round(ips * gflop_img / 1000.0, 2),
             "mfma_frac_step": round(ips * gflop_img / 1000.0 / (MFMA_PEAK_TFLOPS * world), 4),
-            "final_loss": round(loss_val, 4), **extra,
+            "final_loss": round(loss_val, 4), "launch": launch_mode, **extra,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res))

@@ -204,6 +204,17 @@ int yh_gather_f32(const float* src, const int32_t* idx, int64_t n, float* dst, y
 int yh_sgd_step(float* p, const float* g, float* buf, const uint8_t* group, int64_t n,
                 const float* lr, const float* wd, int ngroups, float momentum, int nesterov,
                 int first_step, const float* grad_scale, yh_stream stream);
+/* the same step with every per-step scalar in DEVICE memory: scal[8] = lr[3] | wd[3] | momentum | first-step flag (!= 0).
+ * No value of the step is a launch argument, so a captured hipGraph replays correctly while the host changes lr / momentum
+ * between replays (warm-up, train_yolov5.py:437-456); at most 3 parameter groups. */
+int yh_sgd_step_dev(float* p, const float* g, float* buf, const uint8_t* group, int64_t n,
+                    const float* scal, int nesterov, const float* grad_scale, yh_stream stream);
+/* EMA with the decay read from device memory (trainer/ema_model.py:20-28: the decay ramps with the update count) */
+int yh_ema_update_dev(float* ema, const float* p, int64_t n, const float* decay_dev, yh_stream stream);
+/* advance the device-resident EMA update counter by one and write the decay of this update,
+ * decay = ratio * (1 - exp(-counter / tau)) evaluated in double (trainer/ema_model.py:12); then yh_ema_update_dev(.., decay, ..).
+ * Keeps the whole train step free of host-computed scalars (hipGraph replay). */
+int yh_ema_advance(int64_t* counter, float* decay, double ratio, double tau, yh_stream stream);
 /* sum of squares of a flat fp32 buffer (for clip_grad_norm_, train_yolov5.py:344) */
 int yh_sumsq(const float* x, int64_t n, float* part, float* out, yh_stream stream);
 /* clip coefficient min(1, max_norm/(sqrt(sumsq)+1e-6)) as a device scalar for yh_sgd_step's grad_scale */

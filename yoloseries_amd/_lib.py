@@ -124,6 +124,9 @@ _SIGS = {
     "yh_pack_bf16": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "yh_gather_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "yh_sgd_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _i32, _i32, _vp, _vp]),
+    "yh_sgd_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp]),
+    "yh_ema_update_dev": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "yh_ema_advance": (_i32, [_vp, _vp, C.c_double, C.c_double, _vp]),
     "yh_sumsq": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "yh_clip_scale": (_i32, [_vp, _f32, _vp, _vp]),
     "yh_ema_update": (_i32, [_vp, _vp, _i64, _f32, _vp]),

@@ -45,6 +45,44 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
         p[i] = pv - lr[gi] * upd;
     }
 }
+// same update with the per-step scalars read from device memory (scal = lr[0..2] | wd[0..2] | momentum | first-step flag):
+// nothing about the step is baked into the launch arguments, so a captured hipGraph replays with the values the host wrote
+// into `scal` before the replay (warm-up of lr / momentum, train_yolov5.py:437-456)
+__global__ void sgd_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                               const uint8_t* __restrict__ group, long n, const float* __restrict__ scal, int nesterov,
+                               const float* __restrict__ grad_scale)
+{
+    const float gs = grad_scale ? *grad_scale : 1.f;
+    const float lr[3] = {scal[0], scal[1], scal[2]}, wd[3] = {scal[3], scal[4], scal[5]};
+    const float momentum = scal[6];
+    const bool first = scal[7] != 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int gi = group ? group[i] : 0;
+        gi = gi > 2 ? 2 : gi;
+        float pv = p[i];
+        float gv = g[i] * gs + (gi == 0 ? wd[0] : (gi == 1 ? wd[1] : wd[2])) * pv;
+        float b = first ? gv : momentum * buf[i] + gv;
+        buf[i] = b;
+        float upd = nesterov ? gv + momentum * b : b;
+        p[i] = pv - (gi == 0 ? lr[0] : (gi == 1 ? lr[1] : lr[2])) * upd;
+    }
+}
+__global__ void ema_dev_kernel(float* __restrict__ e, const float* __restrict__ p, long n, const float* __restrict__ decay_dev)
+{
+    const float decay = *decay_dev;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        e[i] = decay * e[i] + (1.f - decay) * p[i];
+}
+// EMA decay schedule kept on the device (trainer/ema_model.py:12: decay = ratio * (1 - exp(-n / tau)), n = update count):
+// one thread advances the counter and writes the decay of THIS update, evaluated in double like the reference's Python float
+__global__ void ema_advance_kernel(long long* __restrict__ counter, float* __restrict__ decay, double ratio, double tau)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const long long n = counter[0] + 1;
+        counter[0] = n;
+        decay[0] = (float)(ratio * (1.0 - exp(-(double)n / tau)));
+    }
+}
 __global__ __launch_bounds__(TH) void sumsq_part_kernel(const float* __restrict__ x, long n, float* __restrict__ part)
 {
     __shared__ double sw[TH / 64];
@@ -130,6 +168,30 @@ extern "C" int yh_sgd_step(float* p, const float* g, float* buf, const uint8_t* 
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(TH), 0, (hipStream_t)stream,
                        p, g, buf, group, (long)n, lr, wd, momentum, nesterov, first_step, grad_scale);
     YH_CHECK_LAUNCH("yh_sgd_step");
+    return YH_OK;
+}
+extern "C" int yh_sgd_step_dev(float* p, const float* g, float* buf, const uint8_t* group, int64_t n,
+                               const float* scal, int nesterov, const float* grad_scale, yh_stream stream)
+{
+    YH_CHECK_ARG(p && g && buf && scal && n >= 0, "yh_sgd_step_dev: bad args");
+    if (n == 0) return YH_OK;
+    hipLaunchKernelGGL(sgd_dev_kernel, dim3(grid_for(n)), dim3(TH), 0, (hipStream_t)stream, p, g, buf, group, (long)n, scal, nesterov, grad_scale);
+    YH_CHECK_LAUNCH("yh_sgd_step_dev");
+    return YH_OK;
+}
+extern "C" int yh_ema_update_dev(float* ema, const float* p, int64_t n, const float* decay_dev, yh_stream stream)
+{
+    YH_CHECK_ARG(ema && p && decay_dev && n >= 0, "yh_ema_update_dev: bad args");
+    if (n == 0) return YH_OK;
+    hipLaunchKernelGGL(ema_dev_kernel, dim3(grid_for(n)), dim3(TH), 0, (hipStream_t)stream, ema, p, (long)n, decay_dev);
+    YH_CHECK_LAUNCH("yh_ema_update_dev");
+    return YH_OK;
+}
+extern "C" int yh_ema_advance(int64_t* counter, float* decay, double ratio, double tau, yh_stream stream)
+{
+    YH_CHECK_ARG(counter && decay && tau > 0.0, "yh_ema_advance: bad args");
+    hipLaunchKernelGGL(ema_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)counter, decay, ratio, tau);
+    YH_CHECK_LAUNCH("yh_ema_advance");
     return YH_OK;
 }
 extern "C" int yh_sumsq(const float* x, int64_t n, float* part, float* out, yh_stream stream)

@@ -201,3 +201,16 @@ def ema_update(ema, p, decay):
 
 def clip_scale(sumsq_t, max_norm, out):
     check(lib().yh_clip_scale(_p(sumsq_t), float(max_norm), _p(out), _st()), "yh_clip_scale")
+
+
+def sgd_step_dev(p, g, buf, group, scal, nesterov, grad_scale=None):
+    """SGD step with lr | wd | momentum | first-step flag read from the device tensor `scal` (8 floats): graph-replay safe"""
+    check(lib().yh_sgd_step_dev(_p(p), _p(g), _p(buf), _p(group), p.numel(), _p(scal), int(nesterov), _p(grad_scale), _st()), "yh_sgd_step_dev")
+
+
+def ema_update_dev(ema, p, decay_dev):
+    check(lib().yh_ema_update_dev(_p(ema), _p(p), p.numel(), _p(decay_dev), _st()), "yh_ema_update_dev")
+
+
+def ema_advance(counter, decay, ratio, tau):
+    check(lib().yh_ema_advance(_p(counter), _p(decay), float(ratio), float(tau), _st()), "yh_ema_advance")

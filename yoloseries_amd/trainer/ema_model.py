@@ -19,7 +19,9 @@ class ExponentialMovingAverageModel:
     def __init__(self, model, decay_ratio=0.9999, update_num=0):
         self.ema = deepcopy(_unwrap(model)).eval()
         self.update_num = update_num
+        self.decay_ratio = decay_ratio
         self.get_decay_weight = lambda x: decay_ratio * (1 - math.exp(-x / 2000))
+        self._dev_state = None          # (counter int64[1], decay float32[1]) on the device + the count it holds
         for parm in self.ema.parameters():
             parm.requires_grad_(False)
         self._flat = None
@@ -47,6 +49,12 @@ class ExponentialMovingAverageModel:
                 self.ema._yh_reset()
         return self._flat
 
+    def graph_pre_replay(self):
+        """host-side bookkeeping of one update that runs as a graph replay (the device counter advances inside the graph)"""
+        self.update_num += 1
+        if self._dev_state is not None:
+            self._dev_state[2] = self.update_num
+
     def update(self, model):
         with torch.no_grad():
             self.update_num += 1
@@ -56,19 +64,33 @@ class ExponentialMovingAverageModel:
             pack = st['pack'] if st else None
             if pack is not None and pack.valid_for(src):
                 from .. import hipk
+                # the decay of this update is produced on the device from a device-resident update counter (same formula,
+                # evaluated in double): the launch takes no host scalar, so a captured step replays correctly
+                if self._dev_state is None or self._dev_state[2] != self.update_num - 1 or self._dev_state[0].device != pack.device:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("ExponentialMovingAverageModel: update counter changed outside update(); run one "
+                                           "eager update before capturing")
+                    cnt = torch.tensor([self.update_num - 1], dtype=torch.int64).to(pack.device)
+                    dec = torch.zeros(1, dtype=torch.float32, device=pack.device)
+                    self._dev_state = [cnt, dec, self.update_num - 1]
+                cnt, dec = self._dev_state[0], self._dev_state[1]
+                hipk.ema_advance(cnt, dec, self.decay_ratio, 2000.0)
+                self._dev_state[2] = self.update_num
+                def _ema(dst, srcv):
+                    hipk.ema_update_dev(dst, srcv, dec)
                 est = self.ema.__dict__.get('_yh')
                 epack = est['pack'] if est else None
                 if epack is not None and epack.valid_for(self.ema) and epack.n == pack.n and epack.nbuf == pack.nbuf:
                     # the EMA module has been evaluated: its parameters live in its own engine arenas (same layout as the
                     # source's) — update those in place and keep its programs / activation buffers / tuned descriptors
-                    hipk.ema_update(epack.flat, pack.flat, decay_weight)
+                    _ema(epack.flat, pack.flat)
                     if pack.nbuf:
-                        hipk.ema_update(epack.fbuf, pack.fbuf, decay_weight)
+                        _ema(epack.fbuf, pack.fbuf)
                     return
                 fp, fb = self._flat_views(pack)
-                hipk.ema_update(fp, pack.flat, decay_weight)
+                _ema(fp, pack.flat)
                 if pack.nbuf:
-                    hipk.ema_update(fb, pack.fbuf, decay_weight)
+                    _ema(fb, pack.fbuf)
                 # integer buffers (num_batches_tracked) are not averaged by the reference either
                 return
             state = src.state_dict()

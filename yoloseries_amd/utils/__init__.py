@@ -14,3 +14,4 @@ from .model_utils import *  # noqa: F401,F403
 from .launch import *  # noqa: F401,F403
 from .logger import *  # noqa: F401,F403
 from .visualizer import *  # noqa: F401,F403
+from .graph import GraphedStep  # noqa: F401

@@ -54,8 +54,9 @@ class FlatSGD:
                 raise YoloHipError(f"FlatSGD: checkpointed momentum buffer has {self._pending_buf.numel()} elements, the model {pack.n}")
             self.buf.copy_(self._pending_buf.to(dev))
             self._pending_buf = None
-        self.lr_t = torch.zeros(3, dtype=torch.float32, device=dev)
-        self.wd_t = torch.zeros(3, dtype=torch.float32, device=dev)
+        # per-step scalars live in device memory (lr[3] | wd[3] | momentum | first-step flag): the step kernel takes no
+        # host value as a launch argument, so a captured hipGraph of the step replays correctly (utils/graph.py)
+        self.scal = torch.zeros(8, dtype=torch.float32, device=dev)
         self.part = torch.zeros(4096, dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.scale = torch.ones(1, dtype=torch.float32, device=dev)
@@ -98,18 +99,33 @@ class FlatSGD:
         self._use_scale = True
         return self.sumsq          # device scalar: total_norm ** 2 (no host sync)
 
+    def _sync_scalars(self):
+        """device copy of lr / weight decay / momentum / first-step flag, rewritten only when a value changed (warm-up,
+        per-epoch schedule).  The copy is an ordinary stream-ordered H2D from pageable memory: staged when it is issued,
+        so the host may run ahead; it must be issued outside a graph capture (GraphedStep calls this before each replay)."""
+        vals = tuple(float(pg["lr"]) for pg in self.param_groups) + tuple(float(pg["weight_decay"]) for pg in self.param_groups) + \
+            (float(self.param_groups[0]["momentum"]), 1.0 if self.steps == 0 else 0.0)
+        if vals != self._lr_host:
+            if torch.cuda.is_current_stream_capturing():
+                raise YoloHipError("FlatSGD: learning-rate / momentum changed inside a graph capture; call graph_pre_replay() "
+                                   "(or step once eagerly) before capturing")
+            self.scal.copy_(torch.tensor(vals, dtype=torch.float32))
+            self._lr_host = vals
+
     def step(self):
         pack = self._pack()
         g = self._grad()
-        lrs = tuple(float(pg["lr"]) for pg in self.param_groups) + tuple(float(pg["weight_decay"]) for pg in self.param_groups)
-        if lrs != self._lr_host:
-            self.lr_t.copy_(torch.tensor(lrs[:3], dtype=torch.float32))
-            self.wd_t.copy_(torch.tensor(lrs[3:], dtype=torch.float32))
-            self._lr_host = lrs
-        hipk.sgd_step(pack.flat, g, self.buf, self.group, self.lr_t, self.wd_t, float(self.param_groups[0]["momentum"]),
-                      self.nesterov, self.steps == 0, self.scale if self._use_scale else None)
+        self._sync_scalars()
+        hipk.sgd_step_dev(pack.flat, g, self.buf, self.group, self.scal, self.nesterov, self.scale if self._use_scale else None)
         self.steps += 1
         self._use_scale = False
+
+    def graph_pre_replay(self):
+        """host-side bookkeeping of one step that runs as a graph replay: refresh the device scalars if the schedule moved
+        them, count the step"""
+        self._pack()
+        self._sync_scalars()
+        self.steps += 1
 
     def zero_grad(self, set_to_none=True):
         self._gacc, self._nacc = None, 0
