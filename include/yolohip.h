@@ -321,7 +321,9 @@ int yh_filter_decoded(const float* dec, int B, int N, int num_class, float conf_
  *  thr_inclusive: 1 -> suppress when iou >= thr (numba_nms), 0 -> iou > thr (gpu_nms)
  *  merge_filter: postprocess_bbox filter (eval_yolov5.py:306-315)
  *  out: [B][max_keep][6] ; nkeep [B] ; keep_idx [B][max_keep] index into the candidate list
- *  ws: yh_nms_ws_bytes                                                            */
+ *  Candidates are sorted once by (score descending, index ascending) and consumed in chunks of 64 whose mutual suppression is a
+ *  64 x 64 bit matrix built with wave shuffles; scores must be non-negative (non-positive scores are never selected).
+ *  ws: yh_nms_ws_bytes(B, cap) bytes, 16-byte aligned (sort keys, class-offset boxes in candidate and in sorted order, flags) */
 size_t yh_nms_ws_bytes(int B, int cap);
 int yh_nms_batched(const float* cand, const int32_t* ncand, int B, int cap,
                    float iou_thr, int class_aware, int thr_inclusive, int max_keep, int merge_filter,

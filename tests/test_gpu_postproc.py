@@ -167,3 +167,47 @@ def test_gpu_nms_pairwise_kinds_and_soft_nms(dev):
     np.testing.assert_array_equal(got.cpu().numpy(), g["soft_exp_giou"])
     with pytest.raises(ValueError):
         U.gpu_nms(b, s, "siou", 0.3)
+
+
+def test_nms_many_candidates_vs_oracle(dev):
+    """>= 10^4 candidates per image (a trained net at conf 0.001, BASELINE config #5): the sorted / bit-matrix NMS kernel keeps
+    the oracle's rows in the oracle's pick order, through the global-memory sort path (> 8192 candidates) and the LDS one"""
+    from oracle import postproc as opp
+    from yoloseries_amd.trainer import YOLOV5Evaluator
+    from yoloseries_amd.utils.synth import COCO_ANCHORS
+    nc = 8
+    r = np.random.RandomState(321)
+
+    def clustered(nclust, per, img=1280):
+        rows = []
+        for _ in range(nclust):
+            c = r.uniform(40, img - 40, 2); wh = r.uniform(20, 200, 2); cl = r.randint(nc)
+            for _ in range(per):
+                cc = c + r.uniform(-10, 10, 2); ww = wh * r.uniform(0.7, 1.3, 2)
+                cls = r.uniform(0.0, 0.1, nc); cls[cl] = r.uniform(0.3, 1.0)
+                rows.append(np.concatenate([cc, ww, [r.uniform(0.01, 1.0)], cls]))
+        a = np.array(rows, np.float32)
+        return a[r.permutation(len(a))]
+    big = clustered(400, 30)                 # 12 000 candidates -> global-memory sort
+    small = clustered(150, 30)               # 4 500 -> LDS sort
+    dec = np.zeros((2, len(big), 5 + nc), np.float32)
+    dec[0] = big
+    dec[1, :len(small)] = small
+    hyp = dict(device=dev, num_class=nc, input_img_size=[1280, 1280], iou_threshold=0.2, conf_threshold=0.3, cls_threshold=0.3,
+               max_predictions_per_img=300, iou_type="iou", mutil_label=False, agnostic=True, postprocess_bbox=True, wfb=False,
+               use_tta=False, half=False, compute_metric_conf_threshold=0.001, compute_metric_iou_threshold=0.65,
+               compute_metric_cls_threshold=0.001)
+    ev = YOLOV5Evaluator(None, torch.from_numpy(COCO_ANCHORS), hyp, compute_metric=True)
+    got = ev.numba_nms(torch.from_numpy(dec).to(dev))
+    ref = opp.postprocess_v5(dec, 0.001, 0.001, 0.65)
+    assert ev.last_ncand[0] >= 10000 and 3000 <= ev.last_ncand[1] <= 8192
+    for a, b in zip(got, ref):
+        assert len(b) == 300                 # capped at max_predictions_per_img
+        np.testing.assert_array_equal(a, b)
+    # no cap: every kept box of the full greedy pass
+    hyp2 = dict(hyp, max_predictions_per_img=20000, postprocess_bbox=False)   # (the merge filter only applies below 3000 candidates)
+    ev2 = YOLOV5Evaluator(None, torch.from_numpy(COCO_ANCHORS), hyp2, compute_metric=True)
+    got2 = ev2.numba_nms(torch.from_numpy(dec[:1]).to(dev))
+    ref2 = opp.postprocess_v5(dec[:1], 0.001, 0.001, 0.65, max_keep=20000)
+    assert len(ref2[0]) > 300
+    np.testing.assert_array_equal(got2[0], ref2[0])

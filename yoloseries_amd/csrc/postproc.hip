@@ -233,63 +233,130 @@ __device__ __forceinline__ float pair_iou(const float4 a, const float4 b, float 
     return inter / den;
 }
 
-__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ cand, const int32_t* __restrict__ ncand, int cap,
+// Greedy NMS == "walk the candidates in (score descending, index ascending) order; keep one iff no earlier KEPT box suppresses
+// it" (utils/nms.py:10-27 picks arg-max with first index on ties and only ever zeroes scores, so the pick order is exactly
+// that order restricted to the kept boxes; non-positive scores are never picked).  One workgroup (16 waves) per image:
+//   1. 64-bit keys (score bits << 32 | ~index) are bitonic-sorted once — in LDS up to 8192 candidates, in the L2-resident
+//      workspace above — and the class-offset boxes are permuted into that order;
+//   2. the sorted list is consumed in chunks of 64: a chunk none of whose members is still alive is skipped without a barrier
+//      (every wave reads the same 64 flags); otherwise wave 0 builds, with wave shuffles, the 64 x 64 suppression bit matrix
+//      of the chunk (lane j: mask of earlier members that suppress j), resolves it in score order, appends the survivors to
+//      the keep list (stopping at max_keep), and all 16 waves strike out the later candidates those survivors suppress.
+//   At most max_keep chunks are ever resolved (each resolved chunk keeps >= 1 box), two barriers per resolved chunk instead
+//   of three per kept box, and no arg-max scans.  Selection order, tie rule, NaN-IoU and threshold conventions are unchanged.
+constexpr int NMS_LDS_KEYS = 8192;
+
+__device__ __forceinline__ void bitonic_sort_desc(unsigned long long* keys, int P2, int t)
+{
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < P2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], c = keys[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < c) : (a > c)) { keys[i] = c; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ cand, const int32_t* __restrict__ ncand, int cap, int P2cap,
                                                    float iou_thr, int class_aware, int inclusive, int max_keep, int merge_filter,
                                                    float* __restrict__ out, int32_t* __restrict__ nkeep, int32_t* __restrict__ keep_idx,
-                                                   float* __restrict__ ws)
+                                                   unsigned char* __restrict__ ws)
 {
-    __shared__ float s_val[16];
-    __shared__ int s_idx[16];
-    __shared__ int s_pick;
-    __shared__ float s_pickval;
+    __shared__ unsigned long long s_keys[NMS_LDS_KEYS];
+    __shared__ float4 s_kbox[64];
+    __shared__ int s_nk, s_k, s_pick, s_nvalid;
     __shared__ int s_flag[512];
     const int b = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     int n = ncand[b];
     if (n > cap) n = cap;
     const float* cb = cand + (size_t)b * cap * 6;
-    float* sc = ws + (size_t)b * cap * 5;                 // scores
-    float4* bx = reinterpret_cast<float4*>(sc + cap);     // offset boxes (cap is a multiple of 4)
+    // workspace of this image: keys [P2cap] u64 | boxes in candidate order [cap] | boxes in sorted order [cap] | removed flags [cap]
+    unsigned char* wb = ws + (size_t)b * ((size_t)P2cap * 8 + (size_t)cap * 36);
+    unsigned long long* gkeys = reinterpret_cast<unsigned long long*>(wb);
+    float4* bx = reinterpret_cast<float4*>(wb + (size_t)P2cap * 8);
+    float4* sbx = bx + cap;
+    unsigned char* rem = reinterpret_cast<unsigned char*>(sbx + cap);
     int32_t* kp = keep_idx + (size_t)b * max_keep;
     const float uclamp = inclusive ? 0.f : 1e-9f;          // gpu_nms uses gpu_iou (union clamp 1e-9)
 
-    for (int i = t; i < n; i += 1024) {
-        const float* r = cb + (size_t)i * 6;
-        const float off = class_aware ? r[5] * 4096.f : r[5] * 0.f;       // eval_yolov5.py:293-298
-        bx[i] = make_float4(r[0] + off, r[1] + off, r[2] + off, r[3] + off);
-        sc[i] = r[4];
+    int P2 = 1024;
+    while (P2 < n) P2 <<= 1;
+    unsigned long long* keys = P2 <= NMS_LDS_KEYS ? s_keys : gkeys;
+    if (t == 0) s_nvalid = 0;
+    __syncthreads();
+    int myvalid = 0;
+    for (int i = t; i < P2; i += 1024) {
+        unsigned long long key = 0ull;
+        if (i < n) {
+            const float* r = cb + (size_t)i * 6;
+            const float off = class_aware ? r[5] * 4096.f : r[5] * 0.f;       // eval_yolov5.py:293-298
+            bx[i] = make_float4(r[0] + off, r[1] + off, r[2] + off, r[3] + off);
+            rem[i] = 0;
+            const float sc = r[4];
+            if (sc > 0.f) { key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i); ++myvalid; }
+        }
+        keys[i] = key;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) myvalid += __shfl_xor(myvalid, o, 64);
+    if (lane == 0 && myvalid) atomicAdd(&s_nvalid, myvalid);
+    __syncthreads();
+    const int nvalid = s_nvalid;                           // candidates with a positive score: the only ones ever picked
+    bitonic_sort_desc(keys, P2, t);
+    for (int q = t; q < nvalid; q += 1024) sbx[q] = bx[0xFFFFFFFFu - (unsigned)(keys[q] & 0xFFFFFFFFull)];
     __syncthreads();
 
     int k = 0;
-    while (k < max_keep) {
-        // arg-max with first index on ties
-        float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int i = t; i < n; i += 1024) { const float v = sc[i]; if (v > bv) { bv = v; bi = i; } }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    for (int base = 0; base < nvalid && k < max_keep; base += 64) {
+        const int q = base + lane;
+        const bool alive = q < nvalid && rem[q] == 0;
+        const unsigned long long alive_mask = __ballot(alive);            // identical in every wave: no barrier needed to skip
+        if (alive_mask == 0ull) continue;
+        if (wv == 0) {
+            const float4 mine = alive ? sbx[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned long long supp_by = 0ull;                            // earlier alive members of the chunk that suppress this one
+            for (unsigned long long m = alive_mask; m; m &= m - 1) {
+                const int i = __builtin_ctzll(m);
+                const float4 bi = make_float4(__shfl(mine.x, i, 64), __shfl(mine.y, i, 64), __shfl(mine.z, i, 64), __shfl(mine.w, i, 64));
+                if (alive && lane > i) {
+                    const float iou = pair_iou(bi, mine, uclamp);
+                    if (inclusive ? (iou >= iou_thr) : (iou > iou_thr)) supp_by |= 1ull << i;
+                }
+            }
+            unsigned long long kept = 0ull;
+            int kk = k;
+            for (unsigned long long m = alive_mask; m && kk < max_keep; m &= m - 1) {
+                const int i = __builtin_ctzll(m);
+                const unsigned lo = __shfl((unsigned)supp_by, i, 64), hi = __shfl((unsigned)(supp_by >> 32), i, 64);
+                const unsigned long long si = ((unsigned long long)hi << 32) | lo;
+                if ((si & kept) == 0ull) { kept |= 1ull << i; ++kk; }
+            }
+            if ((kept >> lane) & 1ull) {
+                const int r = __popcll(kept & ((1ull << lane) - 1ull));
+                kp[k + r] = (int)(0xFFFFFFFFu - (unsigned)(keys[q] & 0xFFFFFFFFull));
+                s_kbox[r] = mine;
+            }
+            if (lane == 0) { s_nk = kk - k; s_k = kk; }
         }
-        if (lane == 0) { s_val[wv] = bv; s_idx[wv] = bi; }
         __syncthreads();
-        if (t == 0) {
-            float v = s_val[0]; int ix = s_idx[0];
-            for (int w = 1; w < 16; ++w) if (s_val[w] > v || (s_val[w] == v && s_idx[w] < ix)) { v = s_val[w]; ix = s_idx[w]; }
-            s_pick = ix; s_pickval = v;
-        }
-        __syncthreads();
-        const float pv = s_pickval;
-        const int pi = s_pick;
-        if (!(pv > 0.f)) break;                            // `while score_copy.sum() > 0` on non-negative scores
-        if (t == 0) kp[k] = pi;
-        ++k;
-        const float4 pb = bx[pi];
-        for (int i = t; i < n; i += 1024) {
-            const float iou = pair_iou(pb, bx[i], uclamp);
-            const bool sup = inclusive ? (iou >= iou_thr) : (iou > iou_thr);
-            if (sup || i == pi) sc[i] = 0.f;
+        const int nk = s_nk;
+        k = s_k;
+        if (k < max_keep) {
+            for (int q2 = base + 64 + t; q2 < nvalid; q2 += 1024) {
+                if (rem[q2]) continue;
+                const float4 bq = sbx[q2];
+                for (int r = 0; r < nk; ++r) {
+                    const float iou = pair_iou(s_kbox[r], bq, uclamp);
+                    if (inclusive ? (iou >= iou_thr) : (iou > iou_thr)) { rem[q2] = 1; break; }
+                }
+            }
         }
         __syncthreads();
     }
@@ -382,7 +449,9 @@ extern "C" int yh_filter_decoded(const float* dec, int B, int N, int num_class, 
     return YH_OK;
 }
 
-extern "C" size_t yh_nms_ws_bytes(int B, int cap) { return (size_t)B * cap * 5 * sizeof(float); }
+static int nms_pow2(int cap) { int p = 1024; while (p < cap) p <<= 1; return p; }
+/* per image: sort keys [pow2(cap)] u64 | class-offset boxes in candidate order and in sorted order [2][cap] float4 | flags [cap] (+pad) */
+extern "C" size_t yh_nms_ws_bytes(int B, int cap) { return (size_t)B * ((size_t)nms_pow2(cap) * 8 + (size_t)cap * 36); }
 
 extern "C" int yh_nms_batched(const float* cand, const int32_t* ncand, int B, int cap,
                               float iou_thr, int class_aware, int thr_inclusive, int max_keep, int merge_filter,
@@ -392,8 +461,8 @@ extern "C" int yh_nms_batched(const float* cand, const int32_t* ncand, int B, in
     YH_CHECK_ARG(B > 0 && cap > 0 && cap % 4 == 0, "yh_nms_batched: cap must be a positive multiple of 4");
     YH_CHECK_ARG(max_keep > 0 && (max_keep <= 512 || !merge_filter), "yh_nms_batched: max_keep must be in [1,512] when merge_filter is set");
     YH_CHECK_ARG(yh_aligned16(ws), "yh_nms_batched: workspace unaligned");
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, cand, ncand, cap, iou_thr, class_aware,
-                       thr_inclusive, max_keep, merge_filter, out, nkeep, keep_idx, (float*)ws);
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, cand, ncand, cap, nms_pow2(cap), iou_thr, class_aware,
+                       thr_inclusive, max_keep, merge_filter, out, nkeep, keep_idx, (unsigned char*)ws);
     YH_CHECK_LAUNCH("yh_nms_batched");
     return YH_OK;
 }
