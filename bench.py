@@ -172,6 +172,26 @@ def main():
         kept = sum(0 if r is None else len(r) for r in res)
         n_anchor = sum(3 * (img // s) ** 2 for s in (8, 16, 32))
         ncand = sum(ev.last_ncand)
+        # the fused decode + candidate filter alone, against its algorithmic read (every head logit once: anchors x 85 x 2 B)
+        import ctypes as C
+        from yoloseries_amd._lib import check, lib, stream_ptr
+        dd, canon, ptrs = ev._desc(heads)
+        capf = ((n_anchor + 3) // 4) * 4
+        candf = torch.empty(nb, capf, 6, dtype=torch.float32, device=dev)
+        ncf = torch.zeros(nb, dtype=torch.int32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(reps + 1):
+            if it == 1:
+                e0.record()
+            check(lib().yh_decode_filter(C.byref(dd), ptrs, float(ev.conf_threshold), float(ev.cls_threshold), candf.data_ptr(),
+                                         ncf.data_ptr(), capf, stream_ptr()), "yh_decode_filter")
+        e1.record()
+        e1.synchronize()
+        df_ms = e0.elapsed_time(e1) / reps
+        df_bytes = nb * n_anchor * 85 * heads[0].element_size()
+        extra["decode_filter"] = {"bound": "hbm", "achieved": round(df_bytes / df_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(df_bytes / df_ms / 1e6 / HBM_PEAK_GBS, 4), "ms": round(df_ms, 3),
+                                  "bytes_per_image": n_anchor * 85 * heads[0].element_size(), "images": nb}
         extra["nms_synthetic"] = {"images": nb, "anchors_per_image": n_anchor, "candidates_per_image": round(ncand / nb, 1),
                                   "kept_boxes_per_image": round(kept / nb, 1), "images_per_s": round(nb / dtn, 1),
                                   "anchors_per_s": round(nb * n_anchor / dtn), "candidate_boxes_per_s": round(ncand / dtn),
@@ -267,7 +287,9 @@ def main():
             "config": {"workload": workload, "global_batch": B * world, "parallelism": f"dp{world}" + (" (forced RCCL path)" if force_dp else "")},
             "train_tflops": round(ips * gflop_img / 1000.0, 2),
             "mfma_frac_step": round(ips * gflop_img / 1000.0 / (MFMA_PEAK_TFLOPS * world), 4),
-            "final_loss": round(loss_val, 4), "launch": launch_mode, **extra,
+            "final_loss": round(loss_val, 4), "launch": launch_mode,
+            "hbm_frac_step": (round(roof["hbm_bytes_per_step"] / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4)
+                              if roof and roof.get("hbm_bytes_per_step") else None), **extra,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res))
@@ -285,62 +307,119 @@ def _instrument(prog, step, nsteps):
     prof, prog.profile = prog.profile, None
     fam, per_op = {}, []
     for key, recs in prof.items():
-        name, flops, opname = key
+        name, flops, nbytes, opname = key
         ms = sum(s.elapsed_time(e) for s, e in recs)
-        per_op.append((ms / nsteps, name, opname, flops))
-        f = fam.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        per_op.append((ms / nsteps, name, opname, flops, nbytes))
+        f = fam.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
         f["ms"] += ms
         f["flops"] += flops * len(recs)
+        f["bytes"] += nbytes * len(recs)
         f["launches"] += len(recs)
     return fam, per_op
 
 
+def _lib_sha16():
+    import hashlib
+    from yoloseries_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def _pmc_traffic():
+    """per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py): counters cannot be read from
+    inside the process.  The file is stamped with the hash of the libyolohip.so it was collected with; a different library
+    means the numbers describe other kernels, and they are dropped (null) instead of being reported stale."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+            j = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if j.get("lib_sha16") != _lib_sha16():
+        return None
+    return j
+
+
+_PMC_ALIAS = {"yh_bn_silu_bwd_reduce": ("col_reduce_kernel<0>",), "yh_colsum": ("col_reduce_kernel<1>", "colsum_finalize_kernel"),
+              "yh_bn_fold": ("bn_fold_kernel",)}
+
+
+def _pmc_bytes(pmc, name):
+    """HBM bytes per launch of an engine kernel family from the PMC file (profiler kernel names)"""
+    if pmc is None:
+        return None
+    names = _PMC_ALIAS.get(name, (name.replace("yh_", "") + "_kernel", name))
+    vals = [pmc["kernels"][n]["hbm_bytes_per_launch"] for n in names if n in pmc["kernels"]]
+    return sum(vals) if vals else None
+
+
+def _family_roofline(name, d, pmc):
+    """roofline entry of one kernel family from its algorithmic work and measured duration: the bound is the roof the family sits
+    closer to (conv tiles with little reuse — 1x1 layers, the stage-1 layers — are HBM-bound, K-heavy ones MFMA-bound)"""
+    sec = d["ms"] * 1e-3
+    tf = d["flops"] / sec / 1e12
+    gbs = d["bytes"] / sec / 1e9
+    f_mfma, f_hbm = tf / MFMA_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
+    traffic = _pmc_bytes(pmc, name)
+    common = {"kernel": name, "traffic": traffic, "avg_launch_us": round(1000 * d["ms"] / d["launches"], 2),
+              "flops_per_launch": round(d["flops"] / d["launches"]), "bytes_per_launch": round(d["bytes"] / d["launches"]),
+              "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4)}
+    if f_mfma >= f_hbm:
+        return {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f_mfma, 4), **common}
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_hbm, 4), **common}
+
+
 def measure_roofline(model, step, B, nsteps=3):
-    """Roofline of the conv kernel (template instantiation, profiler spelling) with the largest total time.
+    """Roofline of the dominant kernel family (template instantiation, profiler spelling: the one with the largest total time),
+    plus the same entry for the conv family with the largest time among the MFMA-bound ones (`conv`), per-family times, and the
+    step's HBM traffic from the committed PMC passes.
 
     The timed region runs the weight gradients on a side stream next to the dgrad / BatchNorm chain; a kernel's duration
     then includes whatever ran beside it.  The roofline numbers are therefore taken with the kernels back to back
-    (`two_streams` off == `YH_BWD_STREAMS=0`; profiles/r01_kernel_stats_serial.csv is the rocprofv3 summary of that
+    (`two_streams` off == `YH_BWD_STREAMS=0`; profiles/r02_kernel_stats_serial.csv is the rocprofv3 summary of that
     run) — a statement about the kernel, not about the overlap; `overlapped` repeats the same kernel as it runs in the
-    timed configuration (profiles/r01_kernel_stats_bench_b64.csv)."""
+    timed configuration."""
     prog = next(iter(model._yh_state()['progs'].values()))
     two = getattr(prog, "two_streams", False)
     prog.two_streams = False
     fam, per_op = _instrument(prog, step, nsteps)
     prog.two_streams = two
     if os.environ.get("YH_BENCH_LAYERS"):
-        for ms, name, opname, flops in sorted(per_op, reverse=True)[:int(os.environ["YH_BENCH_LAYERS"])]:
-            print(f"# {ms:8.3f} ms/step  {name:28s} {opname:40s} {flops / 1e9 / max(ms, 1e-9):9.1f} TFLOP/s", file=sys.stderr)
-    conv = {k: v for k, v in fam.items() if v["flops"] > 0}
-    if not conv:
+        for ms, name, opname, flops, nbytes in sorted(per_op, reverse=True)[:int(os.environ["YH_BENCH_LAYERS"])]:
+            print(f"# {ms:8.3f} ms/step  {name:36s} {opname:44s} {flops / 1e9 / max(ms, 1e-9):8.1f} TFLOP/s {nbytes / 1e6 / max(ms, 1e-9):8.1f} GB/s",
+                  file=sys.stderr)
+    work = {k: v for k, v in fam.items() if v["ms"] > 0 and (v["flops"] > 0 or v["bytes"] > 0)}
+    if not work:
         return None
-    dom = max(conv, key=lambda k: conv[k]["ms"])
-    d = conv[dom]
-    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    pmc = _pmc_traffic()
+    dom = max(work, key=lambda k: work[k]["ms"])
+    roof = _family_roofline(dom, work[dom], pmc)
+    mfma_fams = {k: v for k, v in work.items() if v["flops"] > 0 and
+                 v["flops"] / MFMA_PEAK_TFLOPS / 1e12 >= v["bytes"] / HBM_PEAK_GBS / 1e9}
+    conv_dom = max(mfma_fams, key=lambda k: mfma_fams[k]["ms"]) if mfma_fams else None
     total_ms = sum(v["ms"] for v in fam.values()) / nsteps
     overlapped = None
     if two:
         fam2, _ = _instrument(prog, step, nsteps)
         d2 = fam2.get(dom)
         if d2 and d2["ms"] > 0:
-            a2 = d2["flops"] / (d2["ms"] * 1e-3) / 1e12
-            overlapped = {"achieved": round(a2, 2), "frac": round(a2 / MFMA_PEAK_TFLOPS, 4),
-                          "avg_launch_us": round(1000 * d2["ms"] / d2["launches"], 2),
+            o = _family_roofline(dom, d2, None)
+            overlapped = {"achieved": o["achieved"], "frac": o["frac"], "avg_launch_us": o["avg_launch_us"],
                           "engine_kernel_ms_per_step": round(sum(v["ms"] for v in fam2.values()) / nsteps, 3)}
-    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py; counters
-    # cannot be read from inside the process), null when not collected
-    traffic = None
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError, KeyError):
-        pass
-    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "mode": "kernels back to back (side stream off)",
-            "flops_per_launch": round(d["flops"] / d["launches"]), "overlapped": overlapped,
-            "avg_launch_us": round(1000 * d["ms"] / d["launches"], 2), "launches_per_step": d["launches"] // nsteps,
-            "family_ms_per_step": {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
-            "engine_kernel_ms_per_step": round(total_ms, 3)}
+    roof.update({"mode": "kernels back to back (side stream off)", "launches_per_step": work[dom]["launches"] // nsteps,
+                 "overlapped": overlapped})
+    if conv_dom is not None:
+        roof["conv"] = _family_roofline(conv_dom, mfma_fams[conv_dom], pmc)
+        roof["conv"]["ms_per_step"] = round(mfma_fams[conv_dom]["ms"] / nsteps, 3)
+    # all MFMA work of the step against the time its kernels take (weighted mean over the conv / wgrad families)
+    cf = sum(v["flops"] for v in work.values())
+    cms = sum(v["ms"] for v in work.values() if v["flops"] > 0)
+    roof["conv_kernels_tflops"] = round(cf / (cms * 1e-3) / 1e12, 2) if cms > 0 else None
+    roof["algorithmic_hbm_bytes_per_step"] = round(sum(v["bytes"] for v in work.values()) / nsteps)
+    # whole step (engine kernels + loss + optimizer + packing) as the PMC passes saw it; null when the file is stale or absent
+    roof["hbm_bytes_per_step"] = round(pmc["hbm_bytes_per_step"]) if pmc is not None and pmc.get("hbm_bytes_per_step") else None
+    roof["family_ms_per_step"] = {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+    roof["engine_kernel_ms_per_step"] = round(total_ms, 3)
+    return roof
 
 
 if __name__ == "__main__":

@@ -131,6 +131,7 @@ typedef struct yh_wgrad_desc {
     int32_t  B, Ho, Wo, Hi, Wi, KH, KW, stride, pad;
     float*   dw;                      /* [N][KH*KW*Ctot] fp32, accumulated          */
     int32_t  splits;                  /* split of the M (pixel) reduction, >=1      */
+    int32_t  tile_k;                  /* launch tuning: 64 = 64-pixel k-steps on the wide 64-row tilings (0 / 32: default) */
 } yh_wgrad_desc;
 int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
 const char* yh_conv_wgrad_kernel_name(int N, int Kseg);   /* instantiation used for a layer, profiler spelling */

@@ -122,8 +122,8 @@ def test_conv_dgrad(dev, B, H, W, Cin, Cout, k, s, p):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CASES)
-@pytest.mark.parametrize("splits", [1, 5])
-def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits):
+@pytest.mark.parametrize("splits,tile_k", [(1, 0), (5, 0), (3, 64)])
+def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits, tile_k):
     from yoloseries_amd import hipk
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     ldg = ((Cout + 7) // 8) * 8
@@ -132,6 +132,7 @@ def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits):
     x = _nhwc(B, H, W, Cin, dev, 11)
     dw = torch.zeros(Cout, k * k * Cin, device=dev)
     d = hipk.wgrad_desc(hipk.full(gyb), Cout, hipk.full(x), 0, Cin, B, Ho, Wo, H, W, k, s, p, dw, splits)
+    d.tile_k = tile_k                    # 64-pixel k-steps where the layer's tiling has that variant, ignored elsewhere
     hipk.wgrad_launch(d)
     torch.cuda.synchronize()
     w = torch.zeros(Cout, Cin, k, k, device=dev, requires_grad=True)

@@ -45,7 +45,7 @@ class WgradDesc(C.Structure):
         ("seg", Seg), ("coff_k", C.c_int32), ("Ctot", C.c_int32),
         ("B", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-        ("dw", C.c_void_p), ("splits", C.c_int32),
+        ("dw", C.c_void_p), ("splits", C.c_int32), ("tile_k", C.c_int32),
     ]
 
 

@@ -299,7 +299,11 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     k.pointwise = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->seg.ups) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = k.Kseg <= 384;
-    const int TK = wide ? 32 : 64;
+    // pixels per k-step: 32 for the wide tilings (more resident blocks), 64 when asked for (d->tile_k == 64: half the barriers and
+    // twice the loads in flight per thread; the engine times both per layer) and for the general tiles
+    const int cfg = wg_config(d->N, k.Kseg);
+    const bool tk64 = wide && d->tile_k == 64 && (cfg == 2 || cfg == 3);
+    const int TK = (wide && !tk64) ? 32 : 64;
     int splits = d->splits;
     int rps = (int)((M + splits - 1) / splits);
     rps = ((rps + TK - 1) / TK) * TK;
@@ -312,14 +316,14 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
         conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_><<<grid, dim3(WN_ * WC_ * 64), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
     } while (0)
     k.ctiles = wide ? 1 : (k.Kseg + 127) / 128;
-    switch (wg_config(d->N, k.Kseg)) {
+    switch (cfg) {
     case 0:
         if (k.Kseg <= 160) YH_WG(1, 5, 1, 1, 32, 3, (d->N + 31) / 32);        // stem: 5 waves x one 32-column tile (144 of 160 used)
         else               YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32);
         break;
     case 1: YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32); break;
-    case 2: YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64); break;
-    case 3: YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64); break;
+    case 2: if (tk64) YH_WG(1, 4, 2, 1, 64, 2, (d->N + 63) / 64); else YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64); break;
+    case 3: if (tk64) YH_WG(1, 4, 2, 2, 64, 2, (d->N + 63) / 64); else YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64); break;
     case 4: YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64); break;
     case 5: YH_WG(2, 2, 1, 2, 64, 3, (d->N + 63) / 64); break;
     default: YH_WG(4, 2, 1, 2, 64, 4, (d->N + 127) / 128); break;      // 8 waves of 32 x 64 (measured 5% over 4 waves of 64 x 64)

@@ -482,7 +482,7 @@ class Program:
             if isinstance(op, PoolOp):
                 s, dd = op.src.sl(), op.dst.sl()
                 args = (s.ptr(), s.ld, B, op.src.buf.H, op.src.buf.W, s.C, dd.ptr(), dd.ld, None)
-                self.cmd_eval.append((L.yh_maxpool5_fwd, args, op.name, ('yh_maxpool5_fwd', 0)))
+                self.cmd_eval.append((L.yh_maxpool5_fwd, args, op.name, ('yh_maxpool5_fwd', 0, 4.0 * B * op.src.buf.H * op.src.buf.W * s.C)))
                 continue
             st = {}
             self.op_state[op.name] = st
@@ -502,7 +502,7 @@ class Program:
             for (conv, bn), n in zip(op.parts, op.part_N):
                 self.cmd_eval.append((L.yh_bn_fold, (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                                                      bn.running_var.data_ptr(), float(bn.eps), n,
-                                                     st['fold'].data_ptr() + 4 * c0, st['fold'].data_ptr() + 4 * (op.N + c0)), op.name, ('yh_bn_fold', 0)))
+                                                     st['fold'].data_ptr() + 4 * c0, st['fold'].data_ptr() + 4 * (op.N + c0)), op.name, ('yh_bn_fold', 0, 0.0)))
                 c0 += n
             de.scale, de.shift = st['fold'].data_ptr(), st['fold'].data_ptr() + 4 * op.N
             de.act = YH_ACT_SILU
@@ -532,7 +532,7 @@ class Program:
                 op.idx = torch.zeros(B, op.src.buf.H, op.src.buf.W, op.src.C, dtype=torch.int8, device=self.dev)
                 s, dd = op.src.sl(), op.dst.sl()
                 args = (s.ptr(), s.ld, B, op.src.buf.H, op.src.buf.W, s.C, dd.ptr(), dd.ld, op.idx.data_ptr())
-                self.cmd_train.append((L.yh_maxpool5_fwd, args, op.name, ('yh_maxpool5_fwd', 0)))
+                self.cmd_train.append((L.yh_maxpool5_fwd, args, op.name, ('yh_maxpool5_fwd', 0, 5.0 * B * op.src.buf.H * op.src.buf.W * s.C)))
                 continue
             M = B * op.Ho * op.Wo
             st = self.op_state[op.name]
@@ -557,12 +557,12 @@ class Program:
                 self.cmd_train.append((L.yh_bn_finalize, (
                     st['stats'].data_ptr() + 4 * c0, nblk, op.Npad, n, M, bn.weight.data_ptr(), bn.bias.data_ptr(),
                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(),
-                    float(bn.eps), float(mom), ws.data_ptr()), op.name, ('yh_bn_finalize', 0)))
+                    float(bn.eps), float(mom), ws.data_ptr()), op.name, ('yh_bn_finalize', 0, 8.0 * nblk * n)))
                 dst = op.outs[pi].sl()
                 res = op.res.sl() if (op.res is not None and pi == 0) else None
                 self.cmd_train.append((L.yh_bn_silu_apply, (
                     op.y.t.data_ptr() + 2 * c0, op.y.C, ws.data_ptr(), n, M, dst.ptr(), dst.ld,
-                    res.ptr() if res else None, res.ld if res else 0), op.name, ('yh_bn_silu_apply', 0)))
+                    res.ptr() if res else None, res.ld if res else 0), op.name, ('yh_bn_silu_apply', 0, (6.0 if res else 4.0) * M * n)))
                 c0 += n
 
     # -- forward ---------------------------------------------------------------------------
@@ -577,9 +577,17 @@ class Program:
         check(rc, "yh_conv_kernel_name")
         return buf.value.decode()
 
+    @staticmethod
+    def _conv_bytes(d):
+        """algorithmic HBM bytes of one yh_conv_igemm launch: every input segment read once, the output written once (read too when
+        it accumulates), residual / fused-reduction operands read once; weights are negligible next to the activations"""
+        rd = sum(2.0 * d.B * (d.Hi >> d.seg[i].ups) * (d.Wi >> d.seg[i].ups) * d.seg[i].C for i in range(d.nseg))
+        out = 2.0 * d.B * d.Ho * d.Wo * d.N
+        return rd + out * (2.0 if d.accumulate else 1.0) + (out * min(1.0, d.nsplit / max(d.N, 1)) if d.res else 0.0) + (out if d.bnr_part else 0.0)
+
     def _fam_conv(self, op, d):
         M = self.B * op.Ho * op.Wo
-        return (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else op.Ctot))
+        return (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else op.Ctot), self._conv_bytes(d))
 
     def _run(self, cmds):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -698,7 +706,7 @@ class Program:
                 acc = claim(op.src)
                 go, gi = op.dst.sl(True), op.src.sl(True)
                 cmds.append((L.yh_maxpool5_bwd, (go.ptr(), go.ld, op.idx.data_ptr(), B, op.src.buf.H, op.src.buf.W, go.C,
-                                                 gi.ptr(), gi.ld, acc), op.name, ('yh_maxpool5_bwd', 0)))
+                                                 gi.ptr(), gi.ld, acc), op.name, ('yh_maxpool5_bwd', 0, (7.0 if acc else 5.0) * B * op.src.buf.H * op.src.buf.W * go.C)))
                 continue
             M = B * op.Ho * op.Wo
             st = self.op_state[op.name]
@@ -706,14 +714,14 @@ class Program:
             gys = self.gy_scratch
             if op.kind == 'cba':
                 gys = self.gy_ring[n_cba % NGZ]
-                cmds.append(('gz_begin', n_cba % NGZ, None, ('sync', 0)))       # main stream: wait until this gz buffer's last wgrad is done
+                cmds.append(('gz_begin', n_cba % NGZ, None, ('sync', 0, 0.0)))       # main stream: wait until this gz buffer's last wgrad is done
                 n_cba += 1
             if op.kind == 'plain':
                 # gradient arrives in op.y.g (set per call); bias grad = column sums
                 st['gy_ref'] = 'head'
                 gy_ptr_holder = st
                 conv = op.parts[0][0]
-                cmds.append(('head_colsum', op, pk.bias_g.get((op.name, 0)), ('yh_colsum', 0)))
+                cmds.append(('head_colsum', op, pk.bias_g.get((op.name, 0)), ('yh_colsum', 0, 2.0 * M * op.y.C)))
                 gy_ld, gyN = op.y.C, op.N
                 gy_sl = None
             else:
@@ -732,11 +740,11 @@ class Program:
                         part_ptr, nblk = fused[0].data_ptr(), fused[1]
                     else:
                         cmds.append((L.yh_bn_silu_bwd_reduce, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), n, M,
-                                                               part_ptr), op.name, ('yh_bn_silu_bwd_reduce', 0)))
+                                                               part_ptr), op.name, ('yh_bn_silu_bwd_reduce', 0, 4.0 * M * n)))
                     goff, boff = pk.bn_g[(op.name, pi)]
                     cmds.append((L.yh_bn_bwd_finalize, (part_ptr, nblk, n, M, ws.data_ptr(),
                                                         pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
-                                                        coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0)))
+                                                        coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0, 8.0 * nblk * n)))
                     gres_ptr, gres_ld, gres_acc = None, 0, 0
                     if op.res is not None and pi == 0 and op.res.buf.needs_grad:
                         gres_acc = claim(op.res)
@@ -744,11 +752,12 @@ class Program:
                         gres_ptr, gres_ld = gr.ptr(), gr.ld
                     cmds.append((L.yh_bn_silu_bwd_apply, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), bn.weight.data_ptr(),
                                                           coef.data_ptr(), n, M, gys.data_ptr() + 2 * c0, op.N,
-                                                          gres_ptr, gres_ld, gres_acc), op.name, ('yh_bn_silu_bwd_apply', 0)))
+                                                          gres_ptr, gres_ld, gres_acc), op.name,
+                                 ('yh_bn_silu_bwd_apply', 0, (6.0 + (4.0 if gres_acc else 2.0) * (gres_ptr is not None)) * M * n)))
                     c0 += n
                 gy_ld, gyN = op.N, op.N
             # wgrad per segment (side stream: starts when gz is ready)
-            cmds.append(('wg_begin', None, None, ('sync', 0)))
+            cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
             coff_k = 0
             for si, sg in enumerate(op.segs):
                 wd = WgradDesc()
@@ -763,9 +772,10 @@ class Program:
                 ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
                 wd.splits = self._tune_wgrad_splits(wd, M, ntile, op)
                 self._keep.append(wd)
-                cmds.append(('wgrad', op, wd, (L.yh_conv_wgrad_kernel_name(gyN, op.k * op.k * sg.C).decode(), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C))))
+                cmds.append(('wgrad', op, wd, (self._wgrad_name(L, wd), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C),
+                                               2.0 * M * gy_ld + 2.0 * B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.C)))
                 coff_k += sg.C
-            cmds.append(('wg_end', (n_cba - 1) % NGZ if op.kind == 'cba' else None, None, ('sync', 0)))
+            cmds.append(('wg_end', (n_cba - 1) % NGZ if op.kind == 'cba' else None, None, ('sync', 0, 0.0)))
             # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
             marks.append((len(cmds), pk.gloc[op.name]))
             # dgrad per segment
@@ -792,8 +802,9 @@ class Program:
                     gl = Slice(sg.buf.g, sg.coff, sg.C)
                     self._keep.append(d)
                     self._tune_conv(d, 'dgrad', op.name)
-                    cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C)))
-                    cmds.append((L.yh_upsample2_bwd, (tmp.data_ptr(), sg.C, B, sg.buf.H, sg.buf.W, sg.C, gl.ptr(), gl.ld, acc), op.name, ('yh_upsample2_bwd', 0)))
+                    cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C, self._conv_bytes(d))))
+                    cmds.append((L.yh_upsample2_bwd, (tmp.data_ptr(), sg.C, B, sg.buf.H, sg.buf.W, sg.C, gl.ptr(), gl.ld, acc), op.name,
+                                 ('yh_upsample2_bwd', 0, (2.0 + (1.0 if acc else 0.5)) * B * op.Hi * op.Wi * sg.C)))
                 else:
                     acc = claim(Ref(sg.buf, sg.coff, sg.C))
                     gl = Slice(sg.buf.g, sg.coff, sg.C)
@@ -816,50 +827,65 @@ class Program:
                         slab = torch.zeros(rows * 2 * sg.C, dtype=torch.float32, device=self.dev)
                         d.bnr_part = slab.data_ptr()
                         self.bnr_fused[(po.name, ppi)] = (slab, rows)
-                    cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C)))
+                    cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C, self._conv_bytes(d))))
         self.cmd_bwd = cmds
         self.bwd_buckets = plan_grad_buckets(marks, pk.gsize, int(os.environ.get("YH_DP_BUCKETS", "4")))
         self.bwd_ready = True
         _tune_cache_save()
 
     def _tune_wgrad_splits(self, wd, M, ntile, op):
-        """Split-M factor of one weight-gradient launch.  The best total block count depends on the tile
-        configuration's residency and on how the atomics of the epilogue amortise (measured 256..1024 blocks,
-        up to 1.6x apart), so it is timed once per layer when the backward program is built
-        (YH_WGRAD_TUNE=0: fixed 512-block rule)."""
+        """Split-M factor (and, for the wide 64-row tilings, the pixels per k-step) of one weight-gradient launch.  The best
+        total block count depends on the tile configuration's residency and on how the atomics of the epilogue amortise
+        (measured 256..1024 blocks, up to 1.6x apart), so it is timed once per layer when the backward program is built
+        (YH_WGRAD_TUNE=0: fixed 512-block rule).  Sets wd.tile_k, returns the split factor."""
         def splits_for(total):
             return max(1, min((M + 255) // 256, (total + ntile - 1) // ntile))
         if os.environ.get("YH_WGRAD_TUNE", "1") == "0":
             return splits_for(512)
-        key = "wgrad:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
-                                                         wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad))
+        key = "wgrad2:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
+                                                          wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad))
         cache = _tune_cache()
         if key in cache:
-            return int(cache[key])
+            sp, wd.tile_k = (int(v) for v in cache[key])
+            return sp
         gy_saved = wd.gy
         if not wd.gy:                      # head gradient arrives at run time: time against the scratch buffer
             if self.gy_scratch.numel() < M * wd.ldg:
                 return splits_for(512)
             wd.gy = self.gy_scratch.data_ptr()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        name = self.L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
+        tks = (0, 64) if name in ("conv_wgrad_kernel<1, 4, 2, 1, 32, 4>", "conv_wgrad_kernel<1, 4, 2, 2, 32, 3>") else (0,)
         best, best_ms = None, None
-        for sp in sorted({splits_for(t) for t in (256, 512, 768, 1024, 1536)}):
-            wd.splits = sp
-            check(self.L.yh_conv_wgrad(C.byref(wd), st), f"yh_conv_wgrad tune [{op.name}]")
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                self.L.yh_conv_wgrad(C.byref(wd), st)
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1)
-            if best_ms is None or ms < best_ms:
-                best, best_ms = sp, ms
+        for tk in tks:
+            wd.tile_k = tk
+            for sp in sorted({splits_for(t) for t in (256, 512, 768, 1024, 1536)}):
+                wd.splits = sp
+                check(self.L.yh_conv_wgrad(C.byref(wd), st), f"yh_conv_wgrad tune [{op.name}]")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    self.L.yh_conv_wgrad(C.byref(wd), st)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if best_ms is None or ms < best_ms:
+                    best, best_ms = (sp, tk), ms
         wd.gy = gy_saved
-        self.wgrad_tuned[(op.name, wd.coff_k)] = (best, best_ms / 3)
-        cache[key] = int(best)
+        wd.tile_k = best[1]
+        self.wgrad_tuned[(op.name, wd.coff_k)] = (best[0], best_ms / 3)
+        cache[key] = [int(best[0]), int(best[1])]
         _tune_cache.dirty = True
-        return best
+        return best[0]
+
+    @staticmethod
+    def _wgrad_name(L, wd):
+        """instantiation yh_conv_wgrad launches for this descriptor, profiler spelling (64-pixel k-steps on the wide tilings:
+        csrc/conv_wgrad.hip, yh_conv_wgrad)"""
+        name = L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
+        if wd.tile_k == 64 and name in ("conv_wgrad_kernel<1, 4, 2, 1, 32, 4>", "conv_wgrad_kernel<1, 4, 2, 2, 32, 3>"):
+            name = name.replace("32, 4>", "64, 2>").replace("32, 3>", "64, 2>")
+        return name
 
     def _bucket_ready(self, bucket_hook, bucket, main, side):
         """hand a finished gradient bucket to the data-parallel hook.  With the side stream, the bucket's weight gradients
