@@ -108,7 +108,19 @@ typedef struct yh_conv_desc {
     const yh_bf16* bnr_z; int32_t bnr_ldz; int32_t bnr_C;
     const float* bnr_ws;
     float*   bnr_part;
+    /* acc_rows > 0: `stats` / `bnr_part` are not fp32 slabs but int64 fixed-point ACCUMULATORS, [acc_rows][2][Npad] resp.
+     * [acc_rows][2][N] (zeroed by the caller before the launch): every block adds its partial sums, scaled by 2^YH_STAT_SHIFT_FWD
+     * resp. 2^YH_STAT_SHIFT_BWD and rounded, to row (block index % acc_rows) with 64-bit integer atomics — associative, so the
+     * totals do not depend on the arrival order.  The consumer passes (yh_bn_silu_apply_acc, yh_bn_silu_bwd_apply_acc) reduce the
+     * few rows in their prologue: no finalize launch.  32 adders per address run at the full atomic rate (16 rows, 512 blocks). */
+    int32_t  acc_rows;
+    int32_t  reserved1;
 } yh_conv_desc;
+#define YH_ACC_ROWS 16           /* most accumulator rows a consumer pass reduces (acc_rows <= YH_ACC_ROWS) */
+#define YH_STAT_SHIFT_FWD 24     /* sums of z, z*z over up to 2^23 pixels: resolution 6e-8, range +-5e11 */
+#define YH_STAT_SHIFT_BWD 40     /* sums of dz, dz*z: resolution 9e-13, range +-8e6 */
+#define YH_STAT_SCALE_FWD 16777216.0f
+#define YH_STAT_SCALE_BWD 1099511627776.0f
 
 /* number of partial-sum rows the conv kernel writes for this shape */
 int yh_conv_stat_blocks(const yh_conv_desc* d);
@@ -222,6 +234,24 @@ int yh_sumsq(const float* x, int64_t n, float* part, float* out, yh_stream strea
 int yh_clip_scale(const float* sumsq, float max_norm, float* out, yh_stream stream);
 /* EMA: e = d*e + (1-d)*p over a flat arena (trainer/ema_model.py:20-28)         */
 int yh_ema_update(float* ema, const float* p, int64_t n, float decay, yh_stream stream);
+
+/* ---- BatchNorm passes fed by the int64 accumulators (yh_conv_desc.acc_rows): the finalize step is the prologue of the pass ----
+ * acc: [rows][2][ldacc] int64 (sum | sum of squares, scaled 2^YH_STAT_SHIFT_FWD), channel c of this BatchNorm at acc[..][c].
+ * Every block reduces the rows for all C channels (rows*2*C 8-byte loads from L2), derives scale / shift; block 0 also writes
+ * ws = scale | shift | mean | invstd (4*C floats, read by the backward) and updates the running statistics (momentum, unbiased
+ * variance, utils/layer_tools.py:87-91 in training mode).  Then out = silu(y*scale+shift) (+res) like yh_bn_silu_apply. */
+int yh_bn_silu_apply_acc(const yh_bf16* y, int ldy, const int64_t* acc, int rows, int ldacc, int C, int64_t M,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                         float eps, float momentum, float* ws, yh_bf16* out, int ldo, const yh_bf16* res, int ldr, yh_stream stream);
+/* column reduction of the BatchNorm+SiLU backward (sum dz | sum dz*z, dz = g*silu'(y*scale+shift)) added into acc [rows][2][C]
+ * int64, scaled 2^YH_STAT_SHIFT_BWD (same role as yh_bn_silu_bwd_reduce; used where no data gradient fuses the reduction) */
+int yh_bn_silu_bwd_reduce_acc(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy, const float* ws, int C, int64_t M,
+                              int64_t* acc, int rows, yh_stream stream);
+/* BatchNorm+SiLU backward apply with the finalize in its prologue: sums from acc [rows][2][C] (yh_conv_desc.bnr_part in accumulator
+ * mode, or yh_bn_silu_bwd_reduce_acc), dgamma / dbeta written by block 0, then gy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) */
+int yh_bn_silu_bwd_apply_acc(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy, const float* ws, const float* gamma,
+                             const int64_t* acc, int rows, int C, int64_t M, float* dgamma, float* dbeta,
+                             yh_bf16* gy, int ldgy, yh_bf16* gres, int ldgres, int gres_acc, yh_stream stream);
 
 /* ------------------------------------------------------------------------ *
  * YOLOv5 loss (loss/yolov5_loss.py:30-235)

@@ -167,3 +167,37 @@ def test_arena_kernels(dev):
     e = torch.randn(n, device=dev); e0 = e.clone()
     hipk.ema_update(e, src, 0.99)
     assert torch.allclose(e, 0.99 * e0 + 0.01 * src, rtol=1e-5, atol=1e-6)
+
+
+def test_bn_accumulator_path_matches_slab_path(dev):
+    """YH_BN_ACC=1 (int64 fixed-point accumulator rows filled by the conv kernels with 64-bit atomics, reduced in the prologue of
+    the BN+SiLU passes: yh_conv_desc.acc_rows, yh_bn_silu_apply_acc, yh_bn_silu_bwd_reduce_acc, yh_bn_silu_bwd_apply_acc) gives the
+    same forward, running statistics and gradients as the default slab + finalize path on a C3 block"""
+    import importlib
+    import os
+    import numpy as np
+    from yoloseries_amd import engine
+    from yoloseries_amd import utils as U
+    res = {}
+    for acc in (False, True):
+        old = engine.BN_ACC
+        engine.BN_ACC = acc
+        try:
+            torch.manual_seed(0)
+            mod = U.C3BottleneckCSP(64, 64, shortcut=True, num_block=2).to(dev).train()
+            x = torch.from_numpy(np.random.RandomState(5).randn(4, 64, 32, 32).astype(np.float32)).to(dev).requires_grad_(True)
+            y = mod(x)
+            go = torch.from_numpy(np.random.RandomState(6).randn(*y.shape).astype(np.float32)).to(dev)
+            grads = torch.autograd.grad(y, [x] + list(mod.parameters()), go)
+            res[acc] = (y.detach().float().cpu(), [g.detach().float().cpu() for g in grads],
+                        {k: v.detach().float().cpu() for k, v in mod.state_dict().items() if "running" in k})
+        finally:
+            engine.BN_ACC = old
+    y0, g0, b0 = res[False]
+    y1, g1, b1 = res[True]
+    # statistics differ only by the fixed-point rounding of the per-block partial sums (2^-24 / 2^-40 absolute)
+    assert (y0 - y1).abs().max() <= 2e-2 * y0.abs().max()
+    for k in b0:
+        torch.testing.assert_close(b1[k], b0[k], rtol=1e-4, atol=1e-5)
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max() <= 3e-2 * b.abs().max() + 1e-6

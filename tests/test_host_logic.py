@@ -31,7 +31,7 @@ def test_ctypes_struct_sizes_match_header_layout():
     import ctypes as C
     from yoloseries_amd import _lib
     assert C.sizeof(_lib.Seg) == 24
-    assert C.sizeof(_lib.ConvDesc) == 2 * 24 + 4 * 2 + 4 * 9 + 4 + 8 + 8 + 8 * 3 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8
+    assert C.sizeof(_lib.ConvDesc) == 2 * 24 + 4 * 2 + 4 * 9 + 4 + 8 + 8 + 8 * 3 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8
     assert C.sizeof(_lib.V5LossDesc) == 4 * 5 + 32 + 8 + 96 + 4 * 4 + 4 * 3 + 12 + 4 + 16 + 4
     assert C.sizeof(_lib.DecodeDesc) == 16 + 32 + 16 + 96 + 4 + 16 + 4
 

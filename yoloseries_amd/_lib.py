@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("stats", C.c_void_p),
         ("tile_n", C.c_int32), ("grid_cap", C.c_int32), ("tile_k", C.c_int32), ("algo", C.c_int32),
         ("bnr_z", C.c_void_p), ("bnr_ldz", C.c_int32), ("bnr_C", C.c_int32), ("bnr_ws", C.c_void_p), ("bnr_part", C.c_void_p),
+        ("acc_rows", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -111,6 +112,9 @@ _SIGS = {
     "yh_bn_finalize": (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
     "yh_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
     "yh_bn_silu_apply": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "yh_bn_silu_apply_acc": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _i32, _vp]),
+    "yh_bn_silu_bwd_reduce_acc": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp]),
+    "yh_bn_silu_bwd_apply_acc": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "yh_ew_blocks": (_i32, [_i64]),
     "yh_bn_silu_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp]),
     "yh_bn_bwd_finalize": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -43,6 +43,27 @@ struct ConvK {
                    // k-steps only, 256 no stem kernel (the ablation masks are compile-time: make ablate ABL=mask)
 };
 
+// Per-block partial sums leave the kernel either as one fp32 slab row per block (deterministic fixed-order reduction by
+// yh_bn_finalize / yh_bn_bwd_finalize) or, with d.acc_rows > 0, as 64-bit fixed-point atomic adds into acc_rows accumulator rows
+// (row = block % acc_rows; integer addition is associative, so the result is still independent of the arrival order): the few
+// rows are then reduced in the prologue of the consumer pass itself and the finalize launches disappear (include/yolohip.h).
+__device__ __forceinline__ void put_stat(const yh_conv_desc& d, size_t blk, int which, int n, float v)
+{
+    if (d.acc_rows > 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(d.stats) + ((blk % (size_t)d.acc_rows) * 2 + which) * (size_t)d.Npad + n,
+                  (unsigned long long)__float2ll_rn(v * YH_STAT_SCALE_FWD));
+    else
+        d.stats[(blk * 2 + which) * d.Npad + n] = v;
+}
+__device__ __forceinline__ void put_bnr(const yh_conv_desc& d, size_t row, int which, int n, float v)
+{
+    if (d.acc_rows > 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(d.bnr_part) + ((row % (size_t)d.acc_rows) * 2 + which) * (size_t)d.N + n,
+                  (unsigned long long)__float2ll_rn(v * YH_STAT_SCALE_BWD));
+    else
+        d.bnr_part[(row * 2 + which) * d.N + n] = v;
+}
+
 template <int BN, int WM, int WN, bool FAST, int MINW>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
 {
@@ -341,8 +362,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
     }
 
     if (d.stats && t < BN) {
-        d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
-        d.stats[((size_t)blockIdx.x * 2 + 1) * d.Npad + n0 + t] = run_q;
+        put_stat(d, blockIdx.x, 0, n0 + t, run_s);
+        put_stat(d, blockIdx.x, 1, n0 + t, run_q);
     }
 }
 
@@ -760,8 +781,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
 #undef STAMP
 
     if (EPI == 1 && t < BN) {
-        d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
-        d.stats[((size_t)blockIdx.x * 2 + 1) * d.Npad + n0 + t] = run_q;
+        put_stat(d, blockIdx.x, 0, n0 + t, run_s);
+        put_stat(d, blockIdx.x, 1, n0 + t, run_q);
     }
     if (EPI == 3) {
         constexpr int CPR2 = BN / 8;
@@ -775,7 +796,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
             const int which = i / BN, c = i - which * BN;
             float v = 0.f;
             for (int j = c / 8; j < NT; j += CPR2) v += sRed[j * 16 + which * 8 + (c & 7)];
-            if (n0 + c < d.N) d.bnr_part[(rowi * 2 + which) * d.N + n0 + c] = v;
+            if (n0 + c < d.N) put_bnr(d, rowi, which, n0 + c, v);
         }
     }
 }
@@ -1134,8 +1155,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
     }
 
     if (EPI == 1 && t < BN) {
-        d.stats[((size_t)blockIdx.x * 2 + 0) * d.Npad + n0 + t] = run_s;
-        d.stats[((size_t)blockIdx.x * 2 + 1) * d.Npad + n0 + t] = run_q;
+        put_stat(d, blockIdx.x, 0, n0 + t, run_s);
+        put_stat(d, blockIdx.x, 1, n0 + t, run_q);
     }
     if (EPI == 3) {
         constexpr int CPR2 = BN / 8;
@@ -1149,7 +1170,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
             const int which = i / BN, c = i - which * BN;
             float v = 0.f;
             for (int j = c / 8; j < NT; j += CPR2) v += sRed[j * 16 + which * 8 + (c & 7)];
-            if (n0 + c < d.N) d.bnr_part[(rowi * 2 + which) * d.N + n0 + c] = v;
+            if (n0 + c < d.N) put_bnr(d, rowi, which, n0 + c, v);
         }
     }
 }
@@ -1574,8 +1595,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
             const int which = i / BN, c = i - which * BN;
             float v = 0.f;
             for (int j = c / 8; j < NT; j += CPR2) v += sRed[j * 16 + which * 8 + (c & 7)];
-            if (EPI == 1) d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + n0 + c] = v;
-            else if (n0 + c < d.N) d.bnr_part[((size_t)blockIdx.x * 2 + which) * d.N + n0 + c] = v;
+            if (EPI == 1) put_stat(d, blockIdx.x, which, n0 + c, v);
+            else if (n0 + c < d.N) put_bnr(d, blockIdx.x, which, n0 + c, v);
         }
     }
 }
@@ -1750,7 +1771,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvK p)
         if (t < 64) {
             const int which = t >> 5, ch = t & 31;
             const float v = sRed[0][which][ch] + sRed[1][which][ch] + sRed[2][which][ch] + sRed[3][which][ch];
-            d.stats[((size_t)blockIdx.x * 2 + which) * d.Npad + ch] = v;
+            put_stat(d, blockIdx.x, which, ch, v);
         }
     }
 }

@@ -141,6 +141,73 @@ __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, co
     }
 }
 
+// The same pass fed by int64 fixed-point accumulators (yh_conv_desc.acc_rows): every block first reduces the few accumulator rows
+// for all C channels (rows * 2 * C 8-byte loads, L2 resident) into scale / shift in LDS — the former yh_bn_finalize launch; block 0
+// additionally publishes ws (scale | shift | mean | invstd) for the backward and updates the running statistics.
+__global__ __launch_bounds__(1024) void bn_silu_apply_acc_kernel(const uint16_t* __restrict__ y, int ldy, const long long* __restrict__ acc, int rows, int ldacc,
+                                         int C, int cpr, long M, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* running_mean, float* running_var, int64_t* num_batches, float eps, float momentum,
+                                         float* __restrict__ ws, uint16_t* __restrict__ out, int ldo,
+                                         const uint16_t* __restrict__ res, int ldr)
+{
+    extern __shared__ float s_cst[];                 // [2][C]: scale | shift
+    const double count = (double)M;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        // all row loads in flight together (a rolled loop pays one L2 round trip per row: 16 us per launch)
+        long long vs[YH_ACC_ROWS], vq[YH_ACC_ROWS];
+#pragma unroll
+        for (int r = 0; r < YH_ACC_ROWS; ++r) {
+            vs[r] = r < rows ? acc[((size_t)r * 2 + 0) * ldacc + c] : 0;
+            vq[r] = r < rows ? acc[((size_t)r * 2 + 1) * ldacc + c] : 0;
+        }
+        long long s = 0, q = 0;
+#pragma unroll
+        for (int r = 0; r < YH_ACC_ROWS; ++r) { s += vs[r]; q += vq[r]; }
+        const double mean = (double)s * (1.0 / (double)YH_STAT_SCALE_FWD) / count;
+        double var = (double)q * (1.0 / (double)YH_STAT_SCALE_FWD) / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float scale = gamma[c] * invstd;
+        const float shift = beta[c] - (float)mean * scale;
+        s_cst[c] = scale;
+        s_cst[C + c] = shift;
+        if (blockIdx.x == 0) {
+            ws[c] = scale; ws[C + c] = shift; ws[2 * C + c] = (float)mean; ws[3 * C + c] = invstd;
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+            if (c == 0 && num_batches) *num_batches += 1;
+        }
+    }
+    __syncthreads();
+    const long T = (long)gridDim.x * blockDim.x;
+    const long rstep = T / cpr;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rstep * cpr) return;
+    long m = gid / cpr;
+    const int c = (int)(gid - m * cpr) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = s_cst[c + e]; sh[e] = s_cst[C + c + e]; }
+    for (; m < M; m += rstep) {
+        uint4 v = *reinterpret_cast<const uint4*>(y + m * ldy + c);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e] * sc[e] + sh[e]);
+        if (res) {
+            uint4 rv = *reinterpret_cast<const uint4*>(res + m * ldr + c);
+            float g[8];
+            unpack8(rv, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bf_round(f[e]) + g[e];
+        }
+        *reinterpret_cast<uint4*>(out + m * ldo + c) = pack8(f);
+    }
+}
+
 // ---------------------------------------------------------------- column reductions
 // Block b owns rows [b*rpb, (b+1)*rpb).  Thread (rg, cch) accumulates 8 channels over
 // rows rg, rg+RG, ...; row groups are combined through LDS.
@@ -150,7 +217,7 @@ template <int MODE>   // 0: BN+SiLU backward sums (gz, gz*xhat) ; 1: plain colum
 __global__ __launch_bounds__(RED_THREADS, 4) void col_reduce_kernel(const uint16_t* __restrict__ ga, int ldga,
                                                                  const uint16_t* __restrict__ y, int ldy,
                                                                  const float* __restrict__ ws, int C, int cpr,
-                                                                 long M, long rpb, float* __restrict__ part)
+                                                                 long M, long rpb, float* __restrict__ part, int acc_rows)
 {
     __shared__ float sP[RED_THREADS * 16];
     const int t = threadIdx.x;
@@ -236,7 +303,11 @@ __global__ __launch_bounds__(RED_THREADS, 4) void col_reduce_kernel(const uint16
         int cc = i - which * C;
         float s = 0.f;
         for (int r = 0; r < RG; ++r) s += sP[(r * 2 + which) * C + cc];
-        part[((size_t)blockIdx.x * 2 + which) * C + cc] = s;
+        if (acc_rows > 0)          // int64 fixed-point accumulator rows (see put_bnr in conv_igemm.hip): order independent
+            atomicAdd(reinterpret_cast<unsigned long long*>(part) + (((size_t)blockIdx.x % acc_rows) * 2 + which) * C + cc,
+                      (unsigned long long)__float2ll_rn(s * YH_STAT_SCALE_BWD));
+        else
+            part[((size_t)blockIdx.x * 2 + which) * C + cc] = s;
     }
 }
 
@@ -289,6 +360,84 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
     for (; m < M; m += rstep) {
         // last readers of both tensors: streamed (non-temporal), they should not displace the gz rows written below,
         // which the weight- and data-gradient kernels read next
+        uint4 gv = ld_nt(ga + m * ldga + c);
+        uint4 yv = ld_nt(y + m * ldy + c);
+        float g[8], yy[8], o[8];
+        unpack8(gv, g);
+        unpack8(yv, yy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float z = yy[e] * sc[e] + sh[e];
+            float sg = sigmoid_fast(z);
+            float dz = g[e] * (sg * (1.f + z * (1.f - sg)));
+            o[e] = A[e] * dz + (Bc[e] * yy[e] + D[e]);
+        }
+        *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
+        if (gres) {
+            uint16_t* dst = gres + m * ldgres + c;
+            if (gres_acc) {
+                uint4 ov = *reinterpret_cast<const uint4*>(dst);
+                float f[8];
+                unpack8(ov, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += g[e];
+                *reinterpret_cast<uint4*>(dst) = pack8(f);
+            } else {
+                *reinterpret_cast<uint4*>(dst) = gv;
+            }
+        }
+    }
+}
+
+// bn_silu_bwd_apply with the former yh_bn_bwd_finalize launch as its prologue: the int64 accumulator rows (sum dz | sum dz*z,
+// scaled 2^YH_STAT_SHIFT_BWD; filled by the data gradient's fused reduction or by col_reduce) are reduced per channel by every
+// block, the per-channel constants of  gz = A*dz + Bc*y + D  go to LDS, block 0 writes dgamma / dbeta.
+__global__ __launch_bounds__(1024) void bn_silu_bwd_apply_acc_kernel(const uint16_t* __restrict__ ga, int ldga, const uint16_t* __restrict__ y, int ldy,
+                                             const float* __restrict__ ws, const float* __restrict__ gamma,
+                                             const long long* __restrict__ acc, int rows, int C, int cpr, long M,
+                                             float* dgamma, float* dbeta,
+                                             uint16_t* __restrict__ gy, int ldgy, uint16_t* gres, int ldgres, int gres_acc)
+{
+    extern __shared__ float s_cst[];                 // [5][C]: scale | shift | A | Bc | D
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        long long v0[YH_ACC_ROWS], v1[YH_ACC_ROWS];
+#pragma unroll
+        for (int r = 0; r < YH_ACC_ROWS; ++r) {
+            v0[r] = r < rows ? acc[((size_t)r * 2 + 0) * C + c] : 0;
+            v1[r] = r < rows ? acc[((size_t)r * 2 + 1) * C + c] : 0;
+        }
+        long long a0 = 0, a1 = 0;
+#pragma unroll
+        for (int r = 0; r < YH_ACC_ROWS; ++r) { a0 += v0[r]; a1 += v1[r]; }
+        const double s0 = (double)a0 * (1.0 / (double)YH_STAT_SCALE_BWD);
+        const float mu = ws[2 * C + c], is = ws[3 * C + c];
+        const double s1 = (double)is * ((double)a1 * (1.0 / (double)YH_STAT_SCALE_BWD) - (double)mu * s0);      // sum(dz*y) -> sum(dz*xhat)
+        if (blockIdx.x == 0) {
+            if (dbeta) dbeta[c] = (float)s0;
+            if (dgamma) dgamma[c] = (float)s1;
+        }
+        const float c1 = (float)(s0 / (double)M), c2 = (float)(s1 / (double)M);
+        const float gi = gamma[c] * is;
+        s_cst[c] = ws[c];
+        s_cst[C + c] = ws[C + c];
+        s_cst[2 * C + c] = gi;
+        s_cst[3 * C + c] = -gi * is * c2;
+        s_cst[4 * C + c] = gi * (mu * is * c2 - c1);
+    }
+    __syncthreads();
+    const long T = (long)gridDim.x * blockDim.x;
+    const long rstep = T / cpr;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rstep * cpr) return;
+    long m = gid / cpr;
+    const int c = (int)(gid - m * cpr) * 8;
+    float sc[8], sh[8], A[8], Bc[8], D[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = s_cst[c + e]; sh[e] = s_cst[C + c + e];
+        A[e] = s_cst[2 * C + c + e]; Bc[e] = s_cst[3 * C + c + e]; D[e] = s_cst[4 * C + c + e];
+    }
+    for (; m < M; m += rstep) {
         uint4 gv = ld_nt(ga + m * ldga + c);
         uint4 yv = ld_nt(y + m * ldy + c);
         float g[8], yy[8], o[8];
@@ -539,8 +688,57 @@ extern "C" int yh_bn_silu_bwd_reduce(const yh_bf16* ga, int ldga, const yh_bf16*
     int nblk = yh_ew_blocks(M);
     long rpb = (M + nblk - 1) / nblk;
     hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
-                       ga, ldga, y, ldy, ws, C, C / 8, (long)M, rpb, part);
+                       ga, ldga, y, ldy, ws, C, C / 8, (long)M, rpb, part, 0);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_reduce");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_silu_apply_acc(const yh_bf16* y, int ldy, const int64_t* acc, int rows, int ldacc, int C, int64_t M,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                                    float eps, float momentum, float* ws, yh_bf16* out, int ldo, const yh_bf16* res, int ldr, yh_stream stream)
+{
+    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && acc && rows > 0 && rows <= YH_ACC_ROWS && ldacc >= C && gamma && beta && ws, "yh_bn_silu_apply_acc: bad args (rows <= 16)");
+    YH_CHECK_SLICE("yh_bn_silu_apply_acc", y, ldy, C);
+    YH_CHECK_SLICE("yh_bn_silu_apply_acc", out, ldo, C);
+    if (res) YH_CHECK_SLICE("yh_bn_silu_apply_acc", res, ldr, C);
+    const int cpr = C / 8;
+    const long nch = (long)M * cpr;
+    // 1024-thread blocks: the accumulator rows are reduced once per block, so fewer, larger blocks pay for it less often
+    hipLaunchKernelGGL(bn_silu_apply_acc_kernel, dim3((ew_grid(nch) + 3) / 4), dim3(1024), 2 * C * sizeof(float), (hipStream_t)stream,
+                       y, ldy, (const long long*)acc, rows, ldacc, C, cpr, (long)M, gamma, beta, running_mean, running_var, num_batches,
+                       eps, momentum, ws, out, ldo, res, ldr);
+    YH_CHECK_LAUNCH("yh_bn_silu_apply_acc");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_silu_bwd_reduce_acc(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy, const float* ws, int C, int64_t M,
+                                         int64_t* acc, int rows, yh_stream stream)
+{
+    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && ws && acc && rows > 0, "yh_bn_silu_bwd_reduce_acc: bad args");
+    YH_CHECK_SLICE("yh_bn_silu_bwd_reduce_acc", ga, ldga, C);
+    YH_CHECK_SLICE("yh_bn_silu_bwd_reduce_acc", y, ldy, C);
+    int nblk = yh_ew_blocks(M);
+    long rpb = (M + nblk - 1) / nblk;
+    hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
+                       ga, ldga, y, ldy, ws, C, C / 8, (long)M, rpb, reinterpret_cast<float*>(acc), rows);
+    YH_CHECK_LAUNCH("yh_bn_silu_bwd_reduce_acc");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_silu_bwd_apply_acc(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy, const float* ws, const float* gamma,
+                                        const int64_t* acc, int rows, int C, int64_t M, float* dgamma, float* dbeta,
+                                        yh_bf16* gy, int ldgy, yh_bf16* gres, int ldgres, int gres_acc, yh_stream stream)
+{
+    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && ws && gamma && acc && rows > 0 && rows <= YH_ACC_ROWS, "yh_bn_silu_bwd_apply_acc: bad args (rows <= 16)");
+    YH_CHECK_SLICE("yh_bn_silu_bwd_apply_acc", ga, ldga, C);
+    YH_CHECK_SLICE("yh_bn_silu_bwd_apply_acc", y, ldy, C);
+    YH_CHECK_SLICE("yh_bn_silu_bwd_apply_acc", gy, ldgy, C);
+    if (gres) YH_CHECK_SLICE("yh_bn_silu_bwd_apply_acc", gres, ldgres, C);
+    const int cpr = C / 8;
+    const long nch = (long)M * cpr;
+    hipLaunchKernelGGL(bn_silu_bwd_apply_acc_kernel, dim3((ew_grid(nch) + 3) / 4), dim3(1024), 5 * C * sizeof(float), (hipStream_t)stream,
+                       ga, ldga, y, ldy, ws, gamma, (const long long*)acc, rows, C, cpr, (long)M, dgamma, dbeta, gy, ldgy, gres, ldgres, gres_acc);
+    YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply_acc");
     return YH_OK;
 }
 
@@ -579,7 +777,7 @@ extern "C" int yh_colsum(const yh_bf16* g, int ldg, int C, int64_t M, float* par
     int nblk = yh_ew_blocks(M);
     long rpb = (M + nblk - 1) / nblk;
     hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
-                       g, ldg, (const uint16_t*)nullptr, 0, (const float*)nullptr, C, C / 8, (long)M, rpb, part);
+                       g, ldg, (const uint16_t*)nullptr, 0, (const float*)nullptr, C, C / 8, (long)M, rpb, part, 0);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(1024), 0, (hipStream_t)stream, part, nblk, C, out);
     YH_CHECK_LAUNCH("yh_colsum");
     return YH_OK;

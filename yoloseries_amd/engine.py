@@ -70,6 +70,12 @@ def _tune_cache_save():
         pass                               # read-only install: tune again next time
 
 
+# YH_BN_ACC=1: BatchNorm statistics / backward sums leave the conv kernels as int64 fixed-point accumulator rows that the BN+SiLU
+# passes reduce in their own prologue (no yh_bn_finalize / yh_bn_bwd_finalize launches: 114 launches fewer per step).  Measured on
+# MI355X it is SLOWER (14.8 vs 14.3 ms per step): every block of the pass stalls on the same reduction before it can stream, which
+# costs more than the 6.5 us finalize launch it replaces — so the per-block fp32 slabs + finalize kernels stay the default.
+BN_ACC = os.environ.get("YH_BN_ACC", "0") == "1"
+ACC_ROWS = int(os.environ.get("YH_ACC_ROWS", "8"))
 NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weight gradients may lag behind by
 
 
@@ -409,7 +415,7 @@ class Program:
         key = f"conv4:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
-            int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part))))
+            int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), d.acc_rows))
         cache = _tune_cache()
         if key in cache:
             d.tile_k, d.grid_cap, d.algo = (int(v) for v in cache[key])
@@ -445,11 +451,11 @@ class Program:
                 bnr_max = max(bnr_max, L.yh_conv_bnr_rows(C.byref(d)))
         tmp_stats = None
         if stats_ok:
-            tmp_stats = torch.zeros(rows_max + 8, 2, d.Npad, dtype=torch.float32, device=self.dev)
+            tmp_stats = torch.zeros(max(rows_max, 2 * ACC_ROWS) + 8, 2, d.Npad, dtype=torch.float32, device=self.dev)
             d.stats = tmp_stats.data_ptr()
         saved_part, tmp_part = d.bnr_part, None
         if d.bnr_part:                   # a slab big enough for every grid tried below
-            tmp_part = torch.zeros((bnr_max + 8) * 2 * d.N, dtype=torch.float32, device=self.dev)
+            tmp_part = torch.zeros((max(bnr_max, 2 * ACC_ROWS) + 8) * 2 * d.N, dtype=torch.float32, device=self.dev)
             d.bnr_part = tmp_part.data_ptr()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         best, best_ms = (0, 0, 1), None
@@ -527,6 +533,7 @@ class Program:
             if b.t is None and not getattr(b, "is_head", False):
                 b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=self.dev)
         self.cmd_train = []
+        self._acc_fwd_elems = 0
         for op in self.ops:
             if isinstance(op, PoolOp):
                 op.idx = torch.zeros(B, op.src.buf.H, op.src.buf.W, op.src.C, dtype=torch.int8, device=self.dev)
@@ -542,6 +549,28 @@ class Program:
             d = self._conv_desc(op, True)
             d.act = YH_ACT_NONE
             d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
+            if BN_ACC:
+                # batch statistics leave the conv as int64 fixed-point adds into ACC_ROWS accumulator rows (order independent);
+                # the BN+SiLU apply reduces those rows in its prologue, so there is no finalize launch.  The rows of all layers
+                # form one arena that a single fill at the start of the forward zeroes.
+                d.acc_rows = ACC_ROWS
+                self._tune_conv(d, 'fwd', op.name, stats_ok=True)
+                st['acc_off'] = self._acc_fwd_elems
+                self._acc_fwd_elems += ACC_ROWS * 2 * op.Npad
+                st['desc_train'] = d
+                self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op, d)))
+                st['ws'] = []
+                c0 = 0
+                for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
+                    ws = torch.zeros(4 * n, dtype=torch.float32, device=self.dev)
+                    st['ws'].append(ws)
+                    mom = bn.momentum if bn.momentum is not None else 0.1
+                    dst = op.outs[pi].sl()
+                    res = op.res.sl() if (op.res is not None and pi == 0) else None
+                    self.cmd_train.append(('apply_acc', (op, c0, n, M, bn, float(mom), ws, dst, res), op.name,
+                                           ('yh_bn_silu_apply_acc', 0, (6.0 if res else 4.0) * M * n)))
+                    c0 += n
+                continue
             self._tune_conv(d, 'fwd', op.name, stats_ok=True)
             nblk = L.yh_conv_stat_blocks(C.byref(d))
             st['stats'] = torch.zeros(nblk, 2, op.Npad, dtype=torch.float32, device=self.dev)
@@ -564,6 +593,26 @@ class Program:
                     op.y.t.data_ptr() + 2 * c0, op.y.C, ws.data_ptr(), n, M, dst.ptr(), dst.ld,
                     res.ptr() if res else None, res.ld if res else 0), op.name, ('yh_bn_silu_apply', 0, (6.0 if res else 4.0) * M * n)))
                 c0 += n
+
+        if BN_ACC:
+            self.acc_fwd = torch.zeros(max(self._acc_fwd_elems, 2), dtype=torch.int64, device=self.dev)
+            cmds = [('fill', self.acc_fwd, None, ('yh_fill_u32', 0, 8.0 * self.acc_fwd.numel()))]
+            for cmd in self.cmd_train:
+                if cmd[0] == 'apply_acc':
+                    op, c0, n, Mx, bn, mom, ws, dst, res = cmd[1]
+                    st = self.op_state[op.name]
+                    acc_ptr = self.acc_fwd.data_ptr() + 8 * (st['acc_off'] + c0)
+                    args = (op.y.t.data_ptr() + 2 * c0, op.y.C, acc_ptr, ACC_ROWS, op.Npad, n, Mx, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                            bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), float(bn.eps), mom,
+                            ws.data_ptr(), dst.ptr(), dst.ld, res.ptr() if res else None, res.ld if res else 0)
+                    cmds.append((L.yh_bn_silu_apply_acc, args, cmd[2], cmd[3]))
+                else:
+                    cmds.append(cmd)
+            for op in self.ops:
+                if isinstance(op, ConvOp) and op.kind == 'cba':
+                    st = self.op_state[op.name]
+                    st['desc_train'].stats = self.acc_fwd.data_ptr() + 8 * st['acc_off']
+            self.cmd_train = cmds
 
     # -- forward ---------------------------------------------------------------------------
     def _kernel_name(self, d):
@@ -596,9 +645,12 @@ class Program:
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            rc = fn(*args, st)
+            if fn == 'fill':
+                rc = self.L.yh_fill_u32(args.data_ptr(), 0, args.numel() * args.element_size() // 4, st)
+            else:
+                rc = fn(*args, st)
             if rc != 0:
-                check(rc, f"{fn.__name__} [{name}]")
+                check(rc, f"{getattr(fn, '__name__', fn)} [{name}]")
             if prof is not None:
                 e1.record()
                 prof.setdefault(meta + (name,), []).append((e0, e1))
@@ -698,6 +750,14 @@ class Program:
                 return False
             return not any(k2[0] == key[0] and k2 != key and not (k2[1] + k2[2] <= key[1] or k2[1] >= key[1] + key[2]) for k2 in uses)
         self.bnr_fused = {}
+        # accumulator rows of the BatchNorm-backward sums of every ConvBnAct part: one arena, zeroed by one fill per backward
+        self.acc_bwd_off, tot = {}, 0
+        for o2 in self.ops:
+            if isinstance(o2, ConvOp) and o2.kind == 'cba':
+                for pi2, n2 in enumerate(o2.part_N):
+                    self.acc_bwd_off[(o2.name, pi2)] = tot
+                    tot += ACC_ROWS * 2 * n2
+        self.acc_bwd = torch.zeros(max(tot, 2), dtype=torch.int64, device=self.dev) if BN_ACC else None
 
         marks = []
         for op in reversed(self.ops):
@@ -734,6 +794,23 @@ class Program:
                     self.coef_scratch[(op.name, pi)] = coef
                     nblk = L.yh_ew_blocks(M)
                     ypart = op.y.t.data_ptr() + 2 * c0
+                    if BN_ACC:
+                        acc_ptr = self.acc_bwd.data_ptr() + 8 * self.acc_bwd_off[(op.name, pi)]
+                        if self.bnr_fused.get((op.name, pi)) is None:     # no data gradient took the reduction into its epilogue
+                            cmds.append((L.yh_bn_silu_bwd_reduce_acc, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), n, M, acc_ptr, ACC_ROWS),
+                                         op.name, ('yh_bn_silu_bwd_reduce', 0, 4.0 * M * n)))
+                        goff, boff = pk.bn_g[(op.name, pi)]
+                        gres_ptr, gres_ld, gres_acc = None, 0, 0
+                        if op.res is not None and pi == 0 and op.res.buf.needs_grad:
+                            gres_acc = claim(op.res)
+                            gr = op.res.sl(True)
+                            gres_ptr, gres_ld = gr.ptr(), gr.ld
+                        cmds.append((L.yh_bn_silu_bwd_apply_acc, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), bn.weight.data_ptr(), acc_ptr, ACC_ROWS,
+                                                                  n, M, pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
+                                                                  gys.data_ptr() + 2 * c0, op.N, gres_ptr, gres_ld, gres_acc), op.name,
+                                     ('yh_bn_silu_bwd_apply_acc', 0, (6.0 + (4.0 if gres_acc else 2.0) * (gres_ptr is not None)) * M * n)))
+                        c0 += n
+                        continue
                     part_ptr = self.part_scratch.data_ptr()
                     fused = self.bnr_fused.get((op.name, pi))
                     if fused is not None:          # the consumer's data gradient already left the partial sums in its own slab
@@ -815,13 +892,18 @@ class Program:
                         rows = L.yh_conv_bnr_rows(C.byref(d))
                         if rows > 0:
                             po, ppi, pc0 = producer_of[key]
-                            slab = torch.zeros(rows * 2 * sg.C, dtype=torch.float32, device=self.dev)
                             d.bnr_z, d.bnr_ldz = po.y.t.data_ptr() + 2 * pc0, po.y.C
                             d.bnr_ws, d.bnr_C = self.op_state[po.name]['ws'][ppi].data_ptr(), sg.C
-                            d.bnr_part = slab.data_ptr()
-                            self.bnr_fused[(po.name, ppi)] = (slab, rows)
+                            if BN_ACC:
+                                d.bnr_part = self.acc_bwd.data_ptr() + 8 * self.acc_bwd_off[(po.name, ppi)]
+                                d.acc_rows = ACC_ROWS
+                                self.bnr_fused[(po.name, ppi)] = (self.acc_bwd, ACC_ROWS)
+                            else:
+                                slab = torch.zeros(rows * 2 * sg.C, dtype=torch.float32, device=self.dev)
+                                d.bnr_part = slab.data_ptr()
+                                self.bnr_fused[(po.name, ppi)] = (slab, rows)
                     self._tune_conv(d, 'dgrad', op.name)
-                    if d.bnr_part and L.yh_conv_bnr_rows(C.byref(d)) != self.bnr_fused[(po.name, ppi)][1]:
+                    if not BN_ACC and d.bnr_part and L.yh_conv_bnr_rows(C.byref(d)) != self.bnr_fused[(po.name, ppi)][1]:
                         # the tuned block cap changed the grid: size the slab for it
                         rows = L.yh_conv_bnr_rows(C.byref(d))
                         slab = torch.zeros(rows * 2 * sg.C, dtype=torch.float32, device=self.dev)
@@ -912,6 +994,8 @@ class Program:
         pk, L = self.pack, self.L
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         hipk.fill_zero(pk.gpack)
+        if self.acc_bwd is not None:
+            hipk.fill_zero(self.acc_bwd)
         heads = {}
         for o, g in zip(self.outputs, head_grads):
             if isinstance(o, ConvOp):
