@@ -101,7 +101,8 @@ typedef struct yh_conv_desc {
                            * (conv_v3_kernel) with a 256x128 / 128x128 / 128x64 tile, 5 the 3x3 halo kernel (conv_halo_kernel), when the shape
                            * is eligible                                                                              */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
-     * (it must be the ONLY writer of that gradient: out0 covers exactly the producer's N channels, no accumulate):
+     * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
+     * contributions already in out0 are added first and the sums are taken over the rounded total):
      * bnr_z = the producer's raw conv output (same pixel grid / channels as out0), bnr_ws = its scale | shift (stride bnr_C),
      * bnr_part = slab [yh_conv_bnr_rows()][2][N] receiving sum(dz), sum(dz*z) per block, dz = g * silu'(z*scale+shift).
      * Replaces yh_bn_silu_bwd_reduce for that layer; yh_bn_bwd_finalize consumes the slab.  NULL: off.          */

@@ -172,6 +172,8 @@ V3_CASES = [
     (2, 20, 20, 96, 160, 3, 1, 1),       # 32-channel k-steps (96 % 64 != 0), ragged N tile
     (1, 33, 17, 64, 64, 3, 1, 1),        # odd sizes, rows past M in the last tile
     (3, 8, 8, 512, 256, 1, 1, 0),
+    (2, 24, 24, 80, 80, 3, 1, 1),        # halo kernel with a 16-channel tail block (YOLOv5x widths)
+    (1, 32, 32, 112, 176, 3, 1, 1),      # 48-channel tail (forward and data gradient)
 ]
 
 
@@ -204,9 +206,16 @@ def test_conv_fwd_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     wp = hipk.pack_weight_fwd(w)
     ref = F.conv2d(_nchw(x), w, None, stride=s, padding=p).permute(0, 2, 3, 1)
+    xin = hipk.full(x)
+    if Cin % 64:
+        # ragged channel count: the input is a channel slice of a wider buffer whose other channels are NaN — the kernels'
+        # 128-byte row fetches run over them (and over the next tap's weights) but must never feed them to an MFMA
+        xbuf = torch.full((B, H, W, Cin + 16), float("nan"), dtype=torch.bfloat16, device=dev)
+        xbuf[..., 8:8 + Cin] = x
+        xin = hipk.Slice(xbuf, 8, Cin)
     for with_bias in (False, True):
         out = torch.full((B, Ho, Wo, Cout), 7.0, dtype=torch.bfloat16, device=dev)
-        d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, Ho, Wo, H, W, k, s, p, wp, Cout, hipk.full(out),
+        d = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, Ho, Wo, H, W, k, s, p, wp, Cout, hipk.full(out),
                            bias=bias if with_bias else None)
         d.algo = algo
         _expect_family(d, algo)
@@ -270,6 +279,20 @@ def test_conv_dgrad_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
     zz = z.float().reshape(-1, Cin).double()
     a = zz * ws[:Cin].double() + ws[Cin:].double()
     sg = torch.sigmoid(a)
+    dz = gq * (sg * (1 + a * (1 - sg)))
+    got = slab.double().sum(0)
+    assert torch.allclose(got[0], dz.sum(0), rtol=2e-3, atol=2e-3 * dz.abs().sum(0).max().item())
+    assert torch.allclose(got[1], (dz * zz).sum(0), rtol=2e-3, atol=2e-3 * (dz * zz).abs().sum(0).max().item())
+    # the same as the LAST of several writers: earlier contributions already in the buffer are added (bit-identical to the
+    # accumulating generic epilogue above) and the sums are taken over the rounded total
+    gx3 = gx0.clone()
+    d2.out0, d2.accumulate = gx3.data_ptr(), 1
+    assert lib().yh_conv_bnr_rows(C.byref(d2)) == rows
+    slab.zero_()
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    assert torch.equal(gx3, gx)
+    gq = gx3.float().reshape(-1, Cin).double()
     dz = gq * (sg * (1 + a * (1 - sg)))
     got = slab.double().sum(0)
     assert torch.allclose(got[0], dz.sum(0), rtol=2e-3, atol=2e-3 * dz.abs().sum(0).max().item())

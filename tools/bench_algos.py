@@ -28,10 +28,11 @@ elif which == "v5l":
               ("s4_cba3", 20, 1024, 1024, 1, 1)]
 else:
     B = 16
-    shapes = [("s1_conv", 640, 96 - 32, 128 + 32, 3, 2), ("s1_b_3x3", 320, 64, 64, 3, 1), ("s2_conv", 320, 160, 320, 3, 2),
-              ("s2_b_3x3", 160, 160, 160, 3, 1), ("s3_conv", 160, 320, 640, 3, 2), ("s3_b_3x3", 80, 320, 320, 3, 1),
-              ("s3_cba12", 80, 640, 640, 1, 1), ("s4_conv", 80, 640, 1280, 3, 2), ("s4_b_3x3", 40, 640, 640, 3, 1)]
-
+    shapes = [("s1_conv", 640, 80, 160, 3, 2), ("s1_b_3x3", 320, 80, 80, 3, 1), ("s1_b_1x1", 320, 80, 80, 1, 1),
+              ("s1_cba12", 320, 160, 160, 1, 1), ("s2_conv", 320, 160, 320, 3, 2), ("s2_b_3x3", 160, 160, 160, 3, 1),
+              ("s2_b_1x1", 160, 160, 160, 1, 1), ("s2_cba12", 160, 320, 320, 1, 1), ("s3_conv", 160, 320, 640, 3, 2),
+              ("s3_b_3x3", 80, 320, 320, 3, 1), ("s3_cba12", 80, 640, 640, 1, 1), ("s4_conv", 80, 640, 1280, 3, 2),
+              ("s4_b_3x3", 40, 640, 640, 3, 1)]
 
 def kname(d):
     buf = C.create_string_buffer(96)

@@ -738,6 +738,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
                     }
                     *reinterpret_cast<uint4*>(dst) = v;
                 } else {
+                    if (EPI == 3 && d.accumulate) {
+                        // last writer of a gradient with several contributions: add the earlier ones (bf16, as the generic
+                        // epilogue does) and take the BatchNorm-backward sums over the rounded total
+                        const uint4 ov = *reinterpret_cast<const uint4*>(d.out0 + orow * d.ld0 + n);
+                        float f[8], g0[8];
+                        unpack8(v, f);
+                        unpack8(ov, g0);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += g0[e];
+                        v = pack8(f);
+                    }
                     *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
                     if (EPI == 3) {
                         const uint4 zv = zpre[i];
@@ -828,9 +839,14 @@ __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rs, unsig
 #endif
 }
 
-template <int BMT, int BN, int WM, int WN, int BKT, int STG, int EPI>
+// TL (tail, BKT 64 only): the channel count is a multiple of 16 but not of 64 (YOLOv5m / v5x widths: 96, 80, 160, 320 + 160 ...):
+// the last channel block of every tap runs (C % 64) / 16 of its four 16-channel sub-steps.  Its rows are still fetched whole
+// (128 bytes: the bytes behind the last channel are the next pixel's / the next tap's, zeros past the end of the buffer)
+// and never read as fragments.
+template <int BMT, int BN, int WM, int WN, int BKT, int STG, int EPI, bool TL = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
 {
+    static_assert(!TL || BKT == 64, "tail blocks: 64-channel k-steps only");
     constexpr int NWV = WM * WN;
     constexpr int NT = NWV * 64;
     constexpr int TM = BMT / (WM * 32);
@@ -866,7 +882,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
     const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
     const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
     const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
-    const int ncb = p.Ctot / BKT;
+    const int ncb = TL ? (p.Ctot + BKT - 1) / BKT : p.Ctot / BKT;
+    const int tailn = TL ? (p.Ctot % BKT) / 16 : BKT / 16;
     const int nkt = nkh * nkw * ncb;
     const int HcWc = p.Hc * p.Wc;
     const int C0 = d.seg[0].C;
@@ -999,7 +1016,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
 #pragma unroll
         for (int s = 0; s < STG - 1; ++s)
             if (s < nkt) issue(s);
-        int slot = 0, islot = STG - 1;
+        int slot = 0, islot = STG - 1, rd_cb = 0;
         for (int kt = 0; kt < nkt; ++kt) {
             // this wave's transfers of stage kt have landed when at most the younger stages are outstanding
             const int younger = nkt - 1 - kt;
@@ -1009,8 +1026,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
             __builtin_amdgcn_s_barrier();          // stage kt complete for every wave; stage kt-1 no longer read by anyone
             if (kt + STG - 1 < nkt) issue(islot);
             const unsigned char* sbase = smem + slot * STAGE_BYTES;
+            int ksn = BKT / 16;                    // wave-uniform: sub-steps of this channel block
+            if (TL) {
+                if (rd_cb + 1 == ncb) { ksn = tailn; rd_cb = 0; } else ++rd_cb;
+            }
 #pragma unroll
             for (int ks = 0; ks < BKT / 16; ++ks) {
+                if (TL && ks >= ksn) continue;
                 bf16x8_t af[TM], bfr[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -1121,6 +1143,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
                     }
                     *reinterpret_cast<uint4*>(dst) = v;
                 } else {
+                    if (EPI == 3 && d.accumulate) {
+                        // last writer of a gradient with several contributions: add the earlier ones (bf16, as the generic
+                        // epilogue does) and take the BatchNorm-backward sums over the rounded total
+                        const uint4 ov = *reinterpret_cast<const uint4*>(d.out0 + orow * d.ld0 + n);
+                        float f[8], g0[8];
+                        unpack8(v, f);
+                        unpack8(ov, g0);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += g0[e];
+                        v = pack8(f);
+                    }
                     *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
                     if (EPI == 3) {
                         const uint4 zv = zpre[i];
@@ -1187,7 +1220,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
 // output pixel of the tile (ragged tiles) read a zero line, so their accumulators are exact zeros for the statistics.
 struct HaloGeom { int TH, TW, PW, NP, tiles_x, tiles_y; };
 
-template <int BN, int EPI>
+// TL (tail): the channel count is a multiple of 16 but not of 64 (YOLOv5m / v5x widths: 96, 80, 160): the last channel block
+// runs only (C % 64) / 16 of its four 16-channel sub-steps.  Its DMA still fetches whole 128-byte rows (the bytes behind the
+// last channel belong to the next pixel / the next tap's weights, or are zero-filled past the end of the buffer): they are
+// never read as fragments.
+template <int BN, int EPI, bool TL>
 __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const HaloGeom hg)
 {
     constexpr int BMT = 256, WM = 4, WN = 2, BKT = 64, STG = 4;
@@ -1215,8 +1252,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int n0 = blockIdx.y * BN;
-    const int ncb = p.Ctot / BKT;
-    const int nkt = 9 * ncb;
+    const int ncb = (p.Ctot + BKT - 1) / BKT;
+    const int tailn = TL ? (p.Ctot % BKT) / 16 : BKT / 16;   // 16-channel sub-steps of the last channel block
     const int H = d.Ho, W = d.Wo;                    // stride 1, pad 1: input grid == output grid
     const int TH = hg.TH, TW = hg.TW, PW = hg.PW, NP = hg.NP;
     const int tiles_per_img = hg.tiles_x * hg.tiles_y;
@@ -1343,8 +1380,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
         bf16x8_t afN[TM], bfN[TN];
         for (int cblk = 0; cblk < ncb; ++cblk) {
             const bool last_blk = cblk + 1 == ncb;
+            const int ksn = (TL && last_blk) ? tailn : BKT / 16;      // wave-uniform
             if (last_blk && has_next) patch_offsets(tile + gridDim.x, voffN);
-            const unsigned char* pbase = smem + pb * PATCH_BYTES;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kt = cblk * 9 + tap;
@@ -1418,6 +1455,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
                 }
 #pragma unroll
                 for (int ks = 0; ks < BKT / 16; ++ks) {
+                    if (TL && ks >= ksn) continue;
                     if (ks == 0) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i) af[i] = afN[i];
@@ -1431,7 +1469,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
                         for (int j = 0; j < TN; ++j)
                             bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + sbase + rdBk[ks] + j * (32 * ROWB)));
                     }
-                    if (ks == BKT / 16 - 2 && !(tap == 8 && last_blk)) {
+                    if (ks == (TL ? 0 : BKT / 16 - 2) && !(tap == 8 && last_blk)) {
                         // request sub-step 0 of the NEXT step (next tap of this channel block, or tap 0 of the next block in the other
                         // patch buffer, whose parts landed before this step's barrier)
                         const int ntap = tap == 8 ? 0 : tap + 1;
@@ -1547,6 +1585,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
                         }
                         *reinterpret_cast<uint4*>(dst) = v;
                     } else {
+                        if (EPI == 3 && d.accumulate) {
+                            const uint4 ov = *reinterpret_cast<const uint4*>(d.out0 + orow * d.ld0 + n);
+                            float f[8], g0[8];
+                            unpack8(v, f);
+                            unpack8(ov, g0);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) f[e] += g0[e];
+                            v = pack8(f);
+                        }
                         *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
                         if (EPI == 1) {
                             float f[8];
@@ -1833,13 +1880,14 @@ int pick_bkt(const yh_conv_desc* d, int bn) {
     return 64;
 }
 
+int conv_v3_bkt(const yh_conv_desc* d);
 // LDS-DMA kernel (conv_v3_kernel) variant for this descriptor: 0 = none (v2 / generic kernel), 1 = 256 x 128 tile (8 waves),
 // 2 = 128 x 128 (4 waves), 3 = 128 x 64 (4 waves).  d->algo: 0 library default, 1 force v2, 2..4 = variant 1..3 when eligible.
 int conv_v3_variant(const yh_conv_desc* d)
 {
     if (d->algo == 1 || d->algo == 5 || stem_eligible(d) || !conv_v2_ok(d)) return 0;
     { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 512)) return 0; }
-    for (int s = 0; s < d->nseg; ++s) if (d->seg[s].C % 32) return 0;
+    if (conv_v3_bkt(d) == 0) return 0;
     if (d->N <= 32) return 0;
     if (d->tile_n == 32) return 0;
     const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || d->nsplit < d->N;
@@ -1856,14 +1904,14 @@ int conv_v3_variant(const yh_conv_desc* d)
     if (d->N > 64 && K >= 512 && M >= 256L * 192) return 1;
     return 0;
 }
-// halo kernel (conv_halo_kernel): 3x3 / stride 1 / pad 1, one input segment with a multiple of 64 channels, N > 32.
+// halo kernel (conv_halo_kernel): 3x3 / stride 1 / pad 1, one input segment with >= 64 channels in a multiple of 16, N > 32.
 // d->algo: 5 forces it when eligible; 0 (library default) takes it when the tile geometry wastes < 25 % of the MFMA rows
 bool conv_halo_ok(const yh_conv_desc* d, HaloGeom* g)
 {
     if (d->algo != 0 && d->algo != 5) return false;
     { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 1024)) return false; }
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->nseg != 1 || d->seg[0].ups) return false;
-    if (d->seg[0].C % 64 || d->N <= 32 || d->tile_n == 32) return false;
+    if (d->seg[0].C % 16 || d->seg[0].C < 64 || d->N <= 32 || d->tile_n == 32) return false;
     if (d->Ho != d->Hi || d->Wo != d->Wi) return false;
     if (!conv_v2_ok(d)) return false;
     const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || d->nsplit < d->N;
@@ -1879,9 +1927,21 @@ bool conv_halo_ok(const yh_conv_desc* d, HaloGeom* g)
     return true;
 }
 
+// channels per k-step of the LDS-DMA kernel: 0 = not eligible.  64 needs whole 64-channel blocks in every segment but the
+// last, whose channel count may be any multiple of 16 (the "tail" variant of the kernel); 32 needs multiples of 32 everywhere.
+// Where both work, 64 is the default (half the barriers) and d->tile_k == 32 selects the short steps.
 int conv_v3_bkt(const yh_conv_desc* d) {
-    for (int s = 0; s < d->nseg; ++s) if (d->seg[s].C % 64) return 32;
-    return d->tile_k == 32 ? 32 : 64;
+    bool ok64 = true, ok32 = true;
+    int Ctot = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const int C = d->seg[s].C;
+        Ctot += C;
+        if (C % 32) ok32 = false;
+        if (s + 1 < d->nseg ? (C % 64 != 0) : (C % 16 != 0)) ok64 = false;
+    }
+    if (Ctot < 64) ok64 = false;
+    if (ok64 && !(ok32 && d->tile_k == 32)) return 64;
+    return ok32 ? 32 : 0;
 }
 
 void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
@@ -2042,7 +2102,8 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (generic && d->stats) k.v2 = 0;            // statistics of an affine/activated output: generic kernel only
     if (ragged && !k.v2) k.fast = 0;              // the generic kernel's fast loader needs whole 32-channel blocks
     if (d->bnr_part) {
-        YH_CHECK_ARG(k.v2 && !generic && !d->stats && d->mode == YH_CONV_DGRAD && !stem_eligible(d),
+        const bool generic_na = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || k.d.nsplit < d->N;
+        YH_CHECK_ARG(k.v2 && !generic_na && !d->stats && d->mode == YH_CONV_DGRAD && !stem_eligible(d),
                      "yh_conv_igemm: the fused BatchNorm-backward reduction needs the plain buffer-load data-gradient path");
         YH_CHECK_ARG(d->bnr_z && yh_aligned16(d->bnr_z) && d->bnr_ldz % 8 == 0 && d->bnr_ws && d->bnr_C >= d->N && d->N % 8 == 0,
                      "yh_conv_igemm: bad fused-reduction operands");
@@ -2050,26 +2111,28 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (halo) {
         YH_CHECK_ARG(k.v2 && !k.cls, "yh_conv_igemm: the halo kernel needs the buffer-load path");
         const int epi = d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0));
-        if (name_out) { snprintf(name_out, name_len, "conv_halo_kernel<%d, %d>", bn, epi); return YH_OK; }
+        const bool tl = (k.Ctot % 64) != 0;
+        if (name_out) { snprintf(name_out, name_len, tl ? "conv_halo_kernel<%d, %d, true>" : "conv_halo_kernel<%d, %d, false>", bn, epi); return YH_OK; }
         hipStream_t sth = (hipStream_t)stream;
         const dim3 gridh(gx, gy), blkh(512);
-#define YH_LAUNCH_HALO(BN_)                                                                                          \
+#define YH_LAUNCH_HALO(BN_, TL_)                                                                                     \
         do {                                                                                                         \
             const size_t sm = conv_halo_smem_bytes<BN_>();                                                           \
             static bool attr_set = false;                                                                            \
             if (!attr_set) {                                                                                         \
-                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 0, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 1, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 2, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 3, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
                 attr_set = true;                                                                                     \
             }                                                                                                        \
-            if (epi == 3)      conv_halo_kernel<BN_, 3><<<gridh, blkh, sm, sth>>>(k, hgeo);                          \
-            else if (epi == 2) conv_halo_kernel<BN_, 2><<<gridh, blkh, sm, sth>>>(k, hgeo);                          \
-            else if (epi == 1) conv_halo_kernel<BN_, 1><<<gridh, blkh, sm, sth>>>(k, hgeo);                          \
-            else               conv_halo_kernel<BN_, 0><<<gridh, blkh, sm, sth>>>(k, hgeo);                          \
+            if (epi == 3)      conv_halo_kernel<BN_, 3, TL_><<<gridh, blkh, sm, sth>>>(k, hgeo);                     \
+            else if (epi == 2) conv_halo_kernel<BN_, 2, TL_><<<gridh, blkh, sm, sth>>>(k, hgeo);                     \
+            else if (epi == 1) conv_halo_kernel<BN_, 1, TL_><<<gridh, blkh, sm, sth>>>(k, hgeo);                     \
+            else               conv_halo_kernel<BN_, 0, TL_><<<gridh, blkh, sm, sth>>>(k, hgeo);                     \
         } while (0)
-        if (bn == 64) YH_LAUNCH_HALO(64); else YH_LAUNCH_HALO(128);
+        if (tl) { if (bn == 64) YH_LAUNCH_HALO(64, true); else YH_LAUNCH_HALO(128, true); }
+        else    { if (bn == 64) YH_LAUNCH_HALO(64, false); else YH_LAUNCH_HALO(128, false); }
 #undef YH_LAUNCH_HALO
         YH_CHECK_LAUNCH("yh_conv_igemm(halo)");
         return YH_OK;
@@ -2077,34 +2140,36 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (v3) {
         YH_CHECK_ARG(k.v2, "yh_conv_igemm: the LDS-DMA kernel needs the buffer-load path");
         const int bkt3 = conv_v3_bkt(d);
+        const bool tl3 = bkt3 == 64 && (k.Ctot % 64) != 0;
         const int epi = d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0));
         const int bmt = v3 == 1 ? 256 : 128;
         const int stg = v3 == 1 ? (bkt3 == 64 ? 3 : 4) : (v3 == 2 ? (bkt3 == 64 ? 2 : 4) : (bkt3 == 64 ? 3 : 4));
         if (name_out) {
-            snprintf(name_out, name_len, "conv_v3_kernel<%d, %d, %d, 2, %d, %d, %d>", bmt, bn, v3 == 1 ? 4 : 2, bkt3, stg, epi);
+            snprintf(name_out, name_len, "conv_v3_kernel<%d, %d, %d, 2, %d, %d, %d%s>", bmt, bn, v3 == 1 ? 4 : 2, bkt3, stg, epi,
+                     tl3 ? ", true" : "");
             return YH_OK;
         }
         hipStream_t st3 = (hipStream_t)stream;
-#define YH_LAUNCH_V3(BMT_, BN_, WM_, BKT_, STG_)                                                                     \
+#define YH_LAUNCH_V3(BMT_, BN_, WM_, BKT_, STG_, TL_)                                                                \
         do {                                                                                                         \
             const size_t sm = conv3_smem_bytes<BMT_, BN_, WM_, BKT_, STG_>();                                        \
             const dim3 blk(WM_ * 2 * 64);                                                                            \
             static bool attr_set = false;                                                                            \
             if (!attr_set) {                                                                                         \
-                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
                 attr_set = true;                                                                                     \
             }                                                                                                        \
-            if (epi == 3)      conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3><<<grid, blk, sm, st3>>>(k);          \
-            else if (epi == 2) conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2><<<grid, blk, sm, st3>>>(k);          \
-            else if (epi == 1) conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1><<<grid, blk, sm, st3>>>(k);          \
-            else               conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0><<<grid, blk, sm, st3>>>(k);          \
+            if (epi == 3)      conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3, TL_><<<grid, blk, sm, st3>>>(k);     \
+            else if (epi == 2) conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2, TL_><<<grid, blk, sm, st3>>>(k);     \
+            else if (epi == 1) conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1, TL_><<<grid, blk, sm, st3>>>(k);     \
+            else               conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0, TL_><<<grid, blk, sm, st3>>>(k);     \
         } while (0)
-        if (v3 == 1) { if (bkt3 == 64) YH_LAUNCH_V3(256, 128, 4, 64, 3); else YH_LAUNCH_V3(256, 128, 4, 32, 4); }
-        else if (v3 == 2) { if (bkt3 == 64) YH_LAUNCH_V3(128, 128, 2, 64, 2); else YH_LAUNCH_V3(128, 128, 2, 32, 4); }
-        else { if (bkt3 == 64) YH_LAUNCH_V3(128, 64, 2, 64, 3); else YH_LAUNCH_V3(128, 64, 2, 32, 4); }
+        if (v3 == 1) { if (tl3) YH_LAUNCH_V3(256, 128, 4, 64, 3, true); else if (bkt3 == 64) YH_LAUNCH_V3(256, 128, 4, 64, 3, false); else YH_LAUNCH_V3(256, 128, 4, 32, 4, false); }
+        else if (v3 == 2) { if (tl3) YH_LAUNCH_V3(128, 128, 2, 64, 2, true); else if (bkt3 == 64) YH_LAUNCH_V3(128, 128, 2, 64, 2, false); else YH_LAUNCH_V3(128, 128, 2, 32, 4, false); }
+        else { if (tl3) YH_LAUNCH_V3(128, 64, 2, 64, 3, true); else if (bkt3 == 64) YH_LAUNCH_V3(128, 64, 2, 64, 3, false); else YH_LAUNCH_V3(128, 64, 2, 32, 4, false); }
 #undef YH_LAUNCH_V3
         YH_CHECK_LAUNCH("yh_conv_igemm(v3)");
         return YH_OK;
@@ -2167,7 +2232,7 @@ extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream) { return c
 extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
 {
     if (!d || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 8 || d->seg[0].ups || d->N % 8) return 0;
-    if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || d->nsplit < d->N || d->stats) return 0;
+    if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N || d->stats) return 0;
     { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 16)) return 0; }
     const unsigned long M = (unsigned long)d->B * d->Ho * d->Wo;
     if (M >= (1ul << 31) - BM) return 0;

@@ -39,7 +39,9 @@ __device__ __forceinline__ v4s tr_read(const uint16_t* p) {
 constexpr int wg_pitch(int cols) { return (cols % 64 == 32) ? cols : cols + 32; }
 
 // WN x WC waves, each wave computes (TNW*32) x (TCW*32); TK pixels per k-step
-template <int WN, int WC, int TNW, int TCW, int TK, int MINW>
+// PF2: two tiles in flight per thread (see the register sets below): +7..12 % on the stem and the general (K > 384) tilings;
+// off where the second set would spill and on the 1x1 tilings, which already stream at 5.4 TB/s (measured 2 % slower with it)
+template <int WN, int WC, int TNW, int TCW, int TK, int MINW, bool PF2 = false>
 __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const WgK p)
 {
     constexpr int NT = WN * WC * 64;              // threads per block
@@ -131,8 +133,10 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
     }
     const int stepH = TK / d.Wo, stepW = TK - stepH * d.Wo;
 
-    u32x4_t ra[ACH], rb[BCH];
-    auto load_tile = [&](int kt) {
+    // two register sets: the tile of k-step kt+2 is requested while tile kt is multiplied and tile kt+1 (requested one step
+    // earlier) moves to LDS — two tiles in flight per thread; the layers this kernel serves are HBM bound
+    u32x4_t ra0[ACH], rb0[BCH], ra1[ACH], rb1[BCH];
+    auto load_tile = [&](int kt, u32x4_t (&ra)[ACH], u32x4_t (&rb)[BCH]) {
         const int mb = mbeg + kt * TK;             // scalar
         const bool mv = mb + row < mend;
         const unsigned sg = (unsigned)mb * (unsigned)(d.ldg * 2);
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
     };
     uint16_t* const stA = sA + row * PA + sub * 8;
     uint16_t* const stB = sB + row * PB + sub * 8;
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const u32x4_t (&ra)[ACH], const u32x4_t (&rb)[BCH]) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j)
             if ((sub + TPR * j) * 8 < TN) *reinterpret_cast<u32x4_t*>(stA + buf * TK * PA + TPR * j * 8) = ra[j];
@@ -177,13 +181,7 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
     const uint16_t* const fa = sA + frag_row * PA + wn * TNW * 32 + frag_col;
     const uint16_t* const fb = sB + frag_row * PB + wc * TCW * 32 + frag_col;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        const bool more = (kt + 1) < nkt;
-        if (more) load_tile(kt + 1);
+    auto multiply = [&](int buf) {
         const uint16_t* a = fa + buf * TK * PA;
         const uint16_t* b = fb + buf * TK * PB;
 #pragma unroll
@@ -211,8 +209,35 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
                 for (int j = 0; j < TCW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
+    };
+
+    // tile j travels through register set j & 1 into LDS buffer j & 1
+    load_tile(0, ra0, rb0);
+    store_tile(0, ra0, rb0);
+    if (PF2) {
+        if (nkt > 1) load_tile(1, ra1, rb1);
         __syncthreads();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            if (kt + 2 < nkt) load_tile(kt + 2, ra0, rb0);
+            multiply(0);
+            if (kt + 1 < nkt) store_tile(1, ra1, rb1);
+            __syncthreads();
+            if (kt + 1 >= nkt) break;
+            if (kt + 3 < nkt) load_tile(kt + 3, ra1, rb1);
+            multiply(1);
+            if (kt + 2 < nkt) store_tile(0, ra0, rb0);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            const bool more = (kt + 1) < nkt;
+            if (more) load_tile(kt + 1, ra0, rb0);
+            multiply(buf);
+            if (more) store_tile(buf ^ 1, ra0, rb0);
+            __syncthreads();
+        }
     }
 
     // C[n][col]: lane holds column (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5)
@@ -249,9 +274,9 @@ int wg_config(int N, int Kseg)
     return N <= 64 ? 5 : 6;
 }
 const char* const wg_names[7] = {
-    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3>", "conv_wgrad_kernel<1, 4, 1, 3, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 1, 32, 4>",
-    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 3, 32, 2>", "conv_wgrad_kernel<2, 2, 1, 2, 64, 3>",
-    "conv_wgrad_kernel<4, 2, 1, 2, 64, 4>"};
+    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3, true>", "conv_wgrad_kernel<1, 4, 1, 3, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 1, 32, 4>",
+    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 3, 32, 2>", "conv_wgrad_kernel<2, 2, 1, 2, 64, 3, true>",
+    "conv_wgrad_kernel<4, 2, 1, 2, 64, 4, true>"};
 
 }  // namespace
 
@@ -259,7 +284,7 @@ const char* const wg_names[7] = {
 extern "C" const char* yh_conv_wgrad_kernel_name(int N, int Kseg)
 {
     const int c = wg_config(N, Kseg);
-    return (c == 0 && Kseg <= 160) ? "conv_wgrad_kernel<1, 5, 1, 1, 32, 3>" : wg_names[c];
+    return (c == 0 && Kseg <= 160) ? "conv_wgrad_kernel<1, 5, 1, 1, 32, 3, true>" : wg_names[c];
 }
 
 /* tile the kernel will use for a layer: rows (out channels) x im2col columns per block; used by the host to size `splits` */
@@ -310,23 +335,23 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     k.rows_per_split = rps;
     splits = (int)((M + rps - 1) / rps);
     YH_CHECK_ARG(splits <= 65528, "yh_conv_wgrad: too many splits");
-#define YH_WG(WN_, WC_, TNW_, TCW_, TK_, MINW_, NT_)                                                            \
+#define YH_WG(WN_, WC_, TNW_, TCW_, TK_, MINW_, NT_, PF2_)                                                      \
     do {                                                                                                        \
         dim3 grid((NT_) * k.ctiles, (splits + 7) / 8 * 8);                                                      \
-        conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_><<<grid, dim3(WN_ * WC_ * 64), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
+        conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_, PF2_><<<grid, dim3(WN_ * WC_ * 64), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
     } while (0)
     k.ctiles = wide ? 1 : (k.Kseg + 127) / 128;
     switch (cfg) {
     case 0:
-        if (k.Kseg <= 160) YH_WG(1, 5, 1, 1, 32, 3, (d->N + 31) / 32);        // stem: 5 waves x one 32-column tile (144 of 160 used)
-        else               YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32);
+        if (k.Kseg <= 160) YH_WG(1, 5, 1, 1, 32, 3, (d->N + 31) / 32, true);  // stem: 5 waves x one 32-column tile (144 of 160 used)
+        else               YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32, true);
         break;
-    case 1: YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32); break;
-    case 2: if (tk64) YH_WG(1, 4, 2, 1, 64, 2, (d->N + 63) / 64); else YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64); break;
-    case 3: if (tk64) YH_WG(1, 4, 2, 2, 64, 2, (d->N + 63) / 64); else YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64); break;
-    case 4: YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64); break;
-    case 5: YH_WG(2, 2, 1, 2, 64, 3, (d->N + 63) / 64); break;
-    default: YH_WG(4, 2, 1, 2, 64, 4, (d->N + 127) / 128); break;      // 8 waves of 32 x 64 (measured 5% over 4 waves of 64 x 64)
+    case 1: YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32, false); break;
+    case 2: if (tk64) YH_WG(1, 4, 2, 1, 64, 2, (d->N + 63) / 64, false); else YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64, false); break;
+    case 3: if (tk64) YH_WG(1, 4, 2, 2, 64, 2, (d->N + 63) / 64, false); else YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64, false); break;
+    case 4: YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64, false); break;
+    case 5: YH_WG(2, 2, 1, 2, 64, 3, (d->N + 63) / 64, true); break;
+    default: YH_WG(4, 2, 1, 2, 64, 4, (d->N + 127) / 128, true); break; // 8 waves of 32 x 64 (measured 5% over 4 waves of 64 x 64)
     }
 #undef YH_WG
     YH_CHECK_LAUNCH("yh_conv_wgrad");

@@ -412,7 +412,7 @@ class Program:
         only the number of BatchNorm partial-sum rows follows the grid."""
         if os.environ.get("YH_CONV_TUNE", "1") == "0":
             return
-        key = f"conv4:{kind}:" + ",".join(str(int(v)) for v in (
+        key = f"conv5:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
             int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), d.acc_rows))
@@ -443,6 +443,8 @@ class Program:
                 kn = self._kernel_name(d)
                 if ("conv_v3" in kn and algo < 5) or ("conv_halo" in kn and algo == 5):
                     cands.append((algo, 0, 0))
+                    if algo < 5 and kn.endswith(", true>") and all(d.seg[i].C % 32 == 0 for i in range(d.nseg)):
+                        cands.append((algo, 32, 0))    # ragged last channel block: 32-channel steps instead of 64 + tail
         rows_max, bnr_max = 1, 1
         for algo, tk, cap in cands:
             d.algo, d.tile_k, d.grid_cap = algo, tk, cap
@@ -700,8 +702,12 @@ class Program:
         self.ups_scratch = {}
         self.wgrad_tuned = {}
 
+        writes_seen = {}
+
         def claim(ref):
             """returns accumulate flag for a write into grad(ref) and marks it written"""
+            k3 = (ref.buf.name, ref.coff, ref.C)
+            writes_seen[k3] = writes_seen.get(k3, 0) + 1
             flags = ref.buf.ginit[ref.coff:ref.coff + ref.C]
             if flags.all():
                 return 1
@@ -721,10 +727,12 @@ class Program:
             else:
                 o.buf.ginit[o.coff:o.coff + o.C] = True
 
-        # Which ConvBnAct outputs get their gradient from exactly ONE data-gradient launch (one conv reads exactly that
-        # slice, no residual / pool / overlapping use, no upsampling in between)?  For those the BatchNorm-backward
-        # reduction is taken in that dgrad's epilogue (yh_conv_desc.bnr_*) and the separate reduce pass is dropped.
+        # Which ConvBnAct outputs get the LAST contribution to their gradient from a data-gradient launch (a conv reads exactly
+        # that slice, not upsampled; residual adds / pools / other convs that read it come later in the forward, so their
+        # gradient is already in the buffer)?  For those the BatchNorm-backward reduction is taken in that dgrad's epilogue
+        # (yh_conv_desc.bnr_*, accumulating where it is not the only writer) and the separate reduce pass is dropped.
         fuse_ok = os.environ.get("YH_FUSE_BNR", "1") != "0"
+        fuse_acc = os.environ.get("YH_FUSE_BNR_ACC", "1") != "0"     # ... also when that launch accumulates onto earlier writers
         uses, producer_of = {}, {}
         for o2 in self.ops:
             if isinstance(o2, PoolOp):
@@ -744,9 +752,12 @@ class Program:
             if not isinstance(o2, ConvOp):
                 uses.setdefault((o2.buf.name, o2.coff, o2.C), []).append(('out',))
 
-        def sole_writer(key):
+        def last_writer(key):
+            """asked by a data-gradient launch that has just claimed `key` (a non-upsampled conv segment): was that the LAST write
+            into this gradient slice — every other consumer (conv segments, residual adds, pools) comes later in the forward
+            and so earlier in this program — with no differently-sliced use of the same buffer overlapping it?"""
             u = uses.get(key, [])
-            if len(u) != 1 or u[0][0] != 'seg' or u[0][1]:
+            if any(x[0] == 'out' for x in u) or writes_seen.get(key, 0) != len(u):
                 return False
             return not any(k2[0] == key[0] and k2 != key and not (k2[1] + k2[2] <= key[1] or k2[1] >= key[1] + key[2]) for k2 in uses)
         self.bnr_fused = {}
@@ -888,7 +899,7 @@ class Program:
                     d.out0, d.ld0, d.accumulate = gl.ptr(), gl.ld, acc
                     self._keep.append(d)
                     key = (sg.buf.name, sg.coff, sg.C)
-                    if fuse_ok and acc == 0 and key in producer_of and sole_writer(key):
+                    if fuse_ok and key in producer_of and last_writer(key) and (acc == 0 or fuse_acc):
                         rows = L.yh_conv_bnr_rows(C.byref(d))
                         if rows > 0:
                             po, ppi, pc0 = producer_of[key]
