@@ -96,7 +96,8 @@ typedef struct yh_conv_desc {
      * summation grouping) of the statistics rows; yh_conv_stat_blocks() honours both.            */
     int32_t  tile_n;
     int32_t  grid_cap;
-    int32_t  tile_k;      /* channels per k-step, 32 or 64 (64 needs every segment C % 64 == 0 and the 128-wide tile) */
+    int32_t  tile_k;      /* channels per k-step, 32 or 64 (64 needs whole 64-channel blocks in every segment but the last and the
+                           * 128-wide tile on the register-staged kernel)                                               */
     int32_t  algo;        /* kernel family: 0 library default, 1 register-staged (conv_v2_kernel), 2..4 LDS-DMA ring
                            * (conv_v3_kernel) with a 256x128 / 128x128 / 128x64 tile, 5 the 3x3 halo kernel (conv_halo_kernel), when the shape
                            * is eligible                                                                              */

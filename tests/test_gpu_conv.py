@@ -42,6 +42,7 @@ CASES = [
     (2, 24, 24, 80, 160, 3, 1, 1),       # YOLOv5x / v5m widths: channel counts that are not multiples of 32 (ragged last block)
     (2, 24, 24, 48, 96, 3, 2, 1),
     (2, 16, 16, 80, 80, 1, 1, 0),
+    (2, 10, 10, 512, 128, 1, 1, 0),      # pointwise layer on the general (K > 384) weight-gradient tiling
 ]
 
 
@@ -143,10 +144,11 @@ def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits, tile_k):
     _close(dw, ref, 2e-3, 2e-3 * scale)
 
 
-def test_conv_wgrad_segment_upsampled(dev):
-    """wgrad of one segment of a concat input, read through the 2x upsample."""
+@pytest.mark.parametrize("C0,C1,Cout", [(32, 64, 64), (512, 448, 128)])
+def test_conv_wgrad_segment_upsampled(dev, C0, C1, Cout):
+    """wgrad of one segment of a concat input, read through the 2x upsample (wide tiling; general tiling)."""
     from yoloseries_amd import hipk
-    B, H, W, C0, C1, Cout = 2, 16, 16, 32, 64, 64
+    B, H, W = 2, 16, 16
     lo = _nhwc(B, H // 2, W // 2, C0, dev, 12)
     sk = _nhwc(B, H, W, C1, dev, 13)
     gy = _nhwc(B, H, W, Cout, dev, 14)

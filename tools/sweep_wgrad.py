@@ -41,6 +41,7 @@ for name, H, Cin, Cout, k, s in shapes:
     for tot in (128, 256, 512, 768, 1024, 1536, 3072):
         splits = max(1, min((M + 255) // 256, (tot + ntile - 1) // ntile))
         d = hipk.wgrad_desc(hipk.full(gy), Cout, hipk.full(x), 0, Cin, B, Ho, Ho, H, H, k, s, p, dw, splits)
+        d.tile_k = int(os.environ.get("WG_TK", "0"))
         for _ in range(2):
             hipk.wgrad_launch(d)
         torch.cuda.synchronize()

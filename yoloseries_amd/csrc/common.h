@@ -61,6 +61,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// ---- LDS-DMA (global -> LDS without VGPR staging) ---------------------------
+#define YH_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+// workgroup barrier that orders LDS accesses only: unlike __syncthreads() it does not drain LDS-DMA transfers in flight
+#define YH_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+
+// one LDS-DMA wave instruction: 64 lanes x 16 bytes from (rsrc, per-lane voff + scalar soff) to lds .. lds + 1024
+__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voff, int soff)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void lds_void;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
 // ---- host side helpers -----------------------------------------------------
 void yh_set_error(const char* fmt, ...);
 #define YH_CHECK_ARG(cond, ...) do { if (!(cond)) { yh_set_error(__VA_ARGS__); return YH_EINVAL; } } while (0)

@@ -826,19 +826,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
 // Eligible when every segment has a multiple of BKT channels (host check); everything else runs on v2.
 template <int CHR> __device__ __forceinline__ int swz_f(int row) { return CHR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
-#define YH_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
-// workgroup barrier that orders LDS accesses only: unlike __syncthreads() it does not drain LDS-DMA transfers in flight
-#define YH_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
-
-// one LDS-DMA wave instruction: 64 lanes x 16 bytes from (rsrc, per-lane voff + scalar soff) to lds .. lds + 1024
-__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voff, int soff)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(3))) void lds_void;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds, 16, voff, soff, 0, 0);
-#endif
-}
-
 // TL (tail, BKT 64 only): the channel count is a multiple of 16 but not of 64 (YOLOv5m / v5x widths: 96, 80, 160, 320 + 160 ...):
 // the last channel block of every tap runs (C % 64) / 16 of its four 16-channel sub-steps.  Its rows are still fetched whole
 // (128 bytes: the bytes behind the last channel are the next pixel's / the next tap's, zeros past the end of the buffer)

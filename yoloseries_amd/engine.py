@@ -935,7 +935,7 @@ class Program:
             return max(1, min((M + 255) // 256, (total + ntile - 1) // ntile))
         if os.environ.get("YH_WGRAD_TUNE", "1") == "0":
             return splits_for(512)
-        key = "wgrad2:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
+        key = "wgrad3:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
                                                           wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad))
         cache = _tune_cache()
         if key in cache:
