@@ -59,6 +59,25 @@ def _blocks():
     }
 
 
+def _oracle_block_param_grads(key, sd, x, gout, names):
+    """parameter gradients of one block from the CPU oracle (train-mode BatchNorm, fp32), in the order of `names`"""
+    from oracle.v5net import V5NetOracle
+    o = V5NetOracle({"blk." + k: v for k, v in sd.items()}, train=True)
+    xt = torch.from_numpy(x)
+    if key.startswith("cba"):
+        w = sd["conv.weight"]
+        k = int(w.shape[-1])
+        s, p = {"cba1x1": (1, 0), "cba3x3s2": (2, 1), "cba6x6s2": (2, 2)}[key]
+        y = o.cba(xt, "blk", k, s, p)
+    elif key == "bneck":
+        y = o.bottleneck(xt, "blk", True)
+    elif key in ("c3", "c3ns"):
+        y = o.c3(xt, "blk", key == "c3")
+    else:
+        y = o.sppf(xt, "blk")
+    return torch.autograd.grad(y, [o.params["blk." + n] for n in names], torch.from_numpy(np.asarray(gout, dtype=np.float32)))
+
+
 @pytest.mark.parametrize("key", ["cba1x1", "cba3x3s2", "cba6x6s2", "bneck", "c3", "c3ns", "sppf"])
 def test_block_golden(dev, key):
     g = np.load(os.path.join(G, "g6_blocks.npz"))
@@ -66,6 +85,7 @@ def test_block_golden(dev, key):
     ctor, _ = _blocks()[key]
     mod = ctor()
     fill_state(mod, seed)
+    sd0 = {k: v.detach().clone() for k, v in mod.state_dict().items()}
     mod = mod.to(dev)
     r = np.random.RandomState(seed + 1)
     x = r.randn(2, cin, hw, hw).astype(np.float32)
@@ -85,13 +105,21 @@ def test_block_golden(dev, key):
         # entries (nearly) tie, the route differs from the fp32 reference for a few elements
         _close(grads[0].cpu().numpy(), g[f"{key}_gx"], 6e-2, key + " gx", outlier_frac=0.005 if key == "sppf" else 0.0)
         grads = grads[1:]
-    for (n, p), gr in zip(mod.named_parameters(), grads):
+    oracle_grads = _oracle_block_param_grads(key, sd0, x, g[f"{key}_gout"], [n for n, _ in mod.named_parameters()])
+    for (n, p), gr, og in zip(mod.named_parameters(), grads, oracle_grads):
+        # the reference's own signature of this gradient (sum | abs-sum | norm | first 29 elements) ...
         sig = g[f"{key}_gp_{n}"]
         gf = gr.double().reshape(-1).cpu()
         scale = sig[1] / gf.numel() + 1e-12            # mean |grad| of the reference
         got_first = gf[:29].numpy()
         assert np.abs(got_first - sig[3:3 + len(got_first)]).max() <= 6e-2 * max(np.abs(sig[3:]).max(), scale) + 0.15 * scale, f"{key} grad {n}"
         assert abs(gf.norm().item() - sig[2]) <= 5e-2 * sig[2] + 1e-6, f"{key} grad-norm {n}: {gf.norm().item()} vs {sig[2]}"
+        # ... and EVERY element against the fp32 oracle of the block (oracle/v5net.py, itself pinned by the same signatures)
+        of = og.double().reshape(-1)
+        assert abs(of.norm().item() - sig[2]) <= 1e-4 * sig[2] + 1e-9, f"{key}: oracle gradient of {n} is not the reference's"
+        err = (gf - of).abs()
+        lim = 6e-2 * of.abs() + 0.25 * scale + 2e-2 * of.abs().max()
+        assert not (err > lim).any(), f"{key} grad {n}: {(err > lim).sum().item()} / {err.numel()} elements off (max {err.max().item():.3g})"
     for n, bf in mod.named_buffers():
         ref = g[f"{key}_buf_{n}"]
         if n.endswith("num_batches_tracked"):
