@@ -179,12 +179,13 @@ def main():
         capf = ((n_anchor + 3) // 4) * 4
         candf = torch.empty(nb, capf, 6, dtype=torch.float32, device=dev)
         ncf = torch.zeros(nb, dtype=torch.int32, device=dev)
+        dws = torch.empty(int(lib().yh_decode_filter_ws_bytes(C.byref(dd))), dtype=torch.uint8, device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(reps + 1):
             if it == 1:
                 e0.record()
             check(lib().yh_decode_filter(C.byref(dd), ptrs, float(ev.conf_threshold), float(ev.cls_threshold), candf.data_ptr(),
-                                         ncf.data_ptr(), capf, stream_ptr()), "yh_decode_filter")
+                                         ncf.data_ptr(), capf, dws.data_ptr(), stream_ptr()), "yh_decode_filter")
         e1.record()
         e1.synchronize()
         df_ms = e0.elapsed_time(e1) / reps

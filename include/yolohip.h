@@ -344,7 +344,11 @@ int yh_decode_full(const yh_decode_desc* d, const void* const* preds, float* out
  *  cand: [B][cap][6] fp32 (xmin,ymin,xmax,ymax,conf,cls) ; ncand: [B] int32 (may exceed cap: overflow)
  *  conf_ge: obj >= conf_thr ; cls_gt: cls_conf > cls_thr (v5) / obj*max>=conf & cls>=thr (yolox) */
 int yh_decode_filter(const yh_decode_desc* d, const void* const* preds, float conf_thr, float cls_thr,
-                     float* cand, int32_t* ncand, int cap, yh_stream stream);
+                     float* cand, int32_t* ncand, int cap, void* ws, yh_stream stream);
+/*  ws: yh_decode_filter_ws_bytes(d) bytes, 16-byte aligned: the image is spread over blocks of 64 pixels (rows staged through LDS
+ *  with coalesced loads), their candidates are ordered by a second, per-image pass.  ws == NULL: one workgroup per image walks
+ *  the predictions (same result; for small heads).                                                                     */
+size_t yh_decode_filter_ws_bytes(const yh_decode_desc* d);
 /* The same filter applied to an already decoded (B, N, 5+nc) fp32 tensor — the argument of
  * YOLOV5Evaluator.numba_nms (trainer/eval_yolov5.py:261-286); used after TTA merging.      */
 int yh_filter_decoded(const float* dec, int B, int N, int num_class, float conf_thr, float cls_thr, int yolox,

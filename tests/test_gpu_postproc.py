@@ -211,3 +211,40 @@ def test_nms_many_candidates_vs_oracle(dev):
     ref2 = opp.postprocess_v5(dec[:1], 0.001, 0.001, 0.65, max_keep=20000)
     assert len(ref2[0]) > 300
     np.testing.assert_array_equal(got2[0], ref2[0])
+
+
+@pytest.mark.parametrize("img,thr", [(640, 0.3), (320, 0.001), (1280, 0.3)])
+def test_decode_filter_two_pass_matches_single_block(dev, img, thr):
+    """yh_decode_filter with a workspace (image spread over 64-pixel blocks, rows staged through LDS, second pass orders the
+    candidates) against the one-workgroup-per-image walk (ws == NULL): candidate rows, order and counts bit-identical — fp32
+    heads and the engine's bf16 cell-major heads, ragged last chunks (20x20 / 10x10 maps), a cap smaller than the count"""
+    import ctypes as C
+    from yoloseries_amd import _lib
+    from yoloseries_amd._lib import check, lib
+    from yoloseries_amd.layout import to_cell_major
+    from yoloseries_amd.trainer import YOLOV5Evaluator
+    B = 3
+    heads = synth_nms_heads(B, img, 80, 3, seed=11)
+    ev = YOLOV5Evaluator(None, torch.from_numpy(COCO_ANCHORS), _hyp(dev, img=img, conf_threshold=thr, cls_threshold=thr))
+    for as_bf16 in (False, True):
+        ht = [torch.from_numpy(h).to(dev) for h in heads]
+        if as_bf16:
+            ht = [to_cell_major(h.to(torch.bfloat16))[0] for h in ht]
+        d, canon, ptrs = ev._desc(ht)
+        n = sum(3 * h.shape[2] * h.shape[3] for h in ht)
+        for cap in (((n + 3) // 4) * 4, 64):
+            res = []
+            for two_pass in (False, True):
+                cand = torch.full((B, cap, 6), -7.0, dtype=torch.float32, device=dev)
+                ncand = torch.zeros(B, dtype=torch.int32, device=dev)
+                ws = torch.empty(int(lib().yh_decode_filter_ws_bytes(C.byref(d))), dtype=torch.uint8, device=dev) if two_pass else None
+                check(lib().yh_decode_filter(C.byref(d), ptrs, thr, thr, cand.data_ptr(), ncand.data_ptr(), cap,
+                                             ws.data_ptr() if two_pass else None, _lib.stream_ptr()), "yh_decode_filter")
+                torch.cuda.synchronize()
+                res.append((cand.cpu().numpy(), ncand.cpu().numpy()))
+            (c0, n0), (c1, n1) = res
+            np.testing.assert_array_equal(n1, n0)
+            assert n0.max() > 0
+            for b in range(B):
+                k = min(int(n0[b]), cap)
+                np.testing.assert_array_equal(c1[b, :k], c0[b, :k])

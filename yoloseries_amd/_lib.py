@@ -147,7 +147,8 @@ _SIGS = {
     "yh_iou_matrix": (_i32, [_vp, _i32, _vp, _i32, _f32, _vp, _vp]),
     "yh_iou_pairwise": (_i32, [_i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "yh_decode_full": (_i32, [C.POINTER(DecodeDesc), C.POINTER(_vp), _vp, _vp]),
-    "yh_decode_filter": (_i32, [C.POINTER(DecodeDesc), C.POINTER(_vp), _f32, _f32, _vp, _vp, _i32, _vp]),
+    "yh_decode_filter": (_i32, [C.POINTER(DecodeDesc), C.POINTER(_vp), _f32, _f32, _vp, _vp, _i32, _vp, _vp]),
+    "yh_decode_filter_ws_bytes": (C.c_size_t, [C.POINTER(DecodeDesc)]),
     "yh_filter_decoded": (_i32, [_vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "yh_nms_ws_bytes": (_sz, [_i32, _i32]),
     "yh_nms_batched": (_i32, [_vp, _vp, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

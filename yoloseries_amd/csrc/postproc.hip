@@ -26,6 +26,8 @@ struct DecK {
     const void* pred[MAXS];
     int start[MAXS + 1];      // first prediction index of each stage (per image)
     int ntot;
+    int cstart[MAXS + 1];     // two-pass filter: first 64-pixel chunk of each stage; chunk keys in prediction order are
+    int kstart[MAXS + 1];     //   kstart[s] + a * nchunk(s) + c  (stage, anchor, chunk)
 };
 
 // prediction index (within an image) -> stage, anchor, y, x
@@ -90,7 +92,35 @@ __global__ void decode_full_kernel(const DecK k, float* __restrict__ out)
     }
 }
 
-// One workgroup (1024 threads) per image walks the predictions in order.
+// confidence filter + best class + box of ONE prediction row (eval_yolov5.py:266-285, eval_yolox.py:206-227); true = candidate
+template <typename T>
+__device__ __forceinline__ bool eval_pred(const DecK& k, const T* row, int s, int a, int y, int x, float conf_thr, float cls_thr,
+                                          float* box, float& conf, int& cls)
+{
+    const int nc = k.d.num_class;
+    const float obj = sigm(ldv<T>(row + 4));
+    bool pass = k.d.yolox ? true : (obj >= conf_thr);                 // eval_yolov5.py:266
+    if (!pass) return false;
+    float best = -INFINITY, best_raw = -INFINITY;
+    for (int c = 0; c < nc; ++c) {
+        const float pc = sigm(ldv<T>(row + 5 + c));
+        const float sc = pc * obj;                                // x[:, 5:] *= x[:, 4:5]
+        if (sc > best) { best = sc; cls = c; }                    // first maximum
+        if (pc > best_raw) best_raw = pc;
+    }
+    if (k.d.yolox) pass = (obj * best_raw) >= conf_thr && best >= cls_thr;   // eval_yolox.py:206-207,227
+    else           pass = best > cls_thr;                                      // eval_yolov5.py:285
+    if (!pass) return false;
+    float cb[4];
+    decode_box<T>(k, row, s, a, y, x, cb);
+    box[0] = cb[0] - cb[2] / 2.f; box[1] = cb[1] - cb[3] / 2.f;           // numba_xywh2xyxy
+    box[2] = cb[0] + cb[2] / 2.f; box[3] = cb[1] + cb[3] / 2.f;
+    conf = best;
+    return true;
+}
+
+// One workgroup (1024 threads) per image walks the predictions in order (kept for heads too small to fill the chip otherwise
+// and as the cross-check of the two-pass path in the tests: yh_decode_filter with ws == NULL).
 template <typename T>
 __global__ __launch_bounds__(1024) void decode_filter_kernel(const DecK k, float conf_thr, float cls_thr,
                                                              float* __restrict__ cand, int32_t* __restrict__ ncand, int cap)
@@ -99,7 +129,6 @@ __global__ __launch_bounds__(1024) void decode_filter_kernel(const DecK k, float
     __shared__ int base_s;
     const int b = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int nc = k.d.num_class;
     if (t == 0) base_s = 0;
     __syncthreads();
     float* out = cand + (size_t)b * cap * 6;
@@ -112,27 +141,7 @@ __global__ __launch_bounds__(1024) void decode_filter_kernel(const DecK k, float
             int s, a, y, x;
             locate(k, pi, s, a, y, x);
             const T* row = cell_ptr<T>(k, b, s, a, y, x);
-            const float obj = sigm(ldv<T>(row + 4));
-            bool pass = k.d.yolox ? true : (obj >= conf_thr);                 // eval_yolov5.py:266
-            if (pass) {
-                float best = -INFINITY, best_raw = -INFINITY;
-                for (int c = 0; c < nc; ++c) {
-                    const float pc = sigm(ldv<T>(row + 5 + c));
-                    const float sc = pc * obj;                                // x[:, 5:] *= x[:, 4:5]
-                    if (sc > best) { best = sc; cls = c; }                    // first maximum
-                    if (pc > best_raw) best_raw = pc;
-                }
-                if (k.d.yolox) pass = (obj * best_raw) >= conf_thr && best >= cls_thr;   // eval_yolox.py:206-207,227
-                else           pass = best > cls_thr;                                      // eval_yolov5.py:285
-                if (pass) {
-                    float cb[4];
-                    decode_box<T>(k, row, s, a, y, x, cb);
-                    box[0] = cb[0] - cb[2] / 2.f; box[1] = cb[1] - cb[3] / 2.f;           // numba_xywh2xyxy
-                    box[2] = cb[0] + cb[2] / 2.f; box[3] = cb[1] + cb[3] / 2.f;
-                    conf = best;
-                    flag = true;
-                }
-            }
+            flag = eval_pred<T>(k, row, s, a, y, x, conf_thr, cls_thr, box, conf, cls);
         }
         const unsigned long long bal = __ballot(flag);
         const int within = __popcll(bal & ((1ull << lane) - 1ull));
@@ -156,6 +165,95 @@ __global__ __launch_bounds__(1024) void decode_filter_kernel(const DecK k, float
     if (t == 0) ncand[b] = base_s;
 }
 
+
+
+// Two-pass form of the same filter for heads that matter (17.1 MB per 1280^2 image): pass 1 spreads the image over
+// blocks — a block owns 64 consecutive pixels of one stage, copies their prediction rows to LDS with coalesced 16-byte
+// loads and evaluates one (pixel, anchor) per thread, wave a = anchor a, so a wave ballot orders the candidates of the key
+// (stage, anchor, chunk) — and leaves them in a staging area [B][nkeys][64][6] with their counts; pass 2 (one block per
+// image) turns the counts into offsets in prediction order and moves the candidates to their final rows.  Same arithmetic,
+// same order as decode_filter_kernel.
+constexpr int DPIX = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void decode_scan_kernel(const DecK k, float conf_thr, float cls_thr,
+                                                          float* __restrict__ stage, int32_t* __restrict__ counts, int nkeys)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    T* tile = reinterpret_cast<T*>(dsm);
+    const int b = blockIdx.y;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < MAXS; ++i) if (i < k.d.num_stage && (int)blockIdx.x >= k.cstart[i]) s = i;
+    const int c = blockIdx.x - k.cstart[s];
+    const int hw = k.d.H[s] * k.d.W[s];
+    const int nchunk = (hw + DPIX - 1) / DPIX;
+    const int p0 = c * DPIX;
+    const int npix = min(DPIX, hw - p0);
+    const int ldp = k.d.ldp[s];
+    const T* src = reinterpret_cast<const T*>(k.pred[s]) + ((size_t)b * hw + p0) * ldp;
+    const int nelem = npix * ldp;
+    const int t = threadIdx.x;
+    if (((size_t)src & 15) == 0 && (nelem * (int)sizeof(T)) % 16 == 0) {
+        const int nv = nelem * (int)sizeof(T) / 16;
+        for (int i = t; i < nv; i += 256) reinterpret_cast<uint4*>(tile)[i] = reinterpret_cast<const uint4*>(src)[i];
+    } else {
+        for (int i = t; i < nelem; i += 256) tile[i] = src[i];
+    }
+    __syncthreads();
+    const int a = t >> 6, lane = t & 63;
+    if (a >= k.d.num_anchor) return;
+    bool flag = false;
+    float box[4] = {0, 0, 0, 0}, conf = 0.f;
+    int cls = 0;
+    if (lane < npix) {
+        const int pidx = p0 + lane;
+        const int y = pidx / k.d.W[s], x = pidx - y * k.d.W[s];
+        const T* row = tile + lane * ldp + a * (5 + k.d.num_class);
+        flag = eval_pred<T>(k, row, s, a, y, x, conf_thr, cls_thr, box, conf, cls);
+    }
+    const unsigned long long bal = __ballot(flag);
+    const int key = k.kstart[s] + a * nchunk + c;
+    if (lane == 0) counts[(size_t)b * nkeys + key] = __popcll(bal);
+    if (flag) {
+        float* o = stage + (((size_t)b * nkeys + key) * DPIX + __popcll(bal & ((1ull << lane) - 1ull))) * 6;
+        o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3]; o[4] = conf; o[5] = (float)cls;
+    }
+}
+
+__global__ __launch_bounds__(1024) void decode_gather_kernel(const float* __restrict__ stage, const int32_t* __restrict__ counts, int nkeys,
+                                                              float* __restrict__ cand, int32_t* __restrict__ ncand, int cap)
+{
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) base_s = 0;
+    __syncthreads();
+    float* out = cand + (size_t)b * cap * 6;
+    for (int k0 = 0; k0 < nkeys; k0 += 1024) {
+        const int key = k0 + t;
+        const int cnt = key < nkeys ? counts[(size_t)b * nkeys + key] : 0;
+        int incl = cnt;                                  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int v = wsum[w]; if (w < wv) before += v; total += v; }
+        const int base = base_s;
+        int pos = base + before + incl - cnt;
+        const float* src = stage + ((size_t)b * nkeys + key) * DPIX * 6;
+        for (int i = 0; i < cnt && pos < cap; ++i, ++pos) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) out[(size_t)pos * 6 + e] = src[i * 6 + e];
+        }
+        __syncthreads();
+        if (t == 0) base_s = base + total;
+        __syncthreads();
+    }
+    if (t == 0) ncand[b] = base_s;
+}
 
 // Candidate filter on an already decoded (B, N, 5+nc) fp32 tensor (the argument of
 // YOLOV5Evaluator.numba_nms, eval_yolov5.py:261-286), order preserving.
@@ -408,6 +506,16 @@ int fill_deck(const yh_decode_desc* d, const void* const* preds, DecK* k, const 
     }
     k->start[MAXS] = acc;
     k->ntot = acc;
+    int cacc = 0, kacc = 0;
+    for (int s = 0; s <= MAXS; ++s) {
+        k->cstart[s] = cacc;
+        k->kstart[s] = kacc;
+        if (s < d->num_stage) {
+            const int nchunk = (d->H[s] * d->W[s] + DPIX - 1) / DPIX;
+            cacc += nchunk;
+            kacc += nchunk * d->num_anchor;
+        }
+    }
     return YH_OK;
 }
 
@@ -427,13 +535,46 @@ extern "C" int yh_decode_full(const yh_decode_desc* d, const void* const* preds,
     return YH_OK;
 }
 
+/* staging area [B][nkeys][64][6] fp32 + counts [B][nkeys] int32 of the two-pass filter */
+extern "C" size_t yh_decode_filter_ws_bytes(const yh_decode_desc* d)
+{
+    if (!d || d->B <= 0 || d->num_stage < 1 || d->num_stage > MAXS || d->num_anchor < 1) return 0;
+    size_t nkeys = 0;
+    for (int s = 0; s < d->num_stage; ++s) nkeys += (size_t)((d->H[s] * d->W[s] + DPIX - 1) / DPIX) * d->num_anchor;
+    return (size_t)d->B * nkeys * (DPIX * 6 * 4 + 4);
+}
+
 extern "C" int yh_decode_filter(const yh_decode_desc* d, const void* const* preds, float conf_thr, float cls_thr,
-                                float* cand, int32_t* ncand, int cap, yh_stream stream)
+                                float* cand, int32_t* ncand, int cap, void* ws, yh_stream stream)
 {
     DecK k;
     int rc = fill_deck(d, preds, &k, "yh_decode_filter");
     if (rc) return rc;
     YH_CHECK_ARG(cand && ncand && cap > 0 && cap % 4 == 0, "yh_decode_filter: cand/ncand null or cap not a multiple of 4");
+    if (ws) {
+        YH_CHECK_ARG(yh_aligned16(ws) && d->num_anchor <= 4, "yh_decode_filter: workspace unaligned");
+        const int nkeys = k.kstart[MAXS], nchunks = k.cstart[MAXS];
+        float* stage = reinterpret_cast<float*>(ws);
+        int32_t* counts = reinterpret_cast<int32_t*>(stage + (size_t)d->B * nkeys * DPIX * 6);
+        int ldmax = 0;
+        for (int s = 0; s < d->num_stage; ++s) ldmax = d->ldp[s] > ldmax ? d->ldp[s] : ldmax;
+        const size_t sm = (size_t)DPIX * ldmax * (d->pred_is_f32 ? 4 : 2);
+        YH_CHECK_ARG(sm <= 160 * 1024, "yh_decode_filter: prediction rows of %d elements do not fit the LDS tile", ldmax);
+        const dim3 grid(nchunks, d->B);
+        if (d->pred_is_f32) {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)decode_scan_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL((decode_scan_kernel<float>), grid, dim3(256), sm, (hipStream_t)stream, k, conf_thr, cls_thr, stage, counts, nkeys);
+        } else {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)decode_scan_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL((decode_scan_kernel<uint16_t>), grid, dim3(256), sm, (hipStream_t)stream, k, conf_thr, cls_thr, stage, counts, nkeys);
+        }
+        YH_CHECK_LAUNCH("yh_decode_filter(scan)");
+        hipLaunchKernelGGL(decode_gather_kernel, dim3(d->B), dim3(1024), 0, (hipStream_t)stream, stage, counts, nkeys, cand, ncand, cap);
+        YH_CHECK_LAUNCH("yh_decode_filter(gather)");
+        return YH_OK;
+    }
     if (d->pred_is_f32) hipLaunchKernelGGL((decode_filter_kernel<float>), dim3(d->B), dim3(1024), 0, (hipStream_t)stream, k, conf_thr, cls_thr, cand, ncand, cap);
     else                hipLaunchKernelGGL((decode_filter_kernel<uint16_t>), dim3(d->B), dim3(1024), 0, (hipStream_t)stream, k, conf_thr, cls_thr, cand, ncand, cap);
     YH_CHECK_LAUNCH("yh_decode_filter");

@@ -17,6 +17,16 @@ from ..layout import to_cell_major
 __all__ = ['YOLOV5Evaluator']
 
 
+
+def _decode_ws(owner, d, dev):
+    """workspace of the two-pass decode + filter (yh_decode_filter_ws_bytes), kept on the evaluator between calls"""
+    need = int(lib().yh_decode_filter_ws_bytes(C.byref(d)))
+    ws = getattr(owner, "_decode_ws_buf", None)
+    if ws is None or ws.numel() < need or ws.device != torch.device(dev):
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        owner._decode_ws_buf = ws
+    return ws.data_ptr()
+
 class YOLOV5Evaluator:
 
     def __init__(self, yolo, anchors, hyp, compute_metric=False):
@@ -117,7 +127,7 @@ class YOLOV5Evaluator:
             cand = torch.empty(B, cap, 6, dtype=torch.float32, device=dev)
             ncand = torch.zeros(B, dtype=torch.int32, device=dev)
             check(lib().yh_decode_filter(C.byref(d), ptrs, float(self.conf_threshold), float(self.cls_threshold),
-                                         cand.data_ptr(), ncand.data_ptr(), cap, _lib.stream_ptr()), "yh_decode_filter")
+                                         cand.data_ptr(), ncand.data_ptr(), cap, _decode_ws(self, d, dev), _lib.stream_ptr()), "yh_decode_filter")
             if cap >= n or int(ncand.max().item()) <= cap:
                 break
             cap = ((n + 3) // 4) * 4

@@ -6,7 +6,7 @@ import torch
 from .. import _lib
 from .._lib import DecodeDesc, check, lib
 from ..layout import to_cell_major
-from .eval_yolov5 import YOLOV5Evaluator
+from .eval_yolov5 import YOLOV5Evaluator, _decode_ws
 
 __all__ = ['YOLOXEvaluator']
 
@@ -98,7 +98,7 @@ class YOLOXEvaluator(YOLOV5Evaluator):
         cand = torch.empty(B, cap, 6, dtype=torch.float32, device=dev)
         ncand = torch.zeros(B, dtype=torch.int32, device=dev)
         check(lib().yh_decode_filter(C.byref(d), ptrs, float(self.conf_threshold), float(self.cls_threshold),
-                                     cand.data_ptr(), ncand.data_ptr(), cap, _lib.stream_ptr()), "yh_decode_filter")
+                                     cand.data_ptr(), ncand.data_ptr(), cap, _decode_ws(self, d, dev), _lib.stream_ptr()), "yh_decode_filter")
         return self._run_nms(cand, ncand, B, cap)
 
     def numba_nms(self, preds_out):
