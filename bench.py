@@ -341,7 +341,7 @@ def _pmc_traffic():
 
 
 _PMC_ALIAS = {"yh_bn_silu_bwd_reduce": ("col_reduce_kernel<0>",), "yh_colsum": ("col_reduce_kernel<1>", "colsum_finalize_kernel"),
-              "yh_bn_fold": ("bn_fold_kernel",)}
+              "yh_bn_fold": ("bn_fold_batch_kernel",)}
 
 
 def _pmc_bytes(pmc, name):

@@ -167,6 +167,14 @@ int yh_bn_finalize(const float* stats, int nblk, int ldstat, int C, int64_t coun
 /* inference fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale         */
 int yh_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv,
                float eps, int C, float* scale, float* shift, yh_stream stream);
+/* the same for every BatchNorm of a network in one launch: `items_dev` is a table of nitems entries in DEVICE memory
+ * (the pointers inside it are device pointers; built once per program by the caller)                                 */
+typedef struct yh_bn_fold_item {
+    const float* gamma; const float* beta; const float* rm; const float* rv;
+    float* scale; float* shift;
+    float eps; int32_t C;
+} yh_bn_fold_item;
+int yh_bn_fold_batch(const yh_bn_fold_item* items_dev, int nitems, yh_stream stream);
 /* out = silu(y*scale+shift) (+res) ; all bf16 NHWC slices                      */
 int yh_bn_silu_apply(const yh_bf16* y, int ldy, const float* ws, int C, int64_t M,
                      yh_bf16* out, int ldo, const yh_bf16* res, int ldr, yh_stream stream);

@@ -331,3 +331,40 @@ def test_conv_concat_upsample_algos(dev, algo):
     _close(out0, a[..., :64].to(torch.bfloat16).float() + res.float(), 1e-2, 3e-2)
     _close(out1[..., 32:], a[..., 64:], 8e-3, 2e-2)
     assert (out1[..., :32] == 0).all()
+
+
+@pytest.mark.parametrize("Cout", [32, 48, 64, 80])
+def test_conv_stem_kernel(dev, Cout):
+    """the strip kernel of the stem (3x3 on the 16-channel space-to-depth image, 1..3 output tiles of 32 channels: v5s 32, v5m 48,
+    v5l 64, v5x 80): plain store + BatchNorm partial sums, and folded BatchNorm + SiLU (inference)"""
+    from yoloseries_amd import hipk
+    B, H, W, Cin = 2, 24, 64, 16
+    x = _nhwc(B, H, W, Cin, dev, 41)
+    g = torch.Generator().manual_seed(42)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    ref = F.conv2d(_nchw(x), w, None, stride=1, padding=1).permute(0, 2, 3, 1)
+    # training form: raw output + per-block partial sums
+    out = torch.full((B, H, W, Cout), 7.0, dtype=torch.bfloat16, device=dev)
+    d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.full(out))
+    stats = torch.zeros(hipk.conv_stat_blocks(d), 2, wp.shape[0], device=dev)
+    d.stats = stats.data_ptr()
+    if Cout <= 64:
+        assert "conv_stem_kernel<1" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out, ref, 8e-3, 2e-2)
+    o = out.float().reshape(-1, Cout).double()
+    assert ((stats[:, 0, :Cout].double().sum(0) - o.sum(0)).abs() <= 1e-2 + 4 * 2.0 ** -9 * (o ** 2).sum(0).sqrt()).all()
+    assert ((stats[:, 1, :Cout].double().sum(0) - (o ** 2).sum(0)).abs() <= 1e-2 + 4 * 2.0 ** -8 * (o ** 4).sum(0).sqrt()).all()
+    # inference form: folded BatchNorm + SiLU; the output is a channel slice of a wider buffer that must stay untouched outside it
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=g).to(dev)
+    obuf = torch.full((B, H, W, Cout + 16), 3.0, dtype=torch.bfloat16, device=dev)
+    d2 = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.Slice(obuf, 8, Cout),
+                        scale=scale, shift=shift, act=hipk.YH_ACT_SILU)
+    assert "conv_stem_kernel<2" in _kname(d2), _kname(d2)
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    _close(obuf[..., 8:8 + Cout], F.silu(ref * scale + shift), 8e-3, 2e-2)
+    assert (obuf[..., :8] == 3.0).all() and (obuf[..., 8 + Cout:] == 3.0).all()

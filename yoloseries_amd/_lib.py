@@ -92,6 +92,11 @@ class DecodeDesc(C.Structure):
     ]
 
 
+class BnFoldItem(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("rm", C.c_void_p), ("rv", C.c_void_p),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("eps", C.c_float), ("C", C.c_int32)]
+
+
 YH_CONV_FWD, YH_CONV_DGRAD = 0, 1
 YH_ACT_NONE, YH_ACT_SILU = 0, 1
 
@@ -111,6 +116,7 @@ _SIGS = {
     "yh_conv_kernel_name": (_i32, [C.POINTER(ConvDesc), C.c_char_p, _i32]),
     "yh_bn_finalize": (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
     "yh_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
+    "yh_bn_fold_batch": (_i32, [_vp, _i32, _vp]),
     "yh_bn_silu_apply": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
     "yh_bn_silu_apply_acc": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "yh_bn_silu_bwd_reduce_acc": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp]),

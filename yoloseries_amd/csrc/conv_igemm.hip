@@ -1683,11 +1683,16 @@ constexpr size_t conv3_smem_bytes() {
 // The layer moves 630 MB for 0.6 GFLOP/MB: it is HBM bound.
 struct StemTag {};
 
-template <int EPI>    // 0 plain, 1 + BatchNorm partial sums, 2 folded BN (scale, shift) + SiLU
-__global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvK p)
+// NTL = output-channel tiles of 32 (v5s 32 -> 1; v5m 48 / v5l 64 -> 2; v5x 80 -> 3, inference only: the running sums of
+// three tiles do not fit the register file): the nine fragments of every tile stay in registers, a strip's nine input
+// fragments are loaded once and multiplied with each tile in turn.
+template <int EPI, int NTL>    // 0 plain, 1 + BatchNorm partial sums, 2 folded BN (scale, shift) + SiLU
+__global__ __launch_bounds__(256, NTL == 3 ? 1 : 2) void conv_stem_kernel(const ConvK p)
 {
     constexpr unsigned OOB = 0x80000000u;
-    __shared__ float sRed[4][2][32];
+    static_assert(EPI != 1 || NTL <= 2, "statistics: at most two channel tiles");
+    __shared__ float sRed[EPI == 1 ? 4 : 1][2][32 * NTL];
+    __shared__ __attribute__((aligned(16))) float sConst[2][32 * NTL];           // EPI 2: scale | shift
     const yh_conv_desc& d = p.d;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -1695,23 +1700,29 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvK p)
     const int ldx = d.seg[0].ld * 2;                  // bytes per input pixel
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg[0].ptr, 0, p.segbytes[0], 0x00020000);
 
-    // weights: fragment of tap t for this lane = W[n = r][t*16 + 8h .. +8]
-    bf16x8_t wf[9];
+    // weights: fragment of tap t for this lane = W[n = 32 nt + r][t*16 + 8h .. +8] (rows past N are zero in the packed image)
+    bf16x8_t wf[NTL][9];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
-        wf[tp] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(d.w + (size_t)r * p.Ktot + tp * 16 + 8 * h));
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+            wf[nt][tp] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(d.w + (size_t)(nt * 32 + r) * p.Ktot + tp * 16 + 8 * h));
 
-    // channels of this lane after the MFMA: group g (0..3) -> 8g + 4h + (0..3)
-    float scl[16], sft[16];
     if (EPI == 2) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { scl[g * 4 + e] = d.scale[8 * g + 4 * h + e]; sft[g * 4 + e] = d.shift[8 * g + 4 * h + e]; }
+        for (int i = t; i < 2 * 32 * NTL; i += 256) {
+            const int which = i / (32 * NTL), c = i - which * (32 * NTL);
+            sConst[which][c] = c < d.N ? (which == 0 ? d.scale[c] : d.shift[c]) : 0.f;
+        }
+        __syncthreads();
     }
-    float ssum[16], ssq[16];
+    // channels of this lane after the MFMA: tile nt, group g (0..3) -> 32 nt + 8g + 4h + (0..3)
+    float ssum[EPI == 1 ? NTL : 1][16], ssq[EPI == 1 ? NTL : 1][16];
+    if (EPI == 1) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ssum[nt][e] = 0.f; ssq[nt][e] = 0.f; }
+    }
 
     const int nstrip = p.M >> 5;                      // W % 32 == 0: strips never cross an image row
     const int wstride = gridDim.x * 4;
@@ -1737,47 +1748,56 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvK p)
         }
     };
     auto compute = [&](int s, int set) __attribute__((always_inline)) {
-        f32x16_t acc;
+        const size_t m = (size_t)s * 32 + r;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int nt = 0; nt < NTL; ++nt) {
+            f32x16_t acc;
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tp], __builtin_bit_cast(bf16x8_t, set == 0 ? xa[0][tp] : xa[1][tp]), acc, 0, 0, 0);
-        // acc[g*4 + e]: pixel r, channel 8g + 4h + e
-        uint32_t pk[4][2];
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v[4];
+            for (int tp = 0; tp < 9; ++tp)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][tp], __builtin_bit_cast(bf16x8_t, set == 0 ? xa[0][tp] : xa[1][tp]), acc, 0, 0, 0);
+            // acc[g*4 + e]: pixel r, channel 32 nt + 8g + 4h + e
+            uint32_t pk[4][2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = acc[g * 4 + e];
-                if (EPI == 2) { v[e] = v[e] * scl[g * 4 + e] + sft[g * 4 + e]; if (d.act == YH_ACT_SILU) v[e] = silu_fast(v[e]); }
-            }
-            pk[g][0] = pack2(v[0], v[1]);
-            pk[g][1] = pack2(v[2], v[3]);
-            if (EPI == 1) {                           // statistics of the stored (bf16-rounded) values
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float q = __uint_as_float(e & 1 ? (pk[g][e >> 1] & 0xffff0000u) : (pk[g][e >> 1] << 16));
-                    ssum[g * 4 + e] += q; ssq[g * 4 + e] += q * q;
+                for (int e = 0; e < 4; ++e) v[e] = acc[g * 4 + e];
+                if (EPI == 2) {
+                    const float4 sc = *reinterpret_cast<const float4*>(&sConst[0][nt * 32 + 8 * g + 4 * h]);
+                    const float4 sh = *reinterpret_cast<const float4*>(&sConst[1][nt * 32 + 8 * g + 4 * h]);
+                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                    if (d.act == YH_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_fast(v[e]);
+                    }
+                }
+                pk[g][0] = pack2(v[0], v[1]);
+                pk[g][1] = pack2(v[2], v[3]);
+                if (EPI == 1) {                           // statistics of the stored (bf16-rounded) values
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float q = __uint_as_float(e & 1 ? (pk[g][e >> 1] & 0xffff0000u) : (pk[g][e >> 1] << 16));
+                        ssum[EPI == 1 ? nt : 0][g * 4 + e] += q; ssq[EPI == 1 ? nt : 0][g * 4 + e] += q * q;
+                    }
                 }
             }
+            // lanes l / l+32: lower half keeps its channels 8g..8g+3 of g = 0, 2 and receives 8g+4..8g+7 from the upper
+            // half; the upper half ends up with the 16-byte chunks of g = 1, 3
+            uint4 c01, c23;
+            {
+                auto a0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                auto a1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                auto b0 = __builtin_amdgcn_permlane32_swap(pk[2][0], pk[3][0], false, false);
+                auto b1 = __builtin_amdgcn_permlane32_swap(pk[2][1], pk[3][1], false, false);
+                c01 = make_uint4(a0[0], a1[0], a0[1], a1[1]);
+                c23 = make_uint4(b0[0], b1[0], b0[1], b1[1]);
+            }
+            uint16_t* dst = d.out0 + m * d.ld0 + nt * 32 + 8 * h;
+            *reinterpret_cast<uint4*>(dst) = c01;                                  // channels 32nt +  0..7  (h = 0) /  8..15 (h = 1)
+            if (nt * 32 + 16 < d.N) *reinterpret_cast<uint4*>(dst + 16) = c23;     // channels 32nt + 16..23 (h = 0) / 24..31 (h = 1)
         }
-        // lanes l / l+32: lower half keeps its channels 8g..8g+3 of g = 0, 2 and receives 8g+4..8g+7 from the upper
-        // half; the upper half ends up with the 16-byte chunks of g = 1, 3
-        uint4 c01, c23;
-        {
-            auto a0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
-            auto a1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
-            auto b0 = __builtin_amdgcn_permlane32_swap(pk[2][0], pk[3][0], false, false);
-            auto b1 = __builtin_amdgcn_permlane32_swap(pk[2][1], pk[3][1], false, false);
-            c01 = make_uint4(a0[0], a1[0], a0[1], a1[1]);
-            c23 = make_uint4(b0[0], b1[0], b0[1], b1[1]);
-        }
-        const size_t m = (size_t)s * 32 + r;
-        uint16_t* dst = d.out0 + m * d.ld0 + 8 * h;
-        *reinterpret_cast<uint4*>(dst) = c01;            // channels  0..7  (h = 0) /  8..15 (h = 1)
-        *reinterpret_cast<uint4*>(dst + 16) = c23;       // channels 16..23 (h = 0) / 24..31 (h = 1)
     };
 
     int s = blockIdx.x * 4 + wave;
@@ -1793,28 +1813,31 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(const ConvK p)
     }
 
     if (EPI == 1) {
-        // lane holds 16 channels x its pixel column: sum over the 32 pixel lanes of each half, then over the waves
+        // lane holds 16 channels x its pixel column per tile: sum over the 32 pixel lanes of each half, then over the waves
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float a = ssum[e], q = ssq[e];
+        for (int nt = 0; nt < (EPI == 1 ? NTL : 1); ++nt)
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
-            if (r == 0) { const int ch = 8 * (e >> 2) + 4 * h + (e & 3); sRed[wave][0][ch] = a; sRed[wave][1][ch] = q; }
-        }
+            for (int e = 0; e < 16; ++e) {
+                float a = ssum[nt][e], q = ssq[nt][e];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+                if (r == 0) { const int ch = nt * 32 + 8 * (e >> 2) + 4 * h + (e & 3); sRed[wave][0][ch] = a; sRed[wave][1][ch] = q; }
+            }
         __syncthreads();
-        if (t < 64) {
-            const int which = t >> 5, ch = t & 31;
+        if (t < 64 * NTL) {
+            const int which = t / (32 * NTL), ch = t - which * (32 * NTL);
             const float v = sRed[0][which][ch] + sRed[1][which][ch] + sRed[2][which][ch] + sRed[3][which][ch];
-            put_stat(d, blockIdx.x, which, ch, v);
+            if (ch < d.Npad) put_stat(d, blockIdx.x, which, ch, v);
         }
     }
 }
 
-// geometry the stem kernel covers
 bool stem_eligible(const yh_conv_desc* d)
 {
     if (d->mode != YH_CONV_FWD || d->nseg != 1 || d->seg[0].C != 16 || d->seg[0].ups) return false;
-    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->N != 32 || d->Npad < 32) return false;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1) return false;
+    if (d->N < 32 || d->N > 96 || d->N % 16 || d->Npad < ((d->N + 31) / 32) * 32) return false;     // 1..3 channel tiles of 32
+    if (d->stats && d->N > 64) return false;                                                        // statistics: at most two tiles
     if (d->Wo % 32 || d->bias || d->res || d->accumulate || d->nsplit < d->N) return false;
     if ((d->scale == nullptr) != (d->shift == nullptr)) return false;
     if (d->stats && d->scale) return false;
@@ -2076,12 +2099,18 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (d->nseg == 1) { k.d.seg[1] = k.d.seg[0]; }
     if (stem_eligible(d)) {
         const int epi = d->scale ? 2 : (d->stats ? 1 : 0);
-        if (name_out) { snprintf(name_out, name_len, "conv_stem_kernel<%d>", epi); return YH_OK; }
+        const int ntl = (d->N + 31) / 32;
+        if (name_out) { snprintf(name_out, name_len, "conv_stem_kernel<%d, %d>", epi, ntl); return YH_OK; }
         hipStream_t sst = (hipStream_t)stream;
         const dim3 sg(gx), sb(256);
-        if (epi == 2)      conv_stem_kernel<2><<<sg, sb, 0, sst>>>(k);
-        else if (epi == 1) conv_stem_kernel<1><<<sg, sb, 0, sst>>>(k);
-        else               conv_stem_kernel<0><<<sg, sb, 0, sst>>>(k);
+#define YH_LAUNCH_STEM(NTL_)                                                            \
+        do {                                                                            \
+            if (epi == 2)      conv_stem_kernel<2, NTL_><<<sg, sb, 0, sst>>>(k);        \
+            else if (epi == 1) conv_stem_kernel<1, NTL_ <= 2 ? NTL_ : 2><<<sg, sb, 0, sst>>>(k); \
+            else               conv_stem_kernel<0, NTL_><<<sg, sb, 0, sst>>>(k);        \
+        } while (0)
+        if (ntl == 1) YH_LAUNCH_STEM(1); else if (ntl == 2) YH_LAUNCH_STEM(2); else YH_LAUNCH_STEM(3);
+#undef YH_LAUNCH_STEM
         YH_CHECK_LAUNCH("yh_conv_igemm(stem)");
         return YH_OK;
     }

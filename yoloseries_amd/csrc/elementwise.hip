@@ -107,6 +107,17 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     shift[c] = beta[c] - rm[c] * s;
 }
 
+// every BatchNorm of a network in ONE launch: block b folds item b (a table in device memory)
+__global__ void bn_fold_batch_kernel(const yh_bn_fold_item* items)
+{
+    const yh_bn_fold_item it = items[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += blockDim.x) {
+        float s = it.gamma[c] / sqrtf(it.rv[c] + it.eps);
+        it.scale[c] = s;
+        it.shift[c] = it.beta[c] - it.rm[c] * s;
+    }
+}
+
 // ---------------------------------------------------------------- BN+SiLU apply
 // Grid-stride over 16-byte chunks with a stride that is a multiple of the chunks per row, so a thread
 // keeps its 8 channels for the whole pass and the per-channel constants live in registers.
@@ -658,6 +669,14 @@ extern "C" int yh_bn_fold(const float* gamma, const float* beta, const float* rm
     YH_CHECK_ARG(gamma && beta && rm && rv && scale && shift && C > 0, "yh_bn_fold: bad args");
     hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps, C, scale, shift);
     YH_CHECK_LAUNCH("yh_bn_fold");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_fold_batch(const yh_bn_fold_item* items_dev, int nitems, yh_stream stream)
+{
+    YH_CHECK_ARG(items_dev && nitems > 0, "yh_bn_fold_batch: bad args");
+    hipLaunchKernelGGL(bn_fold_batch_kernel, dim3(nitems), dim3(256), 0, (hipStream_t)stream, items_dev);
+    YH_CHECK_LAUNCH("yh_bn_fold_batch");
     return YH_OK;
 }
 

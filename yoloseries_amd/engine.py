@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import hipk
-from ._lib import (ConvDesc, WgradDesc, YH_ACT_NONE, YH_ACT_SILU, YH_CONV_DGRAD, YH_CONV_FWD, YoloHipError, check, lib)
+from ._lib import (BnFoldItem, ConvDesc, WgradDesc, YH_ACT_NONE, YH_ACT_SILU, YH_CONV_DGRAD, YH_CONV_FWD, YoloHipError, check, lib)
 from .hipk import Slice
 
 BN_EPS_DEFAULT = 1e-3
@@ -486,6 +486,7 @@ class Program:
         B, pk, L = self.B, self.pack, self.L
         self.cmd_train, self.cmd_eval = None, []
         self.op_state = {}
+        fold_items = []                 # every BatchNorm of the net is folded to (scale, shift) by ONE launch ahead of the convs
         for op in self.ops:
             if isinstance(op, PoolOp):
                 s, dd = op.src.sl(), op.dst.sl()
@@ -508,9 +509,11 @@ class Program:
             st['fold'] = torch.zeros(2, op.N, dtype=torch.float32, device=self.dev)
             c0 = 0
             for (conv, bn), n in zip(op.parts, op.part_N):
-                self.cmd_eval.append((L.yh_bn_fold, (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
-                                                     bn.running_var.data_ptr(), float(bn.eps), n,
-                                                     st['fold'].data_ptr() + 4 * c0, st['fold'].data_ptr() + 4 * (op.N + c0)), op.name, ('yh_bn_fold', 0, 0.0)))
+                it = BnFoldItem()
+                it.gamma, it.beta, it.rm, it.rv = bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                it.scale, it.shift = st['fold'].data_ptr() + 4 * c0, st['fold'].data_ptr() + 4 * (op.N + c0)
+                it.eps, it.C = float(bn.eps), n
+                fold_items.append(it)
                 c0 += n
             de.scale, de.shift = st['fold'].data_ptr(), st['fold'].data_ptr() + 4 * op.N
             de.act = YH_ACT_SILU
@@ -526,6 +529,10 @@ class Program:
             st['desc_eval'] = de
             self._tune_conv(de, 'eval', op.name)
             self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name, self._fam_conv(op, de)))
+        if fold_items:
+            arr = (BnFoldItem * len(fold_items))(*fold_items)
+            self.fold_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+            self.cmd_eval.insert(0, (L.yh_bn_fold_batch, (self.fold_table.data_ptr(), len(fold_items)), "bn_fold", ('yh_bn_fold', 0, 0.0)))
         _tune_cache_save()
 
     def _build_train(self):
