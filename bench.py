@@ -310,7 +310,7 @@ def _instrument(prog, step, nsteps):
     for key, recs in prof.items():
         name, flops, nbytes, opname = key
         ms = sum(s.elapsed_time(e) for s, e in recs)
-        per_op.append((ms / nsteps, name, opname, flops, nbytes))
+        per_op.append((ms / nsteps, name, opname, flops * len(recs) / nsteps, nbytes * len(recs) / nsteps))
         f = fam.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
         f["ms"] += ms
         f["flops"] += flops * len(recs)

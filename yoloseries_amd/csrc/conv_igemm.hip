@@ -2162,7 +2162,7 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         const int stg = v3 == 1 ? (bkt3 == 64 ? 3 : 4) : (v3 == 2 ? (bkt3 == 64 ? 2 : 4) : (bkt3 == 64 ? 3 : 4));
         if (name_out) {
             snprintf(name_out, name_len, "conv_v3_kernel<%d, %d, %d, 2, %d, %d, %d%s>", bmt, bn, v3 == 1 ? 4 : 2, bkt3, stg, epi,
-                     tl3 ? ", true" : "");
+                     tl3 ? ", true" : ", false");
             return YH_OK;
         }
         hipStream_t st3 = (hipStream_t)stream;

@@ -274,8 +274,8 @@ int wg_config(int N, int Kseg)
     return N <= 64 ? 5 : 6;
 }
 const char* const wg_names[7] = {
-    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3, true>", "conv_wgrad_kernel<1, 4, 1, 3, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 1, 32, 4>",
-    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3>", "conv_wgrad_kernel<1, 4, 2, 3, 32, 2>", "conv_wgrad_kernel<2, 2, 1, 2, 64, 3, true>",
+    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3, true>", "conv_wgrad_kernel<1, 4, 1, 3, 32, 3, false>", "conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false>",
+    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false>", "conv_wgrad_kernel<1, 4, 2, 3, 32, 2, false>", "conv_wgrad_kernel<2, 2, 1, 2, 64, 3, true>",
     "conv_wgrad_kernel<4, 2, 1, 2, 64, 4, true>"};
 
 }  // namespace

@@ -955,7 +955,7 @@ class Program:
             wd.gy = self.gy_scratch.data_ptr()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         name = self.L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
-        tks = (0, 64) if name in ("conv_wgrad_kernel<1, 4, 2, 1, 32, 4>", "conv_wgrad_kernel<1, 4, 2, 2, 32, 3>") else (0,)
+        tks = (0, 64) if name in ("conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false>", "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false>") else (0,)
         best, best_ms = None, None
         for tk in tks:
             wd.tile_k = tk
@@ -983,8 +983,8 @@ class Program:
         """instantiation yh_conv_wgrad launches for this descriptor, profiler spelling (64-pixel k-steps on the wide tilings:
         csrc/conv_wgrad.hip, yh_conv_wgrad)"""
         name = L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
-        if wd.tile_k == 64 and name in ("conv_wgrad_kernel<1, 4, 2, 1, 32, 4>", "conv_wgrad_kernel<1, 4, 2, 2, 32, 3>"):
-            name = name.replace("32, 4>", "64, 2>").replace("32, 3>", "64, 2>")
+        if wd.tile_k == 64 and name in ("conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false>", "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false>"):
+            name = name.replace("32, 4, false>", "64, 2, false>").replace("32, 3, false>", "64, 2, false>")
         return name
 
     def _bucket_ready(self, bucket_hook, bucket, main, side):
