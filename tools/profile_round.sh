@@ -17,6 +17,7 @@ S=$(find $OUT/serial -name "*kernel_stats.csv" | head -1); cp "$S" $OUT/${TAG}_k
 S=$(find $OUT/b64 -name "*kernel_stats.csv" | head -1); cp "$S" $OUT/${TAG}_kernel_stats_bench_b64.csv
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_traffic.py "$F" "$W" $OUT/pmc_traffic.json 4 > $OUT/pmc_top.txt
+cp $OUT/pmc_traffic.json profiles/pmc_traffic.json       # the bench lines below report `traffic` from the passes just taken (same library)
 python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 # the other BASELINE configs at one GPU (bench lines only): YOLOXs train, YOLOv5l train, YOLOv5x inference at 1280^2 (batch 128, per-layer table)
 python3 bench.py --workload yolox --no-cpu-baseline > $OUT/${TAG}_bench_yolox.json 2> $OUT/bench_yolox.err
