@@ -98,6 +98,8 @@ def main():
                     help="train: YOLOv5 train step (BASELINE configs[1], the default and the judged metric); yolox: YOLOXs + SimOTA "
                          "train step (configs[2]); infer: YOLOv5 eval forward + decode + class-aware NMS (configs[4]: --model xlarge --img 1280)")
     args = ap.parse_args()
+    global PMC_WORKLOAD
+    PMC_WORKLOAD = f"{args.workload}:{args.model}:{args.batch}:{args.img}"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -326,16 +328,20 @@ def _lib_sha16():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
+PMC_WORKLOAD = None      # "<workload>:<model>:<batch>:<img>" of this run, set by main()
+
+
 def _pmc_traffic():
     """per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py): counters cannot be read from
-    inside the process.  The file is stamped with the hash of the libyolohip.so it was collected with; a different library
-    means the numbers describe other kernels, and they are dropped (null) instead of being reported stale."""
+    inside the process.  The file is stamped with the hash of the libyolohip.so it was collected with and with the workload
+    it was collected on; a different library or workload means the numbers describe other kernels / other shapes, and they
+    are dropped (null) instead of being reported stale."""
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
             j = json.load(f)
     except (OSError, ValueError):
         return None
-    if j.get("lib_sha16") != _lib_sha16():
+    if j.get("lib_sha16") != _lib_sha16() or j.get("workload", "train:small:64:640") != PMC_WORKLOAD:
         return None
     return j
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same bench command.
 
-usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [steps profiled]
+usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [steps profiled] [workload tag]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are
 in KiB-like units of 1024 B; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) streaming reads
@@ -57,7 +57,8 @@ def main():
     with open(sys.argv[3], "w") as f:
         json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 (gfx950), unit 1024 B; "
                             "lib_sha16 = sha256 of the libyolohip.so the passes ran with (bench.py drops the numbers when it differs)",
-                   "lib_sha16": sha, "steps_profiled": steps, "hbm_bytes_all_launches": total,
+                   "lib_sha16": sha, "workload": (sys.argv[5] if len(sys.argv) > 5 else "train:small:64:640"),
+                   "steps_profiled": steps, "hbm_bytes_all_launches": total,
                    "hbm_bytes_per_step": (total / steps if steps else None), "kernels": out}, f, indent=1)
     top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
     for k, v in top:
