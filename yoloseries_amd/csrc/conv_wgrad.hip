@@ -327,7 +327,7 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     // pixels per k-step: 32 for the wide tilings (more resident blocks), 64 when asked for (d->tile_k == 64: half the barriers and
     // twice the loads in flight per thread; the engine times both per layer) and for the general tiles
     const int cfg = wg_config(d->N, k.Kseg);
-    const bool tk64 = wide && d->tile_k == 64 && (cfg == 2 || cfg == 3);
+    const bool tk64 = wide && d->tile_k == 64 && cfg <= 3;
     const int TK = (wide && !tk64) ? 32 : 64;
     int splits = d->splits;
     int rps = (int)((M + splits - 1) / splits);
@@ -343,10 +343,10 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     k.ctiles = wide ? 1 : (k.Kseg + 127) / 128;
     switch (cfg) {
     case 0:
-        if (k.Kseg <= 160) YH_WG(1, 5, 1, 1, 32, 3, (d->N + 31) / 32, true);  // stem: 5 waves x one 32-column tile (144 of 160 used)
-        else               YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32, true);
+        if (k.Kseg <= 160) { if (tk64) YH_WG(1, 5, 1, 1, 64, 3, (d->N + 31) / 32, true); else YH_WG(1, 5, 1, 1, 32, 3, (d->N + 31) / 32, true); }  // stem: 5 waves x one 32-column tile (144 of 160 used)
+        else               { if (tk64) YH_WG(1, 4, 1, 2, 64, 2, (d->N + 31) / 32, true); else YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32, true); }
         break;
-    case 1: YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32, false); break;
+    case 1: if (tk64) YH_WG(1, 4, 1, 3, 64, 2, (d->N + 31) / 32, false); else YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32, false); break;
     case 2: if (tk64) YH_WG(1, 4, 2, 1, 64, 2, (d->N + 63) / 64, false); else YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64, false); break;
     case 3: if (tk64) YH_WG(1, 4, 2, 2, 64, 2, (d->N + 63) / 64, false); else YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64, false); break;
     case 4: YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64, false); break;

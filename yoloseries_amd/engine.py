@@ -79,6 +79,16 @@ ACC_ROWS = int(os.environ.get("YH_ACC_ROWS", "8"))
 NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weight gradients may lag behind by
 
 
+# wide weight-gradient tilings that also exist with 64-pixel k-steps (yh_wgrad_desc.tile_k = 64): 32-pixel name -> 64-pixel name
+_WGRAD_TK64 = {
+    "conv_wgrad_kernel<1, 5, 1, 1, 32, 3, true>": "conv_wgrad_kernel<1, 5, 1, 1, 64, 3, true>",
+    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3, true>": "conv_wgrad_kernel<1, 4, 1, 2, 64, 2, true>",
+    "conv_wgrad_kernel<1, 4, 1, 3, 32, 3, false>": "conv_wgrad_kernel<1, 4, 1, 3, 64, 2, false>",
+    "conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false>": "conv_wgrad_kernel<1, 4, 2, 1, 64, 2, false>",
+    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false>": "conv_wgrad_kernel<1, 4, 2, 2, 64, 2, false>",
+}
+
+
 def plan_grad_buckets(marks, gsize, nbuckets):
     """Buckets of the packed gradient arena for the data-parallel exchange.  `marks` lists, in backward order,
     (command index after which an op's gradients are complete, start of the op's slice); ops are laid out in
@@ -942,7 +952,7 @@ class Program:
             return max(1, min((M + 255) // 256, (total + ntile - 1) // ntile))
         if os.environ.get("YH_WGRAD_TUNE", "1") == "0":
             return splits_for(512)
-        key = "wgrad3:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
+        key = "wgrad4:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
                                                           wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad))
         cache = _tune_cache()
         if key in cache:
@@ -955,7 +965,7 @@ class Program:
             wd.gy = self.gy_scratch.data_ptr()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         name = self.L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
-        tks = (0, 64) if name in ("conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false>", "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false>") else (0,)
+        tks = (0, 64) if name in _WGRAD_TK64 else (0,)
         best, best_ms = None, None
         for tk in tks:
             wd.tile_k = tk
@@ -983,8 +993,8 @@ class Program:
         """instantiation yh_conv_wgrad launches for this descriptor, profiler spelling (64-pixel k-steps on the wide tilings:
         csrc/conv_wgrad.hip, yh_conv_wgrad)"""
         name = L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
-        if wd.tile_k == 64 and name in ("conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false>", "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false>"):
-            name = name.replace("32, 4, false>", "64, 2, false>").replace("32, 3, false>", "64, 2, false>")
+        if wd.tile_k == 64:
+            name = _WGRAD_TK64.get(name, name)
         return name
 
     def _bucket_ready(self, bucket_hook, bucket, main, side):
