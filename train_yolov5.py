@@ -30,23 +30,29 @@ from yoloseries_amd.trainer import ExponentialMovingAverageModel, YOLOV5Evaluato
 from yoloseries_amd.utils import FlatSGD, mAP_v2                                    # noqa: E402
 from yoloseries_amd.utils.dist import (DataParallelGrads, all_reduce_norm, get_local_rank, get_rank, get_world_size,
                                        synchronize)                                # noqa: E402
-from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets                  # noqa: E402
+from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_shapes_batch, synth_targets      # noqa: E402
 
 
 class SyntheticLoader:
     """len()-able iterable of collated batches (dataset/data_collater.py:20-64 format), one RNG stream per rank"""
 
-    def __init__(self, steps, batch, img, num_class, device, seed):
-        self.steps, self.batch, self.img, self.nc, self.device, self.seed = steps, batch, img, num_class, device, seed
+    def __init__(self, steps, batch, img, num_class, device, seed, shapes=False):
+        self.steps, self.batch, self.img, self.nc, self.device, self.seed, self.shapes = steps, batch, img, num_class, device, seed, shapes
+        self.epoch = 0
 
     def __len__(self):
         return self.steps
 
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed)
+        self.epoch += 1
         for i in range(self.steps):
-            img = torch.rand(self.batch, 3, self.img, self.img, generator=g)
-            ann = torch.from_numpy(synth_targets(self.batch, self.img, self.nc, 20, seed=self.seed * 1000 + i))
+            if self.shapes:      # learnable task (coloured rectangles): fresh images every epoch, as an augmenting loader gives
+                im, an = synth_shapes_batch(self.batch, self.img, self.nc, 4, seed=(self.seed * 1000 + i) * 997 + self.epoch)
+                img, ann = torch.from_numpy(im), torch.from_numpy(an)
+            else:
+                img = torch.rand(self.batch, 3, self.img, self.img, generator=g)
+                ann = torch.from_numpy(synth_targets(self.batch, self.img, self.nc, 20, seed=self.seed * 1000 + i))
             yield {'img': img.to(self.device, non_blocking=True), 'ann': ann.to(self.device, non_blocking=True)}
 
 
@@ -107,8 +113,9 @@ class Training:
                                                       hyp.get('num_workers', 0))
             self.val_dataloader = PrefetchedDataset(hyp['val_batches'], hyp['batch_size'], img, hyp['num_class'], 101 + self.rank)
         else:
-            self.train_dataloader = SyntheticLoader(hyp['steps_per_epoch'], hyp['batch_size'], img, hyp['num_class'], self.device, 1 + self.rank)
-            self.val_dataloader = SyntheticLoader(hyp['val_batches'], hyp['batch_size'], img, hyp['num_class'], self.device, 101 + self.rank)
+            shapes = hyp.get('data_source', 'tensor') == 'shapes'
+            self.train_dataloader = SyntheticLoader(hyp['steps_per_epoch'], hyp['batch_size'], img, hyp['num_class'], self.device, 1 + self.rank, shapes)
+            self.val_dataloader = SyntheticLoader(hyp['val_batches'], hyp['batch_size'], img, hyp['num_class'], self.device, 101 + self.rank, shapes)
         hyp['warmup_steps'] = max(hyp.get('warmup_epoch', 3) * len(self.train_dataloader), 1)       # :192
         self.model = self.select_model().to(self.device)
         self.dp = DataParallelGrads(self.model) if self.is_distributed else None
@@ -255,8 +262,9 @@ def main(argv=None):
     ap.add_argument("--batch", type=int)
     ap.add_argument("--steps-per-epoch", type=int)
     ap.add_argument("--model-type")
-    ap.add_argument("--data", choices=["tensor", "dataset"], help="tensor: batches generated on the device; dataset: "
-                    "synthetic images through DataLoader + fixed_imgsize_collate_fn + DataPrefetcher (the reference's data path)")
+    ap.add_argument("--data", choices=["tensor", "dataset", "shapes"], help="tensor: random-noise batches; dataset: synthetic images "
+                    "through DataLoader + fixed_imgsize_collate_fn + DataPrefetcher (the reference's data path); shapes: a learnable "
+                    "task (coloured rectangles, colour = class) that shows mAP rising")
     args = ap.parse_args(argv)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.cuda.set_device(get_local_rank())

@@ -77,3 +77,43 @@ def synth_yolox_heads(batch, img_size=640, num_class=80, seed=5, scale=1.0, stri
         t[:, :, 2:4] = (np.log(3.0) + 0.5 * rs.randn(batch, 1, 2, h, w)).astype(np.float32)
         out[name] = t
     return out
+
+
+# learnable synthetic detection task: filled rectangles on a dark noisy background, colour = class.  Used by the training
+# drivers (--data shapes) and tests/test_gpu_driver.py to show that the whole stack (forward, loss, backward, optimizer, EMA,
+# evaluator, mAP) LEARNS — random-noise images (synth_targets alone) can only check that it runs.
+SHAPE_PALETTE = np.array([[1.0, 0.1, 0.1], [0.1, 1.0, 0.1], [0.15, 0.25, 1.0], [1.0, 1.0, 0.1],
+                          [1.0, 0.1, 1.0], [0.1, 1.0, 1.0], [1.0, 0.55, 0.1], [0.9, 0.9, 0.9]], dtype=np.float32)
+
+
+def synth_shapes_batch(batch, img_size=320, num_class=4, max_boxes=4, seed=1):
+    """-> (img (B,3,H,W) float32 in [0,1], ann (B, max_boxes, 6) float32 [xmin,ymin,xmax,ymax,cls,img_idx] padded with -1).
+    Boxes do not overlap by more than a little (rejection sampling), sizes 1/8 .. 1/2 of the image, class < min(num_class, 8)."""
+    rs = np.random.RandomState(seed)
+    nc = min(num_class, len(SHAPE_PALETTE))
+    img = rs.uniform(0.0, 0.25, size=(batch, 3, img_size, img_size)).astype(np.float32)
+    ann = -np.ones((batch, max_boxes, 6), dtype=np.float32)
+    for b in range(batch):
+        placed = []
+        for _ in range(rs.randint(1, max_boxes + 1)):
+            for _try in range(20):
+                w, h = rs.uniform(img_size / 8, img_size / 2, 2)
+                x1, y1 = rs.uniform(0, img_size - w), rs.uniform(0, img_size - h)
+                box = np.array([x1, y1, x1 + w, y1 + h])
+                ok = True
+                for q in placed:
+                    iw = min(box[2], q[2]) - max(box[0], q[0])
+                    ih = min(box[3], q[3]) - max(box[1], q[1])
+                    if iw > 0 and ih > 0 and iw * ih > 0.05 * min(w * h, (q[2] - q[0]) * (q[3] - q[1])):
+                        ok = False
+                        break
+                if ok:
+                    break
+            else:
+                continue
+            c = rs.randint(0, nc)
+            xi1, yi1, xi2, yi2 = int(round(box[0])), int(round(box[1])), int(round(box[2])), int(round(box[3]))
+            img[b, :, yi1:yi2, xi1:xi2] = SHAPE_PALETTE[c][:, None, None] * rs.uniform(0.8, 1.0)
+            ann[b, len(placed)] = [xi1, yi1, xi2, yi2, c, b]
+            placed.append(box)
+    return img, ann
