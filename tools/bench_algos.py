@@ -16,7 +16,7 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device("cuda:0")
 if which == "v5s":
     B = 64
-    shapes = [("s1_cba12", 160, 64, 64, 1, 1), ("s2_conv", 160, 64, 128, 3, 2), ("s2_b_3x3", 80, 64, 64, 3, 1),
+    shapes = [("s1_conv", 320, 32, 64, 3, 2), ("s1_b_3x3", 160, 32, 32, 3, 1), ("s1_cba12", 160, 64, 64, 1, 1), ("s2_conv", 160, 64, 128, 3, 2), ("s2_b_3x3", 80, 64, 64, 3, 1),
               ("s2_cba12", 80, 128, 128, 1, 1), ("s3_conv", 80, 128, 256, 3, 2), ("s3_b_3x3", 40, 128, 128, 3, 1),
               ("s3_b_1x1", 40, 128, 128, 1, 1), ("s3_cba12", 40, 256, 256, 1, 1), ("s4_conv", 40, 256, 512, 3, 2),
               ("s4_b_3x3", 20, 256, 256, 3, 1), ("s4_cba3", 20, 512, 512, 1, 1), ("spp_cba2", 20, 1024, 512, 1, 1)]
