@@ -41,14 +41,21 @@ def _tune_cache_path():
 
 
 def _tune_cache():
-    """launch parameters timed on this machine (per layer shape), kept across processes in a small JSON file"""
+    """launch parameters per layer shape: the shipped table for the BASELINE configurations (tune_defaults.json, timed on an
+    MI355X with tools/make_tune_defaults.sh: the same choices on every box, no tuning launches in the first steps), overlaid by
+    what this machine timed itself for other shapes (kept across processes in a small JSON file).  YH_TUNE_DEFAULTS=0 ignores
+    the shipped table."""
     if _tune_cache.data is None:
         _tune_cache.data = {}
-        try:
-            with open(_tune_cache_path()) as f:
-                _tune_cache.data = dict(json.load(f))
-        except (OSError, ValueError):
-            pass
+        paths = [_tune_cache_path()]
+        if os.environ.get("YH_TUNE_DEFAULTS", "1") != "0":
+            paths.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_defaults.json"))
+        for pth in paths:
+            try:
+                with open(pth) as f:
+                    _tune_cache.data.update(dict(json.load(f)))
+            except (OSError, ValueError):
+                pass
     return _tune_cache.data
 
 
