@@ -22,7 +22,7 @@ python3 bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_default.json 2> $OUT/
 # the other BASELINE configs at one GPU (bench lines only): YOLOXs train, YOLOv5l train, YOLOv5x inference at 1280^2 (batch 128, per-layer table)
 python3 bench.py --workload yolox --no-cpu-baseline > $OUT/${TAG}_bench_yolox.json 2> $OUT/bench_yolox.err
 python3 bench.py --model large --no-cpu-baseline > $OUT/${TAG}_bench_v5l.json 2> $OUT/bench_v5l.err
-YH_BENCH_LAYERS=200 python3 bench.py --workload infer --model xlarge --img 1280 --batch 128 --steps 3 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_infer_v5x_1280_b128.json 2> $OUT/${TAG}_layers_infer_v5x_1280_b128.txt
+YH_BENCH_LAYERS=200 python3 bench.py --workload infer --model xlarge --img 1280 --batch 128 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_infer_v5x_1280_b128.json 2> $OUT/${TAG}_layers_infer_v5x_1280_b128.txt
 # keep the merged-back directory small: the raw traces stay on the box
 rm -rf $OUT/serial $OUT/b64 $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT
