@@ -308,3 +308,12 @@ def test_shipped_tuning_table_matches_the_engine_key_versions():
     assert prefixes == {conv_prefix, wgrad_prefix}, (prefixes, conv_prefix, wgrad_prefix)
     assert len(table) > 300
     assert all(isinstance(v, list) and all(isinstance(x, int) for x in v) for v in table.values())
+
+
+def test_planning_helpers_tolerate_empty_descriptors():
+    """yh_conv_stat_blocks / yh_conv_bnr_rows are called while a descriptor is being filled in: a zero dimension answers 0"""
+    import ctypes as C
+    from yoloseries_amd._lib import ConvDesc, lib
+    d = ConvDesc()
+    assert lib().yh_conv_stat_blocks(C.byref(d)) == 0
+    assert lib().yh_conv_bnr_rows(C.byref(d)) == 0

@@ -2003,8 +2003,13 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
 
 }  // namespace
 
+// the planning helpers are called on half-filled descriptors (sizing, tuning): answer 0 instead of dividing by a zero dimension
+static bool conv_desc_plannable(const yh_conv_desc* d) {
+    return d && (d->nseg == 1 || d->nseg == 2) && d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->Hi > 0 && d->Wi > 0 && d->KH > 0 && d->KW > 0 &&
+           (d->stride == 1 || d->stride == 2) && d->N > 0 && d->seg[0].C > 0;
+}
 extern "C" int yh_conv_stat_blocks(const yh_conv_desc* d) {
-    if (!d) return 0;
+    if (!conv_desc_plannable(d)) return 0;
     int gx, gy, bn;
     conv_grid(d, &gx, &gy, &bn);
     return gx;
@@ -2247,7 +2252,7 @@ extern "C" int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream) { return c
  * cannot take the fused path (the caller keeps the separate yh_bn_silu_bwd_reduce pass). */
 extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
 {
-    if (!d || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 8 || d->seg[0].ups || d->N % 8) return 0;
+    if (!conv_desc_plannable(d) || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 8 || d->seg[0].ups || d->N % 8) return 0;
     if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N || d->stats) return 0;
     { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 16)) return 0; }
     const unsigned long M = (unsigned long)d->B * d->Ho * d->Wo;
