@@ -374,6 +374,26 @@ int yh_nms_batched(const float* cand, const int32_t* ncand, int B, int cap,
                    float iou_thr, int class_aware, int thr_inclusive, int max_keep, int merge_filter,
                    float* out, int32_t* nkeep, int32_t* keep_idx, void* ws, yh_stream stream);
 
+/* ------------------------------------------------------------------------
+ * Program executor: replay a pre-built list of launches with one call (the engine's forward / backward programs; replaces the
+ * host loop over ~700 calls of a train step: train_yolov5.py:327-350 spends that time inside torch's dispatcher instead).
+ * A command is an entry point of this library (index from yh_exec_op) with its arguments widened to 8-byte slots — pointers
+ * and integers as (u)int64, float / double as the bit pattern of a double — in declaration order, the stream slot last (its
+ * value is replaced by streams[cmd.stream]); or YH_CMD_EVENT_RECORD / YH_CMD_STREAM_WAIT with a hipEvent_t in slot 0.
+ * Executed in order; on failure returns the callee's status and, in *failed, the index of the command.              */
+#define YH_CMD_SLOTS 16
+#define YH_CMD_EVENT_RECORD (-1)
+#define YH_CMD_STREAM_WAIT  (-2)
+typedef struct yh_cmd {
+    int32_t  op;            /* yh_exec_op() index, or YH_CMD_EVENT_RECORD / YH_CMD_STREAM_WAIT */
+    int32_t  nslots;        /* argument count incl. the stream */
+    int32_t  stream;        /* index into yh_exec's streams[] */
+    int32_t  reserved;
+    uint64_t slots[YH_CMD_SLOTS];
+} yh_cmd;
+int yh_exec_op(const char* name, int* nargs);
+int yh_exec(const yh_cmd* cmds, int n, const yh_stream* streams, int nstreams, int* failed);
+
 #ifdef __cplusplus
 }
 #endif

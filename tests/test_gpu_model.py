@@ -397,3 +397,34 @@ def test_v5x_1280_eval_through_evaluator(dev):
     assert ev.last_ncand[0] >= 1000
     out = ev(x.to(dev))
     np.testing.assert_array_equal(out[0].numpy(), ref[0])
+
+
+def test_program_executor_matches_per_launch_calls(dev):
+    """the compiled command arrays replayed by yh_exec (one call per pass) against one ctypes call per launch: identical forward
+    outputs (same kernels, same order), gradients equal up to the atomics' summation order"""
+    from yoloseries_amd import engine, models
+    from yoloseries_amd.loss import YOLOV5Loss
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
+    import bench
+    res = {}
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(5)).to(dev)
+    t = torch.from_numpy(synth_targets(2, 128, 80, 8, seed=6, min_boxes=4)).to(dev)
+    for use in (False, True):
+        old = engine.USE_EXEC
+        engine.USE_EXEC = use
+        try:
+            torch.manual_seed(0)
+            m = models.YOLOV5Small(3, 80).to(dev).train()
+            outs = m(x)
+            YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), bench.make_hyp(dev, 128, 2))(outs, t)["tot_loss"].backward()
+            g = m._yh_last_flat_grad.clone()
+            m.eval()
+            with torch.no_grad():
+                ev = [o.float().cpu() for o in m(x)]
+            res[use] = ([o.detach().float().cpu() for o in outs], g.cpu(), ev)
+        finally:
+            engine.USE_EXEC = old
+    (o0, g0, e0), (o1, g1, e1) = res[False], res[True]
+    for a, b in zip(o0 + e0, o1 + e1):
+        assert torch.equal(a, b)
+    assert (g1 - g0).abs().max() <= 1e-4 * g0.abs().max()

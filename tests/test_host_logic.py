@@ -317,3 +317,19 @@ def test_planning_helpers_tolerate_empty_descriptors():
     d = ConvDesc()
     assert lib().yh_conv_stat_blocks(C.byref(d)) == 0
     assert lib().yh_conv_bnr_rows(C.byref(d)) == 0
+
+
+def test_executor_knows_every_program_entry_point():
+    """yh_exec (csrc/exec.hip) replays the engine's command lists: every entry point a Program emits must be in its table, with
+    the argument count the ctypes signature declares (stream included)"""
+    import ctypes as C
+    from yoloseries_amd import _lib
+    L = _lib.lib()
+    for name in ("yh_conv_igemm", "yh_conv_wgrad", "yh_bn_finalize", "yh_bn_fold_batch", "yh_bn_silu_apply", "yh_bn_silu_bwd_reduce",
+                 "yh_bn_bwd_finalize", "yh_bn_silu_bwd_apply", "yh_colsum", "yh_maxpool5_fwd", "yh_maxpool5_bwd", "yh_upsample2_bwd",
+                 "yh_fill_u32"):
+        n = C.c_int32(0)
+        assert L.yh_exec_op(name.encode(), C.byref(n)) >= 0, name
+        assert n.value == len(_lib._SIGS[name][1]) <= _lib.YH_CMD_SLOTS, (name, n.value)
+    assert L.yh_exec_op(b"yh_nms_batched", None) == -1
+    assert C.sizeof(_lib.Cmd) == 16 + 8 * _lib.YH_CMD_SLOTS

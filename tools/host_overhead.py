@@ -1,5 +1,9 @@
-import sys, time, torch
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""Host time to enqueue one train step (forward, loss, backward, clip, SGD, EMA): every step starts with an empty launch queue
+(device sync before it), so the host never waits for the GPU while enqueueing.  YH_EXEC=0 launches every kernel from Python
+(one ctypes call each) instead of replaying the compiled command arrays (csrc/exec.hip)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from yoloseries_amd import models
 from yoloseries_amd.loss import YOLOV5Loss
@@ -15,14 +19,21 @@ for B in (64, 16):
     ema = ExponentialMovingAverageModel(m)
     x = torch.rand(B, 3, 640, 640, device=dev)
     t = torch.from_numpy(synth_targets(B, 640, 80, 20, seed=1)).to(dev)
+    parts = {}
     def step():
-        out = lossf(m(x), t); out['tot_loss'].backward(); opt.clip_grad_norm_(10.0); opt.step(); opt.zero_grad(); ema.update(m)
+        h = time.perf_counter(); y = m(x); parts['forward'] = parts.get('forward', 0) + time.perf_counter() - h
+        h = time.perf_counter(); out = lossf(y, t); parts['loss'] = parts.get('loss', 0) + time.perf_counter() - h
+        h = time.perf_counter(); out['tot_loss'].backward(); parts['backward'] = parts.get('backward', 0) + time.perf_counter() - h
+        h = time.perf_counter(); opt.clip_grad_norm_(10.0); opt.step(); opt.zero_grad(); ema.update(m)
+        parts['optimizer+ema'] = parts.get('optimizer+ema', 0) + time.perf_counter() - h
     for _ in range(5): step()
     torch.cuda.synchronize()
-    hs = []
+    parts.clear()
+    hs, n = [], 10
     t0 = time.perf_counter()
-    for _ in range(10):
+    for _ in range(n):
+        torch.cuda.synchronize()
         h0 = time.perf_counter(); step(); hs.append(time.perf_counter() - h0)
     torch.cuda.synchronize()
-    tot = (time.perf_counter() - t0) / 10
-    print(f"B={B}: step wall {tot*1e3:.2f} ms, host enqueue per step {sum(hs)/len(hs)*1e3:.2f} ms (min {min(hs)*1e3:.2f})")
+    print(f"B={B}: host enqueue per step {sum(hs)/n*1e3:.2f} ms (min {min(hs)*1e3:.2f}): " +
+          ", ".join(f"{k} {v/n*1e3:.2f}" for k, v in parts.items()))

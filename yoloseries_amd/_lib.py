@@ -97,6 +97,15 @@ class BnFoldItem(C.Structure):
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("eps", C.c_float), ("C", C.c_int32)]
 
 
+YH_CMD_SLOTS, YH_CMD_EVENT_RECORD, YH_CMD_STREAM_WAIT = 16, -1, -2
+
+
+class Cmd(C.Structure):
+    """yh_cmd: one command of a program replayed by yh_exec (include/yolohip.h)"""
+    _fields_ = [("op", C.c_int32), ("nslots", C.c_int32), ("stream", C.c_int32), ("reserved", C.c_int32),
+                ("slots", C.c_uint64 * YH_CMD_SLOTS)]
+
+
 YH_CONV_FWD, YH_CONV_DGRAD = 0, 1
 YH_ACT_NONE, YH_ACT_SILU = 0, 1
 
@@ -156,6 +165,8 @@ _SIGS = {
     "yh_decode_filter": (_i32, [C.POINTER(DecodeDesc), C.POINTER(_vp), _f32, _f32, _vp, _vp, _i32, _vp, _vp]),
     "yh_decode_filter_ws_bytes": (C.c_size_t, [C.POINTER(DecodeDesc)]),
     "yh_filter_decoded": (_i32, [_vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _i32, _vp]),
+    "yh_exec_op": (_i32, [C.c_char_p, C.POINTER(_i32)]),
+    "yh_exec": (_i32, [C.POINTER(Cmd), _i32, C.POINTER(_vp), _i32, C.POINTER(_i32)]),
     "yh_nms_ws_bytes": (_sz, [_i32, _i32]),
     "yh_nms_batched": (_i32, [_vp, _vp, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -1642,7 +1642,23 @@ constexpr size_t conv_halo_smem_bytes() {
 
 // tile geometry of the halo kernel for an H x W map: TH x TW output pixels (<= 256) whose (TH+2) x (TW+2) patch fits 352 rows,
 // chosen to waste the fewest MFMA rows (ragged tiles and TH*TW < 256)
+bool conv_halo_geom_search(int H, int W, HaloGeom* g);
+// the search below is ~200 divisions: its result per map size is kept (the planner runs for every launch)
 bool conv_halo_geom(int H, int W, HaloGeom* g)
+{
+    struct Memo { int H, W; bool ok; HaloGeom g; };
+    static thread_local Memo memo[8];
+    static thread_local int next = 0;
+    for (int i = 0; i < 8; ++i)
+        if (memo[i].H == H && memo[i].W == W && H > 0) { *g = memo[i].g; return memo[i].ok; }
+    Memo& m = memo[next];
+    next = (next + 1) & 7;
+    m.H = H; m.W = W;
+    m.ok = conv_halo_geom_search(H, W, &m.g);
+    *g = m.g;
+    return m.ok;
+}
+bool conv_halo_geom_search(int H, int W, HaloGeom* g)
 {
     double best = 0.0;
     bool found = false;
@@ -1832,6 +1848,11 @@ __global__ __launch_bounds__(256, NTL == 3 ? 1 : 2) void conv_stem_kernel(const 
     }
 }
 
+// YH_CONV_DBG (kernel-selection switches for A/B timing) is read once per process: the planner runs for every launch
+int conv_dbg_mask() {
+    static const int mask = [] { const char* e = getenv("YH_CONV_DBG"); return e ? atoi(e) : 0; }();
+    return mask;
+}
 bool stem_eligible(const yh_conv_desc* d)
 {
     if (d->mode != YH_CONV_FWD || d->nseg != 1 || d->seg[0].C != 16 || d->seg[0].ups) return false;
@@ -1844,7 +1865,7 @@ bool stem_eligible(const yh_conv_desc* d)
     if (!d->scale && d->act != YH_ACT_NONE) return false;
     const unsigned long npix = (unsigned long)d->B * d->Hi * d->Wi;
     if (((npix - 1) * d->seg[0].ld + 16) * 2 >= (1ul << 31) || (long)d->B * d->Ho * d->Wo >= (1L << 31) - 64) return false;
-    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 256)) return false; }
+    if (conv_dbg_mask() & 256) return false;
     return true;
 }
 constexpr int STEM_BLOCKS = 256 * 2;
@@ -1860,7 +1881,7 @@ constexpr size_t conv_smem_bytes() {
 bool conv_v2_ok(const yh_conv_desc* d)
 {
     if (d->nseg < 1 || d->nseg > 2) return false;
-    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 16)) return false; }
+    if (conv_dbg_mask() & 16) return false;
     if (d->nseg > 1 && d->seg[0].C % 32) return false;                 // a first concat segment must end on a 32-channel block
     if ((long)d->B * d->Hi * d->Wi >= (1L << 31)) return false;
     int Ctot = 0;
@@ -1886,7 +1907,7 @@ int pick_bkt(const yh_conv_desc* d, int bn) {
     if (d->nseg < 1 || d->nseg > 2) return 32;
     for (int s = 0; s < d->nseg; ++s) if (d->seg[s].C % 64) return 32;
     if (d->tile_k == 32) return 32;
-    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 64)) return 32; }
+    if (conv_dbg_mask() & 64) return 32;
     return 64;
 }
 
@@ -1896,7 +1917,7 @@ int conv_v3_bkt(const yh_conv_desc* d);
 int conv_v3_variant(const yh_conv_desc* d)
 {
     if (d->algo == 1 || d->algo == 5 || stem_eligible(d) || !conv_v2_ok(d)) return 0;
-    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 512)) return 0; }
+    if (conv_dbg_mask() & 512) return 0;
     if (conv_v3_bkt(d) == 0) return 0;
     if (d->N <= 32) return 0;
     if (d->tile_n == 32) return 0;
@@ -1919,7 +1940,7 @@ int conv_v3_variant(const yh_conv_desc* d)
 bool conv_halo_ok(const yh_conv_desc* d, HaloGeom* g)
 {
     if (d->algo != 0 && d->algo != 5) return false;
-    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 1024)) return false; }
+    if (conv_dbg_mask() & 1024) return false;
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->nseg != 1 || d->seg[0].ups) return false;
     if (d->seg[0].C % 16 || d->seg[0].C < 64 || d->N <= 32 || d->tile_n == 32) return false;
     if (d->Ho != d->Hi || d->Wo != d->Wi) return false;
@@ -2061,7 +2082,7 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     else { k.sa = 1; k.sb = -1; k.sc = d->pad; k.sdshift = d->stride == 2 ? 1 : 0; }
     if (k.d.nsplit > k.d.N) k.d.nsplit = k.d.N + 8;   // everything goes to out0
     k.fast = 1;
-    { const char* e = getenv("YH_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
+    k.dbg = conv_dbg_mask();
     // the buffer-load kernel walks 32-channel blocks: a first segment must end on a block boundary, the last may be ragged
     if (d->nseg > 1 && d->seg[0].C % 32) k.fast = 0;
     const bool ragged = (d->seg[d->nseg - 1].C % 32) != 0;
@@ -2254,7 +2275,7 @@ extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
 {
     if (!conv_desc_plannable(d) || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 8 || d->seg[0].ups || d->N % 8) return 0;
     if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N || d->stats) return 0;
-    { const char* e = getenv("YH_CONV_DBG"); if (e && (atoi(e) & 16)) return 0; }
+    if (conv_dbg_mask() & 16) return 0;
     const unsigned long M = (unsigned long)d->B * d->Ho * d->Wo;
     if (M >= (1ul << 31) - BM) return 0;
     const unsigned long npix = (unsigned long)d->B * d->Hi * d->Wi;

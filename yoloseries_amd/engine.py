@@ -21,12 +21,13 @@ with one index-gather launch each.
 import ctypes as C
 import json
 import os
+import struct
 
 import numpy as np
 import torch
 
 from . import hipk
-from ._lib import (BnFoldItem, ConvDesc, WgradDesc, YH_ACT_NONE, YH_ACT_SILU, YH_CONV_DGRAD, YH_CONV_FWD, YoloHipError, check, lib)
+from ._lib import (BnFoldItem, Cmd, ConvDesc, WgradDesc, YH_CMD_EVENT_RECORD, YH_CMD_SLOTS, YH_CMD_STREAM_WAIT, YH_ACT_NONE, YH_ACT_SILU, YH_CONV_DGRAD, YH_CONV_FWD, YoloHipError, check, lib)
 from .hipk import Slice
 
 BN_EPS_DEFAULT = 1e-3
@@ -95,6 +96,63 @@ _WGRAD_TK64 = {
     "conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false>": "conv_wgrad_kernel<1, 4, 2, 1, 64, 2, false>",
     "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false>": "conv_wgrad_kernel<1, 4, 2, 2, 64, 2, false>",
 }
+
+
+# YH_EXEC=0: launch every kernel of a program from Python (one ctypes call each) instead of replaying the compiled command array
+# with one yh_exec call (csrc/exec.hip)
+USE_EXEC = os.environ.get("YH_EXEC", "1") != "0"
+
+
+def _slot(v):
+    """a command argument widened to the 8-byte slot yh_exec expects"""
+    if v is None:
+        return 0
+    if isinstance(v, float):
+        return struct.unpack("<Q", struct.pack("<d", v))[0]
+    if isinstance(v, C.Structure):
+        return C.addressof(v)
+    return int(v) & 0xFFFFFFFFFFFFFFFF
+
+
+class CompiledCmds:
+    """a command list as a yh_cmd array (include/yolohip.h): built once per program, replayed with one call per segment"""
+
+    def __init__(self, L, capacity):
+        self.L = L
+        self.arr = (Cmd * max(capacity, 1))()
+        self.n = 0
+        self.names = []
+        self.source = None              # the Python command list this array was compiled from
+
+    def call(self, fn, args, stream=0, label=""):
+        nargs = C.c_int32(0)
+        op = self.L.yh_exec_op(fn.__name__.encode(), C.byref(nargs))
+        if op < 0 or nargs.value != len(args) + 1 or nargs.value > YH_CMD_SLOTS:
+            raise YoloHipError(f"{fn.__name__} [{label}] cannot be compiled into a program ({len(args)} arguments)")
+        c = self.arr[self.n]
+        c.op, c.nslots, c.stream = op, nargs.value, stream
+        for i, v in enumerate(args):
+            c.slots[i] = _slot(v)
+        self.names.append(f"{fn.__name__} [{label}]")
+        self.n += 1
+        return self.n - 1
+
+    def event(self, kind, handle, stream):
+        c = self.arr[self.n]
+        c.op, c.nslots, c.stream = kind, 1, stream
+        c.slots[0] = int(handle)
+        self.names.append("event record" if kind == YH_CMD_EVENT_RECORD else "stream wait")
+        self.n += 1
+
+    def run(self, streams, lo=0, hi=None):
+        hi = self.n if hi is None else hi
+        if hi <= lo:
+            return
+        failed = C.c_int32(-1)
+        arr = (C.c_void_p * len(streams))(*streams)
+        rc = self.L.yh_exec(C.cast(C.byref(self.arr, lo * C.sizeof(Cmd)), C.POINTER(Cmd)), hi - lo, arr, len(streams), C.byref(failed))
+        if rc != 0:
+            check(rc, self.names[lo + failed.value] if failed.value >= 0 else "yh_exec")
 
 
 def plan_grad_buckets(marks, gsize, nbuckets):
@@ -404,6 +462,7 @@ class Program:
                 b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=dev)
         self.generation = 0
         self.profile = None             # {(kernel family, algorithmic flops): [(start_event, end_event)]} when profiling
+        self._compiled = {}             # 'train' | 'eval' | ('bwd', two_streams, hooked) -> CompiledCmds (yh_exec replay)
         self.bwd_ready = False
         self._keep = []                 # keeps ctypes structs / tensors alive
         self._build_forward()
@@ -520,7 +579,7 @@ class Program:
                 d.out0, d.ld0, d.nsplit = pk.wpack.data_ptr(), op.y.C, op.N   # placeholder: head buffers are fresh tensors per forward
                 st['desc'] = d
                 st['fam'] = self._fam_conv(op, d)
-                self.cmd_eval.append((L.yh_conv_igemm, (C.byref(d),), op.name, st['fam']))
+                self.cmd_eval.append((L.yh_conv_igemm, (d,), op.name, st['fam']))
                 continue
             # folded BN + SiLU (+ residual) in the conv epilogue
             de = self._conv_desc(op, False)
@@ -546,7 +605,7 @@ class Program:
                 de.res, de.ldr = r.ptr(), r.ld
             st['desc_eval'] = de
             self._tune_conv(de, 'eval', op.name)
-            self.cmd_eval.append((L.yh_conv_igemm, (C.byref(de),), op.name, self._fam_conv(op, de)))
+            self.cmd_eval.append((L.yh_conv_igemm, (de,), op.name, self._fam_conv(op, de)))
         if fold_items:
             arr = (BnFoldItem * len(fold_items))(*fold_items)
             self.fold_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
@@ -571,7 +630,7 @@ class Program:
             M = B * op.Ho * op.Wo
             st = self.op_state[op.name]
             if op.kind == 'plain':
-                self.cmd_train.append((L.yh_conv_igemm, (C.byref(st['desc']),), op.name, st['fam']))
+                self.cmd_train.append((L.yh_conv_igemm, (st['desc'],), op.name, st['fam']))
                 continue
             d = self._conv_desc(op, True)
             d.act = YH_ACT_NONE
@@ -585,7 +644,7 @@ class Program:
                 st['acc_off'] = self._acc_fwd_elems
                 self._acc_fwd_elems += ACC_ROWS * 2 * op.Npad
                 st['desc_train'] = d
-                self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op, d)))
+                self.cmd_train.append((L.yh_conv_igemm, (d,), op.name, self._fam_conv(op, d)))
                 st['ws'] = []
                 c0 = 0
                 for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
@@ -603,7 +662,7 @@ class Program:
             st['stats'] = torch.zeros(nblk, 2, op.Npad, dtype=torch.float32, device=self.dev)
             d.stats = st['stats'].data_ptr()
             st['desc_train'] = d
-            self.cmd_train.append((L.yh_conv_igemm, (C.byref(d),), op.name, self._fam_conv(op, d)))
+            self.cmd_train.append((L.yh_conv_igemm, (d,), op.name, self._fam_conv(op, d)))
             st['ws'] = []
             c0 = 0
             for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
@@ -665,9 +724,26 @@ class Program:
         M = self.B * op.Ho * op.Wo
         return (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else op.Ctot), self._conv_bytes(d))
 
+    def _compile(self, cmds):
+        cc = CompiledCmds(self.L, len(cmds))
+        for fn, args, name, meta in cmds:
+            if fn == 'fill':
+                cc.call(self.L.yh_fill_u32, (args.data_ptr(), 0, args.numel() * args.element_size() // 4), 0, name)
+            else:
+                cc.call(fn, args, 0, name)
+        return cc
+
     def _run(self, cmds):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         prof = self.profile
+        if prof is None and USE_EXEC and not BN_ACC:
+            key = 'train' if cmds is self.cmd_train else 'eval'
+            cc = self._compiled.get(key)
+            if cc is None or cc.source is not cmds:
+                cc = self._compiled[key] = self._compile(cmds)
+                cc.source = cmds
+            cc.run([st.value])
+            return
         for fn, args, name, meta in cmds:
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1018,6 +1094,61 @@ class Program:
         with torch.cuda.stream(side):
             return bucket_hook(part)
 
+    def _compile_backward(self, two, buckets):
+        """the backward command list as a yh_cmd array: kernels on stream 0 (main) / 1 (side: weight gradients), the event
+        records and stream waits of the gz ring in between; returns (array, positions at which a gradient bucket is complete,
+        per-call patches for the head gradients)"""
+        L = self.L
+        cc = CompiledCmds(L, 2 * len(self.cmd_bwd) + 8)
+        cc.source = self.cmd_bwd
+        breaks, patches = [], []
+        pending = [False] * NGZ
+        if two:
+            for ev in [self._ev_gz] + self._ev_wg:        # materialise the raw event handles
+                ev.record(self._side)
+            ev_gz, ev_wg = self._ev_gz.cuda_event, [e.cuda_event for e in self._ev_wg]
+        nb = 0
+        for ci, cmd in enumerate(self.cmd_bwd):
+            while nb < len(buckets) and buckets[nb][0] == ci:
+                breaks.append(cc.n)
+                nb += 1
+            fn = cmd[0]
+            if fn == 'gz_begin':
+                if two and pending[cmd[1]]:
+                    cc.event(YH_CMD_STREAM_WAIT, ev_wg[cmd[1]], 0)
+                    pending[cmd[1]] = False
+            elif fn == 'wg_begin':
+                if two:
+                    cc.event(YH_CMD_EVENT_RECORD, ev_gz, 0)
+                    cc.event(YH_CMD_STREAM_WAIT, ev_gz, 1)
+            elif fn == 'wg_end':
+                if two and cmd[1] is not None:
+                    cc.event(YH_CMD_EVENT_RECORD, ev_wg[cmd[1]], 1)
+                    pending[cmd[1]] = True
+            elif fn == 'head_colsum':
+                _, op, boff, _m = cmd
+                if boff is not None:
+                    i = cc.call(L.yh_colsum, (0, op.y.C, op.y.C, self.B * op.Ho * op.Wo, self.part_scratch.data_ptr(),
+                                              self.pack.gpack.data_ptr() + 4 * boff), 0, op.name)
+                    patches.append(('colsum', None, op.name, i))
+            elif fn == 'wgrad':
+                _, op, wd, _m = cmd
+                cc.call(L.yh_conv_wgrad, (wd,), 1 if two else 0, op.name)
+                if op.kind == 'plain':
+                    patches.append(('wgrad', wd, op.name, -1))
+            elif fn == 'dgrad':
+                _, op, d, _m = cmd
+                cc.call(L.yh_conv_igemm, (d,), 0, op.name)
+                if op.kind == 'plain':
+                    patches.append(('dgrad', d, op.name, -1))
+            else:
+                _, args, name, _m = cmd
+                cc.call(fn, args, 0, name)
+        while nb < len(buckets):
+            breaks.append(cc.n)
+            nb += 1
+        return cc, breaks, patches
+
     def backward(self, head_grads, bucket_hook=None):
         """head_grads: list of [B,h,w,ld] bf16 gradient buffers matching self.outputs (plain ops).
         bucket_hook(slice of the packed fp32 gradient arena) -> finisher or None: called as soon as a bucket of
@@ -1052,6 +1183,36 @@ class Program:
             self._ev_gz.record(main)               # packed arena zeroed, head gradients in place
             side.wait_event(self._ev_gz)
             pending = [False] * NGZ
+        if prof is None and USE_EXEC and not BN_ACC:
+            # replay the compiled command array (yh_exec): one call per bucket segment instead of one ctypes call per launch
+            key = ('bwd', two, bucket_hook is not None)
+            comp = self._compiled.get(key)
+            if comp is None or comp[0].source is not self.cmd_bwd:
+                comp = self._compiled[key] = self._compile_backward(two, buckets)
+            cc, breaks, patches = comp
+            for kind, obj, opname, slot_idx in patches:          # head gradients arrive per call
+                ptr = heads[opname].data_ptr()
+                if kind == 'wgrad':
+                    obj.gy = ptr
+                elif kind == 'dgrad':
+                    obj.seg[0].ptr = ptr
+                else:
+                    cc.arr[slot_idx].slots[0] = ptr
+            streams = [st.value, st_side.value] if two else [st.value]
+            lo = 0
+            for pos in breaks:
+                cc.run(streams, lo, pos)
+                lo = pos
+                finishers.append(self._bucket_ready(bucket_hook, buckets[nb], main if two else None, side if two else None))
+                nb += 1
+            cc.run(streams, lo, cc.n)
+            if two:
+                self._ev_all.record(side)
+                main.wait_event(self._ev_all)
+            for f in finishers:
+                if f is not None:
+                    f()
+            return pk.grads_to_params()
         for ci, cmd in enumerate(self.cmd_bwd):
             while nb < len(buckets) and buckets[nb][0] == ci:
                 finishers.append(self._bucket_ready(bucket_hook, buckets[nb], main if two else None, side if two else None))
