@@ -99,8 +99,8 @@ typedef struct yh_conv_desc {
     int32_t  tile_k;      /* channels per k-step, 32 or 64 (64 needs whole 64-channel blocks in every segment but the last and the
                            * 128-wide tile on the register-staged kernel)                                               */
     int32_t  algo;        /* kernel family: 0 library default, 1 register-staged (conv_v2_kernel), 2..4 LDS-DMA ring
-                           * (conv_v3_kernel) with a 256x128 / 128x128 / 128x64 tile, 5 the 3x3 halo kernel (conv_halo_kernel), when the shape
-                           * is eligible                                                                              */
+                           * (conv_v3_kernel) with a 256x128 / 128x128 / 128x64 tile, 5 the 3x3 halo kernel (conv_halo_kernel), 6 its
+                           * 160-channel-wide variant (conv_halo160_kernel: N % 160 == 0, no statistics), when the shape is eligible */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
      * contributions already in out0 are added first and the sums are taken over the rounded total):

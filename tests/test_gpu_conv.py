@@ -368,3 +368,58 @@ def test_conv_stem_kernel(dev, Cout):
     torch.cuda.synchronize()
     _close(obuf[..., 8:8 + Cout], F.silu(ref * scale + shift), 8e-3, 2e-2)
     assert (obuf[..., :8] == 3.0).all() and (obuf[..., 8 + Cout:] == 3.0).all()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 24, 24, 160, 160), (1, 40, 40, 128, 320), (3, 17, 33, 96, 160), (1, 20, 20, 64, 480)])
+def test_conv_halo160_kernel(dev, B, H, W, Cin, Cout):
+    """the 160-wide halo kernel (algo 6: 3x3 / s1, N a multiple of 160, 16x16x32 MFMA tiles of 64 pixels x 80 channels; inference
+    epilogues): plain store, folded BatchNorm + SiLU + residual with a split destination, and the data gradient — whole and
+    ragged channel blocks (C % 64 = 32), ragged pixel tiles, several N tiles"""
+    from yoloseries_amd import hipk
+    x = _nhwc(B, H, W, Cin, dev, 51)
+    g = torch.Generator().manual_seed(52)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    ref = F.conv2d(_nchw(x), w, None, stride=1, padding=1).permute(0, 2, 3, 1)
+    xin = hipk.full(x)
+    if Cin % 64:
+        xbuf = torch.full((B, H, W, Cin + 16), float("nan"), dtype=torch.bfloat16, device=dev)
+        xbuf[..., 8:8 + Cin] = x
+        xin = hipk.Slice(xbuf, 8, Cin)
+    # plain store
+    out = torch.full((B, H, W, Cout), 7.0, dtype=torch.bfloat16, device=dev)
+    d = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.full(out))
+    d.algo = 6
+    assert "conv_halo160_kernel<0" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out, ref, 8e-3, 2e-2)
+    # folded BatchNorm + SiLU + residual on the first 80 channels, split destination
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=g).to(dev)
+    res = _nhwc(B, H, W, 80, dev, 53)
+    out0 = torch.zeros(B, H, W, 80, dtype=torch.bfloat16, device=dev)
+    obuf = torch.full((B, H, W, Cout - 80 + 16), 3.0, dtype=torch.bfloat16, device=dev)
+    d2 = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.full(out0), nsplit=80,
+                        out1=hipk.Slice(obuf, 8, Cout - 80), scale=scale, shift=shift, act=hipk.YH_ACT_SILU, res=hipk.full(res))
+    d2.algo = 6
+    assert "conv_halo160_kernel<2" in _kname(d2), _kname(d2)
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    a = F.silu(ref * scale + shift)
+    _close(out0, a[..., :80].to(torch.bfloat16).float() + res.float(), 1e-2, 3e-2)
+    _close(obuf[..., 8:8 + Cout - 80], a[..., 80:], 8e-3, 2e-2)
+    assert (obuf[..., :8] == 3.0).all() and (obuf[..., 8 + Cout - 80:] == 3.0).all()
+    # data gradient of a Cout -> Cin' conv whose input has N' = 160 k channels: use the transposed roles (gy has Cin channels here)
+    if Cin % 160 == 0:
+        gy = _nhwc(B, H, W, Cout, dev, 54)
+        wd = hipk.pack_weight_dgrad(w)
+        xz = torch.zeros(B, Cin, H, W, device=dev, requires_grad=True)
+        (gref,) = torch.autograd.grad(F.conv2d(xz, w, stride=1, padding=1), xz, _nchw(gy))
+        gx = torch.zeros(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
+        d3 = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, H, W, 3, 1, 1, wd, Cin, hipk.full(gx))
+        d3.algo = 6
+        assert "conv_halo160_kernel" in _kname(d3), _kname(d3)
+        hipk.conv_launch(d3)
+        torch.cuda.synchronize()
+        _close(gx, gref.permute(0, 2, 3, 1), 1e-2, 4e-2)

@@ -1635,6 +1635,296 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 160-wide variant of the halo kernel for the YOLOv5x widths (N = 160, 320, ...): the 128-wide tiles above compute 256
+// channels for 160.  Same structure (2-D pixel tile, patch staged once per 64-channel block and double buffered, nine taps =
+// nine k-steps, 4-stage weight ring fed by LDS-DMA), but the wave tile is 64 pixels x 80 channels on
+// v_mfma_f32_16x16x32_bf16 (4 x 5 tiles of 16 x 16, nine 16-byte fragment reads per twenty MFMAs) so that 4 x 2 waves cover
+// 256 x 160 exactly.  The 80 KB weight ring leaves 2 x 304 patch rows (conv_halo_geom with that budget: 14 x 17 ... pixel
+// tiles).  Inference epilogues only (EPI 0 plain, EPI 2 bias / folded BN + SiLU / residual / split destination): YOLOv5x is
+// not a training configuration of this build.  Operands swapped as above (D = W x X^T): a lane holds one pixel and four
+// consecutive channels per accumulator.
+template <int EPI, bool TL>
+__global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, const HaloGeom hg)
+{
+    constexpr int BN = 160, BMT = 256, WN = 2, BKT = 64, STG = 4;
+    constexpr int NWV = 8, NT = 512;
+    constexpr int TMR = 4, TNC = 5;                  // 16-pixel / 16-channel tiles per wave (64 x 80)
+    constexpr int ROWB = BKT * 2, CHR = 8, RPI = 8;
+    constexpr int NBI = BN / RPI;                    // 20 weight-tile DMA instructions per k-step: 3 for waves 0..3, 2 for waves 4..7
+    constexpr int NPW = 5;                           // patch DMA instructions per wave and channel block (<= 5*8*8 = 320 rows)
+    constexpr int PATCH_ROWS = 304;
+    constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;   // 38912
+    constexpr int BST_BYTES = BN * ROWB;             // 20480
+    constexpr int ZERO_OFF = 2 * PATCH_BYTES + STG * BST_BYTES;
+    constexpr int MAIN_BYTES = ZERO_OFF + 128;
+    constexpr int CP = BN + 8;                       // epilogue buffer: 64 rows x CP bf16 inside the idle patch buffer
+    static_assert(64 * CP * 2 <= PATCH_BYTES, "epilogue quarter tile must fit a patch buffer");
+    static_assert(EPI == 0 || EPI == 2, "inference epilogues only");
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sConst = reinterpret_cast<float*>(smem + MAIN_BYTES);            // [3][BN]: bias | scale | shift
+    int* sPix = reinterpret_cast<int*>(smem + MAIN_BYTES + 3 * BN * 4);     // [BMT] output pixel of each tile row, -1 = none
+
+    const yh_conv_desc& d = p.d;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.y * BN;
+    const int ncb = TL ? (p.Ctot + BKT - 1) / BKT : p.Ctot / BKT;
+    const int tailn = TL ? (p.Ctot % BKT) / 32 : BKT / 32;   // 32-channel sub-steps of the last channel block (TL: C % 32 == 0 needed)
+    const int H = d.Ho, W = d.Wo;
+    const int TH = hg.TH, TW = hg.TW, PW = hg.PW, NP = hg.NP;
+    const int tiles_per_img = hg.tiles_x * hg.tiles_y;
+    const int ntiles = d.B * tiles_per_img;
+    const int ldx2 = d.seg[0].ld * 2;
+    const bool dgrad = d.mode == YH_CONV_DGRAD;
+    const int nbw = wave < 4 ? 3 : 2;                // weight DMA instructions of this wave per k-step
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg[0].ptr, 0, p.segbytes[0], 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, p.wbytes, 0x00020000);
+
+    const int lrow = lane >> 3, lq = lane & 7;
+    unsigned voffB[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int row = (j * NWV + wave) * RPI + lrow;             // j = 2: rows 128 .. 159 (waves 0..3 only)
+        voffB[j] = (unsigned)(((n0 + row) * p.Ktot + ((lq ^ swz_f<CHR>(row)) * 8)) * 2);
+    }
+    // fragment geometry of v_mfma_f32_16x16x32_bf16: lane l supplies row / column (l & 15), k = 8 (l >> 4) .. +8
+    const int l15 = lane & 15, kq = lane >> 4;
+    int rdW[2];                                       // weight fragment offset inside a ring slot per 32-channel sub-step (+ j * 16 rows)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        rdW[ks] = 2 * PATCH_BYTES + (wn * 80 + l15) * ROWB + (((ks * 4 + kq) ^ swz_f<CHR>(l15)) << 4);
+    // rows of a wave's channel tiles differ by multiples of 16: swz_f(row) = (row >> 1) & 7 then differs by 8 j mod 8 = 0, so the
+    // lane's swizzle term is the same for every tile j
+
+    if (t < 32) reinterpret_cast<unsigned*>(smem + ZERO_OFF)[t] = 0u;
+    if (EPI == 2) {
+        for (int i = t; i < 3 * BN; i += NT) {
+            const int which = i / BN, c = i - which * BN;
+            const float* src = which == 0 ? d.bias : (which == 1 ? d.scale : d.shift);
+            sConst[i] = (src && n0 + c < d.N) ? src[n0 + c] : (which == 1 ? 1.f : 0.f);
+        }
+    }
+    __syncthreads();
+
+    auto patch_offsets = [&](int tile, unsigned (&vo)[NPW]) {
+        const int img = tile / tiles_per_img;
+        const int trem = tile - img * tiles_per_img;
+        const int tyi = trem / hg.tiles_x;
+        const int y0 = tyi * TH, x0 = (trem - tyi * hg.tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int pr = (i * NWV + wave) * RPI + lrow;
+            const int py = pr / PW, px = pr - py * PW;
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            const bool ok = pr < (TH + 2) * PW && y >= 0 && y < H && x >= 0 && x < W;
+            vo[i] = ok ? (unsigned)((img * H + y) * W + x) * (unsigned)ldx2 + (unsigned)((lq ^ swz_f<CHR>(pr)) * 16) : OOB;
+        }
+    };
+    auto issue_patch_part = [&](const unsigned (&vo)[NPW], int part, int cblk, int pbuf) -> int {
+        const int inst = part * NWV + wave;
+        if (inst >= NP) return 0;
+        unsigned char* dst = smem + pbuf * PATCH_BYTES + inst * (RPI * ROWB);
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+            if (i == part) lds_dma16(rs0, dst, vo[i], cblk * (BKT * 2));
+        return 1;
+    };
+    auto issue_W = [&](int tap, int cblk, int slot) {
+        const int sw = (tap * p.Ctot + cblk * BKT) * 2;
+        unsigned char* sb = smem + 2 * PATCH_BYTES + slot * BST_BYTES + wave * (RPI * ROWB);
+        lds_dma16(rsw, sb, voffB[0], sw);
+        lds_dma16(rsw, sb + NWV * RPI * ROWB, voffB[1], sw);
+        if (wave < 4) lds_dma16(rsw, sb + 2 * NWV * RPI * ROWB, voffB[2], sw);
+    };
+
+    int tile = blockIdx.x;
+    unsigned voffP[NPW], voffN[NPW];
+    int slot = 0, islot = STG - 1, pb = 0;
+    if (tile < ntiles) {
+        patch_offsets(tile, voffP);
+#pragma unroll
+        for (int part = 0; part < NPW; ++part) issue_patch_part(voffP, part, 0, 0);
+        issue_W(0, 0, 0);
+        issue_W(1, 0, 1);                             // nine taps per channel block: steps 0..2 are taps 0..2 of block 0
+        issue_W(2, 0, 2);
+        if (wave < 4) { YH_VMCNT(3); } else { YH_VMCNT(2); }   // patch + the weight tiles of steps 0, 1 landed; the third stays in flight
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        const int img = tile / tiles_per_img;
+        const int trem = tile - img * tiles_per_img;
+        const int tyi = trem / hg.tiles_x;
+        const int y0 = tyi * TH, x0 = (trem - tyi * hg.tiles_x) * TW;
+        int pr0[TMR];
+        bool inv[TMR];
+#pragma unroll
+        for (int i = 0; i < TMR; ++i) {
+            const int r = wm * 64 + i * 16 + l15;
+            const int ty = r / TW, tx = r - ty * TW;
+            inv[i] = !(ty < TH && y0 + ty < H && x0 + tx < W);
+            pr0[i] = ty * PW + tx;
+        }
+        for (int r = t; r < BMT; r += NT) {
+            const int ty = r / TW, tx = r - ty * TW;
+            sPix[r] = (ty < TH && y0 + ty < H && x0 + tx < W) ? ((img * H + y0 + ty) * W + x0 + tx) : -1;
+        }
+
+        f32x4_t acc[TMR][TNC];
+#pragma unroll
+        for (int i = 0; i < TMR; ++i)
+#pragma unroll
+            for (int j = 0; j < TNC; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+        int prev_group = 0;
+        for (int cblk = 0; cblk < ncb; ++cblk) {
+            const bool last_blk = cblk + 1 == ncb;
+            const int ksn = (TL && last_blk) ? tailn : BKT / 32;
+            if (last_blk && has_next) patch_offsets(tile + gridDim.x, voffN);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kt = cblk * 9 + tap;
+                // all DMA groups except the one issued at the previous step must have landed (step 0: waited before the tile)
+                if (kt > 0) {
+                    if (prev_group == 0) YH_VMCNT(0);
+                    else if (prev_group == 1) YH_VMCNT(1);
+                    else if (prev_group == 2) YH_VMCNT(2);
+                    else if (prev_group == 3) YH_VMCNT(3);
+                    else YH_VMCNT(4);
+                }
+                __builtin_amdgcn_s_barrier();
+                prev_group = 0;
+                {
+                    // weight tile of step kt + 3 (wrapping into the next tile's stream)
+                    const int tapB = (tap + STG - 1) % 9;
+                    const int cblkB = cblk + ((tap + STG - 1) >= 9 ? 1 : 0);
+                    if (cblkB < ncb || has_next) {
+                        issue_W(tapB, cblkB < ncb ? cblkB : 0, islot);
+                        prev_group = nbw;
+                    }
+                    if (tap < NPW) {
+                        if (!last_blk) prev_group += issue_patch_part(voffP, tap, cblk + 1, pb ^ 1);
+                        else if (has_next) prev_group += issue_patch_part(voffN, tap, 0, pb ^ 1);
+                    }
+                }
+                const int kh = tap / 3, kw = tap % 3;
+                int tapoff = dgrad ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;            // scalar
+                asm volatile("" : "+s"(tapoff));
+                const int sbase = slot * BST_BYTES;
+                int abase[TMR], afx[TMR];
+#pragma unroll
+                for (int i = 0; i < TMR; ++i) {
+                    const int pr = pr0[i] + tapoff;
+                    abase[i] = inv[i] ? ZERO_OFF : pb * PATCH_BYTES + pr * ROWB;
+                    afx[i] = inv[i] ? -1 : swz_f<CHR>(pr);
+                }
+#pragma unroll
+                for (int ks = 0; ks < BKT / 32; ++ks) {
+                    if (TL && ks >= ksn) continue;
+                    bf16x8_t xf[TMR], wf[TNC];
+#pragma unroll
+                    for (int i = 0; i < TMR; ++i) {
+                        const int off = afx[i] < 0 ? (kq << 4) : (((ks * 4 + kq) ^ afx[i]) << 4);
+                        xf[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + abase[i] + off));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TNC; ++j)
+                        wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + sbase + rdW[ks] + j * (16 * ROWB)));
+#pragma unroll
+                    for (int i = 0; i < TMR; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNC; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                }
+                slot = slot + 1 == STG ? 0 : slot + 1;
+                islot = islot + 1 == STG ? 0 : islot + 1;
+            }
+            pb ^= 1;
+        }
+        // the next tile's patch and first two weight tiles must have landed before its step 0 (the third stays in flight);
+        // the epilogue works in the patch buffer the next tile does NOT use
+        if (has_next) { if (wave < 4) { YH_VMCNT(3); } else { YH_VMCNT(2); } } else { YH_VMCNT(0); }
+        uint16_t* sC = reinterpret_cast<uint16_t*>(smem + (pb ^ 1) * PATCH_BYTES);
+        constexpr int CPR = BN / 8;                   // 20 chunks of 8 channels per row
+#pragma unroll 1
+        for (int ph = 0; ph < 4; ++ph) {
+            YH_LDS_BARRIER();                         // previous phase's readers done (ph 0: every wave is out of the k loop)
+            if (wm == ph) {
+#pragma unroll
+                for (int j = 0; j < TNC; ++j) {
+                    const int cc = wn * 80 + j * 16 + 4 * kq;
+                    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f), ct = cb;
+                    if (EPI == 2) {
+                        cb = *reinterpret_cast<const float4*>(sConst + cc);
+                        cs = *reinterpret_cast<const float4*>(sConst + BN + cc);
+                        ct = *reinterpret_cast<const float4*>(sConst + 2 * BN + cc);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TMR; ++i) {
+                        float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                        if (EPI == 2) {
+                            v0 = (v0 + cb.x) * cs.x + ct.x; v1 = (v1 + cb.y) * cs.y + ct.y;
+                            v2 = (v2 + cb.z) * cs.z + ct.z; v3 = (v3 + cb.w) * cs.w + ct.w;
+                            if (d.act == YH_ACT_SILU) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                        }
+                        *reinterpret_cast<uint2*>(sC + (i * 16 + l15) * CP + cc) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+                    }
+                }
+            }
+            YH_LDS_BARRIER();
+            for (int id = t; id < 64 * CPR; id += NT) {
+                const int row = id / CPR;
+                const int cch = id - row * CPR;
+                const int n = n0 + cch * 8;
+                const int orow_i = sPix[ph * 64 + row];
+                if (orow_i >= 0 && n < d.N) {
+                    const size_t orow = (size_t)orow_i;
+                    uint4 v = *reinterpret_cast<const uint4*>(sC + row * CP + cch * 8);
+                    if (EPI == 2) {
+                        uint16_t* dst;
+                        const bool first = n < d.nsplit;
+                        if (first) dst = d.out0 + orow * d.ld0 + n;
+                        else       dst = d.out1 + orow * d.ld1 + (n - d.nsplit);
+                        const bool addres = (d.res != nullptr) && first;
+                        if (addres || d.accumulate) {
+                            float f[8];
+                            unpack8(v, f);
+                            if (addres) {
+                                uint4 rv = *reinterpret_cast<const uint4*>(d.res + orow * d.ldr + n);
+                                float g2[8]; unpack8(rv, g2);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += g2[e];
+                            }
+                            if (d.accumulate) {
+                                uint4 ov = *reinterpret_cast<const uint4*>(dst);
+                                float g2[8]; unpack8(ov, g2);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) f[e] += g2[e];
+                            }
+                            v = pack8(f);
+                        }
+                        *reinterpret_cast<uint4*>(dst) = v;
+                    } else {
+                        *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
+                    }
+                }
+            }
+        }
+        YH_LDS_BARRIER();                             // epilogue buffer and pixel table free for the next tile
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) voffP[i] = voffN[i];
+    }
+}
+
+constexpr size_t conv_halo160_smem_bytes() { return 2 * 304 * 128 + 4 * 160 * 128 + 128 + 3 * 160 * 4 + 256 * 4; }
+
 template <int BN>
 constexpr size_t conv_halo_smem_bytes() {
     return 2 * 352 * 128 + 4 * (size_t)BN * 128 + 128 + 3 * BN * 4 + 256 * 4;
@@ -1642,23 +1932,24 @@ constexpr size_t conv_halo_smem_bytes() {
 
 // tile geometry of the halo kernel for an H x W map: TH x TW output pixels (<= 256) whose (TH+2) x (TW+2) patch fits 352 rows,
 // chosen to waste the fewest MFMA rows (ragged tiles and TH*TW < 256)
-bool conv_halo_geom_search(int H, int W, HaloGeom* g);
-// the search below is ~200 divisions: its result per map size is kept (the planner runs for every launch)
-bool conv_halo_geom(int H, int W, HaloGeom* g)
+bool conv_halo_geom_search(int H, int W, int max_rows, HaloGeom* g);
+// the search below is ~200 divisions: its result per map size is kept (the planner runs for every launch).
+// max_rows: patch rows one buffer holds (352 with the 64- / 128-channel weight ring, 304 next to the 160-channel one)
+bool conv_halo_geom(int H, int W, HaloGeom* g, int max_rows = 352)
 {
-    struct Memo { int H, W; bool ok; HaloGeom g; };
+    struct Memo { int H, W, R; bool ok; HaloGeom g; };
     static thread_local Memo memo[8];
     static thread_local int next = 0;
     for (int i = 0; i < 8; ++i)
-        if (memo[i].H == H && memo[i].W == W && H > 0) { *g = memo[i].g; return memo[i].ok; }
+        if (memo[i].H == H && memo[i].W == W && memo[i].R == max_rows && H > 0) { *g = memo[i].g; return memo[i].ok; }
     Memo& m = memo[next];
     next = (next + 1) & 7;
-    m.H = H; m.W = W;
-    m.ok = conv_halo_geom_search(H, W, &m.g);
+    m.H = H; m.W = W; m.R = max_rows;
+    m.ok = conv_halo_geom_search(H, W, max_rows, &m.g);
     *g = m.g;
     return m.ok;
 }
-bool conv_halo_geom_search(int H, int W, HaloGeom* g)
+bool conv_halo_geom_search(int H, int W, int max_rows, HaloGeom* g)
 {
     double best = 0.0;
     bool found = false;
@@ -1668,7 +1959,7 @@ bool conv_halo_geom_search(int H, int W, HaloGeom* g)
         if (th < 1) continue;
         for (int th2 = th; th2 >= (th > 2 ? th - 2 : 1); --th2) {
             const int pw = tw + 2, ph = th2 + 2;
-            if (pw * ph > 352) continue;
+            if (pw * ph > max_rows) continue;
             const int tx = (W + tw - 1) / tw, ty = (H + th2 - 1) / th2;
             const double eff = (double)H * W / ((double)tx * ty * 256.0);
             if (eff > best + 1e-9) {
@@ -1916,7 +2207,7 @@ int conv_v3_bkt(const yh_conv_desc* d);
 // 2 = 128 x 128 (4 waves), 3 = 128 x 64 (4 waves).  d->algo: 0 library default, 1 force v2, 2..4 = variant 1..3 when eligible.
 int conv_v3_variant(const yh_conv_desc* d)
 {
-    if (d->algo == 1 || d->algo == 5 || stem_eligible(d) || !conv_v2_ok(d)) return 0;
+    if (d->algo == 1 || d->algo == 5 || d->algo == 6 || stem_eligible(d) || !conv_v2_ok(d)) return 0;
     if (conv_dbg_mask() & 512) return 0;
     if (conv_v3_bkt(d) == 0) return 0;
     if (d->N <= 32) return 0;
@@ -1961,6 +2252,22 @@ bool conv_halo_ok(const yh_conv_desc* d, HaloGeom* g)
 // channels per k-step of the LDS-DMA kernel: 0 = not eligible.  64 needs whole 64-channel blocks in every segment but the
 // last, whose channel count may be any multiple of 16 (the "tail" variant of the kernel); 32 needs multiples of 32 everywhere.
 // Where both work, 64 is the default (half the barriers) and d->tile_k == 32 selects the short steps.
+// 160-wide halo kernel (conv_halo160_kernel): only on request (d->algo == 6; the engine times it where it is eligible):
+// 3x3 / stride 1 / pad 1, one segment with >= 64 channels in a multiple of 32, N a multiple of 160, inference epilogues
+bool conv_halo160_ok(const yh_conv_desc* d, HaloGeom* g)
+{
+    if (d->algo != 6 || stem_eligible(d)) return false;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->nseg != 1 || d->seg[0].ups) return false;
+    if (d->seg[0].C % 32 || d->seg[0].C < 64 || d->N % 160 || d->stats || d->bnr_part) return false;
+    if (d->Ho != d->Hi || d->Wo != d->Wi) return false;
+    if (!conv_v2_ok(d)) return false;
+    if ((long)d->B * d->Ho * d->Wo >= (1L << 31)) return false;
+    HaloGeom gg;
+    if (!conv_halo_geom(d->Ho, d->Wo, &gg, 304)) return false;
+    if (g) *g = gg;
+    return true;
+}
+
 int conv_v3_bkt(const yh_conv_desc* d) {
     bool ok64 = true, ok32 = true;
     int Ctot = 0;
@@ -1983,6 +2290,15 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
         return;
     }
     HaloGeom hgm;
+    if (conv_halo160_ok(d, &hgm)) {
+        const int nt = d->N / 160;
+        const long ntiles = (long)d->B * hgm.tiles_x * hgm.tiles_y;
+        int cap = 256 / nt;
+        if (cap < 1) cap = 1;
+        if (d->grid_cap > 0) cap = d->grid_cap;
+        *gx = (int)(ntiles < cap ? ntiles : cap); *gy = nt; *bn = 160;
+        return;
+    }
     if (!stem_eligible(d) && conv_halo_ok(d, &hgm)) {
         const int b = d->N <= 64 ? 64 : 128;
         const int nt = (d->N + b - 1) / b;
@@ -2098,8 +2414,9 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     conv_grid(d, &gx, &gy, &bn);
     YH_CHECK_ARG(gy * bn <= d->Npad, "yh_conv_igemm: Npad too small for tile");
     HaloGeom hgeo;
-    const bool halo = !stem_eligible(d) && conv_halo_ok(d, &hgeo);
-    const int v3 = halo ? 0 : conv_v3_variant(d);
+    const bool halo160 = conv_halo160_ok(d, &hgeo);
+    const bool halo = !halo160 && !stem_eligible(d) && conv_halo_ok(d, &hgeo);
+    const int v3 = (halo || halo160) ? 0 : conv_v3_variant(d);
     if (k.cls && !v3) { gx = (gx + 3) / 4; if (gx > k.mtiles) gx = k.mtiles; }
     dim3 grid(gx, gy, k.cls ? 4 : 1), block(256);
     // ---- lean buffer-load kernel
@@ -2149,6 +2466,27 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
                      "yh_conv_igemm: the fused BatchNorm-backward reduction needs the plain buffer-load data-gradient path");
         YH_CHECK_ARG(d->bnr_z && yh_aligned16(d->bnr_z) && d->bnr_ldz % 8 == 0 && d->bnr_ws && d->bnr_C >= d->N && d->N % 8 == 0,
                      "yh_conv_igemm: bad fused-reduction operands");
+    }
+    if (halo160) {
+        YH_CHECK_ARG(k.v2 && !k.cls, "yh_conv_igemm: the halo kernel needs the buffer-load path");
+        const int epi = generic ? 2 : 0;
+        const bool tl = (k.Ctot % 64) != 0;
+        if (name_out) { snprintf(name_out, name_len, tl ? "conv_halo160_kernel<%d, true>" : "conv_halo160_kernel<%d, false>", epi); return YH_OK; }
+        hipStream_t sth = (hipStream_t)stream;
+        const dim3 gridh(gx, gy), blkh(512);
+        const size_t sm = conv_halo160_smem_bytes();
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_halo160_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            (void)hipFuncSetAttribute((const void*)conv_halo160_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            (void)hipFuncSetAttribute((const void*)conv_halo160_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            (void)hipFuncSetAttribute((const void*)conv_halo160_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            attr_set = true;
+        }
+        if (epi == 2) { if (tl) conv_halo160_kernel<2, true><<<gridh, blkh, sm, sth>>>(k, hgeo); else conv_halo160_kernel<2, false><<<gridh, blkh, sm, sth>>>(k, hgeo); }
+        else          { if (tl) conv_halo160_kernel<0, true><<<gridh, blkh, sm, sth>>>(k, hgeo); else conv_halo160_kernel<0, false><<<gridh, blkh, sm, sth>>>(k, hgeo); }
+        YH_CHECK_LAUNCH("yh_conv_igemm(halo160)");
+        return YH_OK;
     }
     if (halo) {
         YH_CHECK_ARG(k.v2 && !k.cls, "yh_conv_igemm: the halo kernel needs the buffer-load path");

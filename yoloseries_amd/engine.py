@@ -489,7 +489,7 @@ class Program:
         only the number of BatchNorm partial-sum rows follows the grid."""
         if os.environ.get("YH_CONV_TUNE", "1") == "0":
             return
-        key = f"conv5:{kind}:" + ",".join(str(int(v)) for v in (
+        key = f"conv6:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
             int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), d.acc_rows))
@@ -515,10 +515,10 @@ class Program:
                 cands.append((1, tk, cap))
         d.tile_k = d.grid_cap = 0
         if os.environ.get("YH_CONV_V3", "1") != "0":
-            for algo in (2, 3, 4, 5):
+            for algo in (2, 3, 4, 5, 6):
                 d.algo = algo
                 kn = self._kernel_name(d)
-                if ("conv_v3" in kn and algo < 5) or ("conv_halo" in kn and algo == 5):
+                if ("conv_v3" in kn and algo < 5) or ("conv_halo_kernel" in kn and algo == 5) or ("conv_halo160" in kn and algo == 6):
                     cands.append((algo, 0, 0))
                     if algo < 5 and kn.endswith(", true>") and all(d.seg[i].C % 32 == 0 for i in range(d.nseg)):
                         cands.append((algo, 32, 0))    # ragged last channel block: 32-channel steps instead of 64 + tail
