@@ -423,3 +423,12 @@ def test_conv_halo160_kernel(dev, B, H, W, Cin, Cout):
         hipk.conv_launch(d3)
         torch.cuda.synchronize()
         _close(gx, gref.permute(0, 2, 3, 1), 1e-2, 4e-2)
+        # ... accumulating onto an existing gradient (generic epilogue)
+        gacc = _nhwc(B, H, W, Cin, dev, 55)
+        g0 = gacc.clone()
+        d4 = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, H, W, 3, 1, 1, wd, Cin, hipk.full(gacc), accumulate=1)
+        d4.algo = 6
+        assert "conv_halo160_kernel<2" in _kname(d4), _kname(d4)
+        hipk.conv_launch(d4)
+        torch.cuda.synchronize()
+        _close(gacc, gref.permute(0, 2, 3, 1).to(torch.bfloat16).float() + g0.float(), 1e-2, 4e-2)
