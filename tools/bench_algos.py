@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel families of yh_conv_igemm side by side on representative layer shapes: register-staged conv_v2 (algo 1) against the
 LDS-DMA ring kernel conv_v3 with its 256x128 / 128x128 / 128x64 tiles (algo 2..4).
-usage: bench_algos.py [v5s|v5l|v5x1280] [fwd|dgrad|eval] [iters]"""
+usage: bench_algos.py [v5s|v5l|v5x1280] [fwd|dgrad|dgrad3|eval] [iters]"""
 import ctypes as C
 import os
 import sys
@@ -62,6 +62,11 @@ for name, H, Cin, Cout, k, s in shapes:
         gx = torch.zeros(B, H, H, Cin, dtype=torch.bfloat16, device=dev)
         wd = hipk.pack_weight_dgrad(w)
         d = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, H, Ho, Ho, k, s, p, wd, Cin, hipk.full(gx))
+        if mode == "dgrad3":             # with the fused BatchNorm-backward reduction of the producer layer (EPI 3)
+            z = torch.randn(B, H, H, Cin, device=dev).to(torch.bfloat16)
+            ws = torch.cat([torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev)])
+            slab = torch.zeros(8192, 2, Cin, device=dev)
+            d.bnr_z, d.bnr_ldz, d.bnr_C, d.bnr_ws, d.bnr_part = z.data_ptr(), Cin, Cin, ws.data_ptr(), slab.data_ptr()
     fl = 2.0 * M * Cout * Cin * k * k
     res = []
     for algo in (1, 2, 3, 4, 5, 6):

@@ -64,6 +64,23 @@ __device__ __forceinline__ void put_bnr(const yh_conv_desc& d, size_t row, int w
         d.bnr_part[(row * 2 + which) * d.N + n] = v;
 }
 
+// Stride-2 data gradients run as four parity classes of output pixels (2i+ph, 2j+pw) that touch only their structurally
+// non-zero taps: 1, 2, 2 and 4 taps for a 3x3 kernel.  blockIdx.z enumerates (class, slot): a class owns as many slots as it
+// has taps (KH*KW slots in all) and its m-tiles are dealt over slots x gridDim.x blocks, so every block of the launch carries
+// the same work (one z per class left the one-tap class idle 3/4 of the time).
+__device__ __forceinline__ void cls_slot(const yh_conv_desc& d, int z, int& ph, int& pw, int& slot, int& nslots)
+{
+    int acc = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cph = c >> 1, cpw = c & 1;
+        const int kh0 = (cph + d.pad) & 1, kw0 = (cpw + d.pad) & 1;
+        const int n = ((d.KH - kh0 + 1) / 2) * ((d.KW - kw0 + 1) / 2);
+        if (z < acc + n || c == 3) { ph = cph; pw = cpw; slot = z - acc; nslots = n; return; }
+        acc += n;
+    }
+}
+
 template <int BN, int WM, int WN, bool FAST, int MINW>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
 {
@@ -92,7 +109,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
     const int HoWo = d.Ho * d.Wo;
     const int sdmask = (1 << p.sdshift) - 1;
     // parity class of this block (cls mode): output pixels (2i+ph, 2j+pw); taps kh = kh0 + 2a, kw = kw0 + 2b
-    const int ph = p.cls ? (blockIdx.z >> 1) : 0, pw = p.cls ? (blockIdx.z & 1) : 0;
+    int ph = 0, pw = 0, zslot = 0, zslots = 1;
+    if (p.cls) cls_slot(d, blockIdx.z, ph, pw, zslot, zslots);
     const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
     const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
     const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
@@ -102,7 +120,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(const ConvK p)
 
     float run_s = 0.f, run_q = 0.f;
 
-    for (int mt = blockIdx.x; mt < p.mtiles; mt += gridDim.x) {
+    for (int mt = blockIdx.x + gridDim.x * zslot; mt < p.mtiles; mt += gridDim.x * zslots) {
         const int m0 = mt * BM;
         int hb[2], wb[2], img[2];
 #pragma unroll
@@ -414,7 +432,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
     const int n0 = blockIdx.y * BN;
     const int HoWo = d.Ho * d.Wo;
     const int sdmask = (1 << p.sdshift) - 1;
-    const int ph = p.cls ? (blockIdx.z >> 1) : 0, pw = p.cls ? (blockIdx.z & 1) : 0;
+    int ph = 0, pw = 0, zslot = 0, zslots = 1;
+    if (p.cls) cls_slot(d, blockIdx.z, ph, pw, zslot, zslots);
     const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
     const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
     const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
 #define STAMP(var) do { } while (0)
 #endif
 
-    for (int mt = blockIdx.x; mt < p.mtiles; mt += gridDim.x) {
+    for (int mt = blockIdx.x + gridDim.x * zslot; mt < p.mtiles; mt += gridDim.x * zslots) {
 #ifdef YH_CONV_STAMPS
         long long st_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -865,7 +884,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
     const int n0 = blockIdx.y * BN;
     const int HoWo = d.Ho * d.Wo;
     const int sdmask = (1 << p.sdshift) - 1;
-    const int ph = p.cls ? (blockIdx.z >> 1) : 0, pw = p.cls ? (blockIdx.z & 1) : 0;
+    int ph = 0, pw = 0, zslot = 0, zslots = 1;
+    if (p.cls) cls_slot(d, blockIdx.z, ph, pw, zslot, zslots);
     const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
     const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
     const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
@@ -913,7 +933,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
         __syncthreads();
     }
 
-    for (int mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
+    for (int mt = blockIdx.x + gridDim.x * zslot; mt < mtiles; mt += gridDim.x * zslots) {
         const int m0 = mt * BMT;
         int hb[NA], wb[NA], img[NA];
         unsigned voff0[NA], voff1[NA];
@@ -2318,7 +2338,7 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
         const bool cls = d->mode == YH_CONV_DGRAD && d->stride == 2 && d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->KH >= 2 && d->KW >= 2 && !d->stats;
         const long Mc = cls ? M / 4 : M;
         const int mt = (int)((Mc + bmt - 1) / bmt);
-        int cap = (256 * occ) / (nt * (cls ? 4 : 1));
+        int cap = (256 * occ) / (nt * (cls ? d->KH * d->KW : 1));
         if (cap < 1) cap = 1;
         if (d->grid_cap > 0) cap = d->grid_cap;
         *gx = mt < cap ? mt : cap; *gy = nt; *bn = b;
@@ -2417,8 +2437,9 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     const bool halo160 = conv_halo160_ok(d, &hgeo);
     const bool halo = !halo160 && !stem_eligible(d) && conv_halo_ok(d, &hgeo);
     const int v3 = (halo || halo160) ? 0 : conv_v3_variant(d);
-    if (k.cls && !v3) { gx = (gx + 3) / 4; if (gx > k.mtiles) gx = k.mtiles; }
-    dim3 grid(gx, gy, k.cls ? 4 : 1), block(256);
+    const int zslots = k.cls ? d->KH * d->KW : 1;      // (parity class, slot) pairs: see cls_slot
+    if (k.cls && !v3) { gx = (gx + zslots - 1) / zslots; if (gx > k.mtiles) gx = k.mtiles; }
+    dim3 grid(gx, gy, zslots), block(256);
     // ---- lean buffer-load kernel
     const int bkt = pick_bkt(d, bn);
     k.v2 = conv_v2_ok(d) ? 1 : 0;
@@ -2623,12 +2644,13 @@ extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
     conv_grid(d, &gx, &gy, &bn);
     const bool cls = d->stride == 2 && d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->KH >= 2 && d->KW >= 2;
     if (!stem_eligible(d) && conv_halo_ok(d, nullptr)) return gx;
-    if (conv_v3_variant(d)) return cls ? gx * 4 : gx;
+    const int zslots = d->KH * d->KW;
+    if (conv_v3_variant(d)) return cls ? gx * zslots : gx;
     if (cls) {
         const long mt = ((long)(M / 4) + BM - 1) / BM;
-        gx = (gx + 3) / 4;
+        gx = (gx + zslots - 1) / zslots;
         if (gx > mt) gx = (int)mt;
-        return gx * 4;
+        return gx * zslots;
     }
     return gx;
 }
