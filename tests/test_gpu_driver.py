@@ -83,3 +83,23 @@ def test_training_learns_a_detection_task(dev, tmp_path, monkeypatch):
     assert last < 0.6 * first, (first, last)
     # (the fp32 atomics of the weight gradients make every run a slightly different trajectory: observed mAP50 0.25-0.45, recall 0.24-0.6)
     assert t.last_metrics["map50"] > 0.08 and t.last_metrics["recall"] > 0.12, t.last_metrics
+
+
+def test_yolox_training_and_validation_drivers(dev, tmp_path, monkeypatch):
+    """train_yolox.py / val_yolox.py mirrors (the reference's YOLOX drivers differ from the v5 ones in the model table, loss /
+    evaluator constructors, log line, checkpoint names and config file)"""
+    sys.path.insert(0, ROOT)
+    monkeypatch.chdir(tmp_path)
+    import train_yolox
+    import val_yolox
+    t = train_yolox.main(["--epochs", "2", "--img", "128", "--batch", "4", "--steps-per-epoch", "4"])
+    assert type(t.loss_fcn).__name__ == "YOLOXLoss" and type(t.validate).__name__ == "YOLOXEvaluator"
+    losses = [h["tot_loss"] for h in t.history]
+    assert len(losses) == 8 and all(np.isfinite(losses)) and all("l1_loss" in h for h in t.history)
+    assert os.path.basename(t.last_ckpt) == "yolox_small_epoch_2.pth"
+    ck = torch.load(t.last_ckpt, map_location="cpu", weights_only=False)
+    assert len(ck["model_state_dict"]) == 414 and ck["hyp"]["topk"] == 13
+    assert set(t.last_metrics) == {"map", "map50", "precision", "recall", "n_pred"}
+    v = val_yolox.main(["--img", "128", "--batch", "4", "--val-batches", "2", "--ckpt", t.last_ckpt])
+    assert v.loaded_ema and v.metrics["images"] == 8
+    assert all(np.isfinite([v.metrics[k] for k in ("map", "map50", "precision", "recall")]))

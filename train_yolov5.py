@@ -82,6 +82,8 @@ class PrefetchedDataset:
 
 
 class Training:
+    CKPT_PREFIX = "yolov5"            # checkpoint file names (train_yolov5.py:608; train_yolox.py:594 uses "yolox")
+    CLIP_GRAD_NORM = 10.0             # train_yolov5.py:343-344 (train_yolox.py comments the clipping out: None there)
 
     def __init__(self, anchors, hyp):
         self.anchors, self.hyp = anchors, hyp
@@ -119,16 +121,24 @@ class Training:
         hyp['warmup_steps'] = max(hyp.get('warmup_epoch', 3) * len(self.train_dataloader), 1)       # :192
         self.model = self.select_model().to(self.device)
         self.dp = DataParallelGrads(self.model) if self.is_distributed else None
-        anchors = self.anchors.to(self.device)
-        self.loss_fcn = YOLOV5Loss(anchors, hyp)
+        self.loss_fcn = self.build_loss()
         self.ema_model = ExponentialMovingAverageModel(self.model) if hyp['do_ema'] else None
         self.optimizer = self._init_optimizer()
         self.lr_scheduler_fn = self._init_scheduler()
         self.accumulate = max(1, round(hyp['accumulate_loss_step'] / hyp['batch_size'] / get_world_size()))
-        self.validate = YOLOV5Evaluator(self.model, anchors, hyp, compute_metric=True)
+        self.validate = self.build_evaluator(self.model)
         self.start_epoch = hyp.get('start_epoch', 0)
         if hyp.get('pretrained_model_path'):
             self.load_model(hyp['pretrained_model_path'])
+
+    def build_loss(self):
+        return YOLOV5Loss(self.anchors.to(self.device), self.hyp)                     # train_yolov5.py:223
+
+    def build_evaluator(self, model):
+        return YOLOV5Evaluator(model, self.anchors.to(self.device), self.hyp, compute_metric=True)   # :697
+
+    def log_line(self, h):
+        return f"tot {h['tot_loss']:.3f} box {h['iou_loss']:.3f} cof {h['cof_loss']:.3f} cls {h['cls_loss']:.3f} tars {h['tar_nums']}"
 
     def _init_optimizer(self):
         """3 parameter groups: BN weights | conv weights (+weight decay) | biases (train_yolov5.py:258-280)"""
@@ -178,7 +188,8 @@ class Training:
                     loss_dict = self.loss_fcn(stage_preds, x['ann'])
                     loss_dict['tot_loss'].backward()
                 if boundary:
-                    self.optimizer.clip_grad_norm_(10.0)
+                    if self.CLIP_GRAD_NORM is not None:
+                        self.optimizer.clip_grad_norm_(self.CLIP_GRAD_NORM)
                     self.optimizer.step()
                     self.optimizer.zero_grad()
                     if self.ema_model is not None:
@@ -187,8 +198,7 @@ class Training:
                 if self.rank == 0 and (i % 10 == 0 or i == len(self.train_dataloader) - 1):
                     h = self.history[-1]
                     print(f"epoch {epoch + 1}/{hyp['total_epoch']} step {i + 1}/{len(self.train_dataloader)} "
-                          f"tot {h['tot_loss']:.3f} box {h['iou_loss']:.3f} cof {h['cof_loss']:.3f} cls {h['cls_loss']:.3f} "
-                          f"tars {h['tar_nums']} lr {self.optimizer.param_groups[0]['lr']:.5f}", flush=True)
+                          f"{self.log_line(h)} lr {self.optimizer.param_groups[0]['lr']:.5f}", flush=True)
             self.save_model(epoch + 1, step_in_total=step_in_total, loss_dict=self.history[-1])
             if (epoch + 1) % hyp['validation_every'] == 0:
                 self.after_epoch(epoch + 1)
@@ -220,7 +230,7 @@ class Training:
     def save_model(self, cur_epoch, filename=None, step_in_total=None, loss_dict=None, save_optimizer=True):
         if self.rank != 0 or cur_epoch % self.hyp['save_ckpt_every'] != 0:
             return None
-        path = self.cwd / 'checkpoints' / (f'{filename}.pth' if filename else f'yolov5_{self.hyp["model_type"]}_epoch_{cur_epoch}.pth')
+        path = self.cwd / 'checkpoints' / (f'{filename}.pth' if filename else f'{self.CKPT_PREFIX}_{self.hyp["model_type"]}_epoch_{cur_epoch}.pth')
         path.parent.mkdir(parents=True, exist_ok=True)
         hyp_save = {k: v for k, v in self.hyp.items()}
         state = {"model_state_dict": self.model.state_dict(),
@@ -254,9 +264,9 @@ class _Null:
         return False
 
 
-def main(argv=None):
+def main(argv=None, training_cls=None, default_cfg=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfg", default=os.path.join(ROOT, "config", "train_yolov5.yaml"))
+    ap.add_argument("--cfg", default=default_cfg or os.path.join(ROOT, "config", "train_yolov5.yaml"))
     ap.add_argument("--epochs", type=int)
     ap.add_argument("--img", type=int)
     ap.add_argument("--batch", type=int)
@@ -276,8 +286,11 @@ def main(argv=None):
     if args.steps_per_epoch: hyp['steps_per_epoch'] = args.steps_per_epoch  # noqa: E701
     if args.model_type: hyp['model_type'] = args.model_type              # noqa: E701
     if args.data: hyp['data_source'] = args.data                         # noqa: E701
-    anchors = torch.from_numpy(COCO_ANCHORS.copy())                      # train_yolov5.py:819
-    t = Training(anchors, hyp)
+    if training_cls is not None:                                         # train_yolox.py:808: Training(hyp)
+        t = training_cls(hyp)
+    else:
+        anchors = torch.from_numpy(COCO_ANCHORS.copy())                  # train_yolov5.py:819
+        t = Training(anchors, hyp)
     t.step()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

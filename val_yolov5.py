@@ -62,6 +62,9 @@ class Training:
         if hyp.get('pretrained_model_path'):
             self.load_model(hyp['pretrained_model_path'])
 
+    def build_evaluator(self, model):
+        return YOLOV5Evaluator(model, self.anchors.to(self.device), self.hyp, compute_metric=True)      # val_yolov5.py:301
+
     def load_model(self, path):
         """checkpoint keys of train_yolov5.py:603-629; the EMA weights are preferred when present (val_yolov5.py:297-303)"""
         state = torch.load(path, map_location=self.device, weights_only=False)
@@ -107,7 +110,7 @@ class Training:
     def step(self):
         eval_model = self.ema_model.ema if (self.ema_model is not None and self.loaded_ema) else self.model
         eval_model.eval()
-        validater = YOLOV5Evaluator(eval_model, self.anchors.to(self.device), self.hyp, compute_metric=True)
+        validater = self.build_evaluator(eval_model)
         all_preds, all_gts = [], []
         t0 = time.time()
         n_img = 0
@@ -135,9 +138,9 @@ class Training:
         return self.metrics
 
 
-def main(argv=None):
+def main(argv=None, training_cls=None, default_cfg=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfg", default=os.path.join(ROOT, "config", "train_yolov5.yaml"))
+    ap.add_argument("--cfg", default=default_cfg or os.path.join(ROOT, "config", "train_yolov5.yaml"))
     ap.add_argument("--img", type=int)
     ap.add_argument("--batch", type=int)
     ap.add_argument("--val-batches", type=int)
@@ -150,8 +153,11 @@ def main(argv=None):
     if args.val_batches: hyp['val_batches'] = args.val_batches           # noqa: E701
     if args.model_type: hyp['model_type'] = args.model_type              # noqa: E701
     if args.ckpt: hyp['pretrained_model_path'] = args.ckpt               # noqa: E701
-    anchors = torch.from_numpy(COCO_ANCHORS.copy())
-    v = Training(anchors, hyp)
+    if training_cls is not None:
+        v = training_cls(hyp)
+    else:
+        anchors = torch.from_numpy(COCO_ANCHORS.copy())
+        v = Training(anchors, hyp)
     v.step()
     return v
 
