@@ -432,3 +432,23 @@ def test_conv_halo160_kernel(dev, B, H, W, Cin, Cout):
         hipk.conv_launch(d4)
         torch.cuda.synchronize()
         _close(gacc, gref.permute(0, 2, 3, 1).to(torch.bfloat16).float() + g0.float(), 1e-2, 4e-2)
+
+
+def test_conv_wgrad_operand_of_two_gib_is_split_over_the_batch(dev):
+    """yh_conv_wgrad addresses gy / x with 32-bit buffer offsets; an operand of 2 GiB or more is processed as several launches over
+    sub-ranges of the batch (same atomically accumulated dw).  gy here: 8 x 1024 x 1024 x 128 bf16 = 2 GiB."""
+    from yoloseries_amd import hipk
+    B, H, W, Cin, Cout = 8, 1024, 1024, 8, 128
+    g = torch.Generator().manual_seed(61)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    gy = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    for b in range(B):
+        gy[b] = (torch.randn(H, W, Cout, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    assert gy.numel() * 2 >= 2 ** 31
+    dw = torch.zeros(Cout, Cin, device=dev)
+    hipk.wgrad_launch(hipk.wgrad_desc(hipk.full(gy), Cout, hipk.full(x), 0, Cin, B, H, W, H, W, 1, 1, 0, dw, 1024))
+    torch.cuda.synchronize()
+    ref = torch.zeros(Cout, Cin, dtype=torch.float64, device=dev)
+    for b in range(B):                      # fp64 reference image by image (bounded memory)
+        ref += gy[b].reshape(-1, Cout).double().t() @ x[b].reshape(-1, Cin).double()
+    _close(dw.double(), ref, 2e-3, 2e-3 * ref.abs().max().item())

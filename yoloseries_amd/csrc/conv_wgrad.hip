@@ -295,7 +295,34 @@ extern "C" int yh_conv_wgrad_tiles(int N, int Kseg)
     return ((N + tn - 1) / tn) * ((Kseg + 127) / 128);
 }
 
+static int conv_wgrad_launch(const yh_wgrad_desc* d, yh_stream stream);
+
+/* The kernels address gy and the input segment with 32-bit buffer offsets.  A launch whose operands reach 2 GiB is split over the
+ * batch: every part is a launch of its own on a sub-range of images (pointers advanced, dw accumulated by the same atomics). */
 extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
+{
+    YH_CHECK_ARG(d != nullptr && d->B > 0 && d->Ho > 0 && d->Wo > 0 && d->Hi > 0 && d->Wi > 0, "yh_conv_wgrad: null desc / bad dims");
+    const unsigned long gy_img = (unsigned long)d->Ho * d->Wo * d->ldg * 2;
+    const unsigned long x_img = (unsigned long)(d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups) * d->seg.ld * 2;
+    const unsigned long lim = (1ul << 31) - 4096;
+    if (gy_img * d->B < lim && x_img * d->B < lim) return conv_wgrad_launch(d, stream);
+    const unsigned long per = gy_img > x_img ? gy_img : x_img;
+    YH_CHECK_ARG(per < lim, "yh_conv_wgrad: a single image needs a 2 GiB operand");
+    const int chunk = (int)(lim / per);
+    const int parts = (d->B + chunk - 1) / chunk;
+    for (int b0 = 0; b0 < d->B; b0 += chunk) {
+        yh_wgrad_desc p = *d;
+        p.B = d->B - b0 < chunk ? d->B - b0 : chunk;
+        p.gy = d->gy + (size_t)b0 * (gy_img / 2);
+        p.seg.ptr = d->seg.ptr + (size_t)b0 * (x_img / 2);
+        p.splits = (d->splits + parts - 1) / parts;
+        const int rc = conv_wgrad_launch(&p, stream);
+        if (rc != YH_OK) return rc;
+    }
+    return YH_OK;
+}
+
+static int conv_wgrad_launch(const yh_wgrad_desc* d, yh_stream stream)
 {
     YH_CHECK_ARG(d != nullptr, "yh_conv_wgrad: null desc");
     YH_CHECK_ARG(d->gy && yh_aligned16(d->gy) && d->ldg % 8 == 0, "yh_conv_wgrad: gy null/unaligned");

@@ -775,15 +775,6 @@ class Program:
         B, pk, L = self.B, self.pack, self.L
         cmds = []
         max_gy = 0
-        # yh_conv_wgrad addresses its operands with 32-bit buffer offsets: refuse before anything is allocated
-        for op in self.ops:
-            if isinstance(op, ConvOp):
-                gyb = B * op.Ho * op.Wo * (op.y.C if op.kind == 'plain' else op.N) * 2
-                xb = max(B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.buf.C * 2 for sg in op.segs)
-                if gyb >= 2 ** 31 or xb >= 2 ** 31:
-                    raise YoloHipError(f"{op.name}: training at this batch / resolution needs a >= 2 GiB operand in the weight-gradient "
-                                       f"kernel (gy {gyb / 2**30:.2f} GiB, x {xb / 2**30:.2f} GiB); lower the per-GPU batch "
-                                       f"(inference has no such limit)")
         for b in self.bufs:
             b.ginit = np.zeros(b.C, dtype=bool)
             if b.needs_grad and b.g is None and not b.name.endswith(".y") and not getattr(b, "is_head", False):
