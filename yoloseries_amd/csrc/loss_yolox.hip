@@ -89,6 +89,30 @@ __device__ __forceinline__ float iou_xyxy(float ax0, float ay0, float ax1, float
     return inter / fmaxf(a1 + a2 - inter, 1e-9f);
 }
 
+// Block-free arg-max of a (value, index) pair over a wavefront: the pair is packed into one 64-bit key whose unsigned
+// order is (value desc, index asc) for want_max and (value asc, index asc) otherwise, reduced with six DPP steps (row shifts
+// 1/2/4/8, then row_bcast 15 and 31) and read back from lane 63.  Values must not be NaN or -0.0; index 0x7fffffff is the
+// "nothing" sentinel and loses every tie.
+__device__ __forceinline__ void wave_pick(float& v, int& idx, bool want_max)
+{
+    unsigned b = __float_as_uint(v);
+    b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;          // monotone float -> unsigned
+    unsigned hi = want_max ? b : ~b, lo = ~(unsigned)idx;
+#define YH_DPP_MAX(ctrl, rows) { \
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, ctrl, rows, 0xf, false); \
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, ctrl, rows, 0xf, false); \
+        if (ohi > hi || (ohi == hi && olo > lo)) { lo = olo; hi = ohi; } }
+    YH_DPP_MAX(0x111, 0xf) YH_DPP_MAX(0x112, 0xf) YH_DPP_MAX(0x114, 0xf) YH_DPP_MAX(0x118, 0xf)
+    YH_DPP_MAX(0x142, 0xa) YH_DPP_MAX(0x143, 0xc)
+#undef YH_DPP_MAX
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    b = want_max ? hi : ~hi;
+    b = (b & 0x80000000u) ? (b ^ 0x80000000u) : ~b;
+    v = __uint_as_float(b);
+    idx = (int)~lo;
+}
+
 struct StageX { const void* pred; void* gpred; int s, H, W, ld; float stride; };
 
 // ------------------------------------------------------------------------------------------------
@@ -211,14 +235,11 @@ __global__ __launch_bounds__(1024) void yolox_assign_kernel(const XK p, const St
     const int Y = s_misc[3];
     if (Y == 0) { if (t == 0) *fg_count = 0; return; }
 
-    // ---- register-resident path (Y <= 8192 candidates, every 640x640 case): thread t owns candidates t, t+1024, ...;
-    // their decoded boxes stay in registers, IoU / cost of a (gt, candidate) pair are computed on the fly with the
-    // same fp32 expressions as the matrix path below, the ground truths are processed one after the other by the
-    // whole block, and each top-k pick is ONE block-wide arg-max (wave shuffle + 16 LDS slots, one barrier).
+    // ---- register-resident path (Y <= 8192 candidates and topk <= 16: every 640x640 case): thread t owns candidates
+    // t, t+1024, ...; their decoded boxes stay in registers and the IoU / cost of a (gt, candidate) pair are computed
+    // on the fly with the same fp32 expressions as the matrix path below.
     constexpr int MAXJ = 8;
-    if (Y <= MAXJ * 1024) {
-        __shared__ float s_rv[2][16];
-        __shared__ int s_ri[2][16];
+    if (Y <= MAXJ * 1024 && d.topk <= 16) {
         float qx0[MAXJ], qy0[MAXJ], qx1[MAXJ], qy1[MAXJ];
         int qxy[MAXJ], cnt_l[MAXJ], mgt_l[MAXJ];         // qxy: cell column | row << 16
         unsigned invalid = 0;
@@ -249,67 +270,127 @@ __global__ __launch_bounds__(1024) void yolox_assign_kernel(const XK p, const St
             const bool inc = fminf(fminf(cx + -(x + -r), cy + -(yy + -r)), fminf(-cx + (x + r), -cy + (yy + r))) > eps;
             cost = (d.cls_cost_const + 3.f * (-logf(iou + 1e-9f))) + 100000.f * ((inb && inc) ? 0.f : 1.f);
         };
-        const int K = d.topk < Y ? d.topk : Y;
-        int par = 0;
-        for (int g = 0; g < G; ++g) {
-            float vio[MAXJ], vco[MAXJ];
-#pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                vio[j] = -INFINITY; vco[j] = INFINITY;
-                if (!(invalid & (1u << j))) pair(g, j, vio[j], vco[j]);
-            }
-            // sum of the K largest IoUs, picked in (value desc, index asc) order
+        // The ground truths are matched independently of each other (only the per-candidate claim counts meet), so
+        // a round takes GG of them at once: every wave lists its own K best candidates per ground truth with wave
+        // shuffles alone, one wave per ground truth merges the 16 lists (the global top-K is contained in their union
+        // because (value, index) is a strict total order), and the whole round costs five block barriers instead of
+        // one per pick.
+        constexpr int GG = 16, KMAX = 16;
+        __shared__ float s_lv[GG][16][KMAX];
+        __shared__ int s_li[GG][16][KMAX];
+        __shared__ int s_dk[GG];
+        __shared__ int s_pick[GG][KMAX];
+        const int K = d.topk < Y ? d.topk : Y;          // topk <= KMAX on this path
+        // the wave's `count` best of its own candidates for ground truth slot gi -> s_lv/s_li[gi][wv][*]
+        auto wave_list = [&](int gi, const float (&val)[MAXJ], int count, bool want_max) __attribute__((always_inline)) {
             unsigned taken = invalid;
-            float ksum = 0.f;
-            for (int k = 0; k < K; ++k) {
-                float bv = -INFINITY; int bi = 0x7fffffff;
+            for (int k = 0; k < count; ++k) {
+                float bv = want_max ? -INFINITY : INFINITY; int bi = 0x7fffffff;
 #pragma unroll
-                for (int j = 0; j < MAXJ; ++j)
-                    if (!(taken & (1u << j)) && (vio[j] > bv || (vio[j] == bv && t + 1024 * j < bi))) { bv = vio[j]; bi = t + 1024 * j; }
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                for (int j = 0; j < MAXJ; ++j) {
+                    const bool better = want_max ? (val[j] > bv) : (val[j] < bv);
+                    if (!(taken & (1u << j)) && (better || (val[j] == bv && t + 1024 * j < bi))) { bv = val[j]; bi = t + 1024 * j; }
                 }
-                if (lane == 0) { s_rv[par][wv] = bv; s_ri[par][wv] = bi; }
-                __syncthreads();
-                bv = s_rv[par][0]; bi = s_ri[par][0];
-#pragma unroll
-                for (int w = 1; w < 16; ++w) {
-                    const float ov = s_rv[par][w]; const int oi = s_ri[par][w];
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                wave_pick(bv, bi, want_max);
+                if (want_max && !(bv > 0.f)) {
+                    // IoUs are >= 0: everything this wave has left is exactly 0 (or nothing is left, -inf) and adds
+                    // nothing to the top-K sum, whichever of those entries the merge would pick
+                    for (int kk = k + lane; kk < count; kk += 64) { s_lv[gi][wv][kk] = bv; s_li[gi][wv][kk] = 0x7fffffff; }
+                    break;
                 }
-                par ^= 1;
-                ksum += bv;
-                if ((bi & 1023) == t) taken |= 1u << (bi >> 10);
+                if (lane == 0) { s_lv[gi][wv][k] = bv; s_li[gi][wv][k] = bi; }
+                if (bi != 0x7fffffff && (bi & 1023) == t) taken |= 1u << (bi >> 10);
             }
-            int dk = (int)ksum;
-            dk = dk < 1 ? 1 : (dk > Y ? Y : dk);
-            taken = invalid;
-            for (int k = 0; k < dk; ++k) {          // dk smallest costs, (value asc, index asc)
-                float bv = INFINITY; int bi = 0x7fffffff;
+        };
+        for (int g0 = 0; g0 < G; g0 += GG) {
+            const int ng = (G - g0) < GG ? (G - g0) : GG;
+            // ---- K largest IoUs per ground truth, (value desc, index asc)
+            for (int gi = 0; gi < ng; ++gi) {
+                float vio[MAXJ];
 #pragma unroll
-                for (int j = 0; j < MAXJ; ++j)
-                    if (!(taken & (1u << j)) && (vco[j] < bv || (vco[j] == bv && t + 1024 * j < bi))) { bv = vco[j]; bi = t + 1024 * j; }
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                for (int j = 0; j < MAXJ; ++j) {
+                    float co;
+                    vio[j] = -INFINITY;
+                    if (!(invalid & (1u << j))) { pair(g0 + gi, j, vio[j], co); vio[j] += 0.f; }          // -0.0 -> +0.0
                 }
-                if (lane == 0) { s_rv[par][wv] = bv; s_ri[par][wv] = bi; }
-                __syncthreads();
-                bv = s_rv[par][0]; bi = s_ri[par][0];
+                wave_list(gi, vio, K, true);
+            }
+            __syncthreads();
+            if (wv < ng) {
+                // 16 lists of K entries: a lane holds entries lane, lane + 64, ... of the 16 x K table
+                constexpr int EPL = 16 * KMAX / 64;
+                float ev[EPL]; int ei[EPL];
 #pragma unroll
-                for (int w = 1; w < 16; ++w) {
-                    const float ov = s_rv[par][w]; const int oi = s_ri[par][w];
-                    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                for (int q = 0; q < EPL; ++q) {
+                    const int e = lane + 64 * q, w = e / KMAX, k = e % KMAX;
+                    const bool ok = k < K;
+                    ev[q] = ok ? s_lv[wv][w][k] : -INFINITY;
+                    ei[q] = ok ? s_li[wv][w][k] : 0x7fffffff;
                 }
-                par ^= 1;
-                if (bi == 0x7fffffff) break;          // block-uniform
-                if ((bi & 1023) == t) {
-                    const int jj = bi >> 10;
-                    taken |= 1u << jj;
+                unsigned tk = 0;
+                float ksum = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    float bv = -INFINITY; int bi = 0x7fffffff; int bq = -1;
 #pragma unroll
-                    for (int j = 0; j < MAXJ; ++j)
-                        if (j == jj) { cnt_l[j] += 1; mgt_l[j] = g; }
+                    for (int q = 0; q < EPL; ++q)
+                        if (!(tk & (1u << q)) && (ev[q] > bv || (ev[q] == bv && ei[q] < bi))) { bv = ev[q]; bi = ei[q]; bq = q; }
+                    const int mine = bi;
+                    wave_pick(bv, bi, true);
+                    ksum += bv;
+                    if (bq >= 0 && mine == bi && bi != 0x7fffffff) tk |= 1u << bq;
+                }
+                int dk = (int)ksum;
+                dk = dk < 1 ? 1 : (dk > Y ? Y : dk);
+                if (lane == 0) s_dk[wv] = dk < KMAX ? dk : KMAX;          // dk <= K: every IoU is <= 1
+            }
+            __syncthreads();
+            // ---- dk smallest costs per ground truth, (value asc, index asc)
+            for (int gi = 0; gi < ng; ++gi) {
+                float vco[MAXJ];
+#pragma unroll
+                for (int j = 0; j < MAXJ; ++j) {
+                    float io;
+                    vco[j] = INFINITY;
+                    if (!(invalid & (1u << j))) pair(g0 + gi, j, io, vco[j]);
+                }
+                wave_list(gi, vco, s_dk[gi], false);
+            }
+            __syncthreads();
+            if (wv < ng) {
+                constexpr int EPL = 16 * KMAX / 64;
+                const int dk = s_dk[wv];
+                float ev[EPL]; int ei[EPL];
+#pragma unroll
+                for (int q = 0; q < EPL; ++q) {
+                    const int e = lane + 64 * q, w = e / KMAX, k = e % KMAX;
+                    const bool ok = k < dk;
+                    ev[q] = ok ? s_lv[wv][w][k] : INFINITY;
+                    ei[q] = ok ? s_li[wv][w][k] : 0x7fffffff;
+                }
+                unsigned tk = 0;
+                for (int k = 0; k < dk; ++k) {
+                    float bv = INFINITY; int bi = 0x7fffffff; int bq = -1;
+#pragma unroll
+                    for (int q = 0; q < EPL; ++q)
+                        if (!(tk & (1u << q)) && (ev[q] < bv || (ev[q] == bv && ei[q] < bi))) { bv = ev[q]; bi = ei[q]; bq = q; }
+                    const int mine = bi;
+                    wave_pick(bv, bi, false);
+                    if (lane == 0) s_pick[wv][k] = bi == 0x7fffffff ? -1 : bi;
+                    if (bq >= 0 && mine == bi && bi != 0x7fffffff) tk |= 1u << bq;
+                }
+            }
+            __syncthreads();
+            // ---- claims
+            for (int gi = 0; gi < ng; ++gi) {
+                const int dk = s_dk[gi];
+                for (int k = 0; k < dk; ++k) {
+                    const int bi = s_pick[gi][k];
+                    if (bi >= 0 && (bi & 1023) == t) {
+                        const int jj = bi >> 10;
+#pragma unroll
+                        for (int j = 0; j < MAXJ; ++j)
+                            if (j == jj) { cnt_l[j] += 1; mgt_l[j] = g0 + gi; }
+                    }
                 }
             }
         }
@@ -686,10 +767,13 @@ __global__ __launch_bounds__(1024) void yolox_finalize_kernel(const XK p, const 
         for (int b = 0; b < d.B; ++b) a += fc[b];
         sfg[threadIdx.x] = a;
     }
-    if (threadIdx.x == 64) {
+    if (threadIdx.x == 0) sgt = 0;
+    __syncthreads();
+    {
         int g = 0;
-        for (int i = 0; i < d.B * d.maxbox; ++i) g += targets[(size_t)i * 6 + 4] >= 0.f;
-        sgt = g;
+        for (int i = threadIdx.x; i < d.B * d.maxbox; i += 1024) g += targets[(size_t)i * 6 + 4] >= 0.f;
+        for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
+        if (lane == 0 && g) atomicAdd(&sgt, g);
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
