@@ -452,3 +452,75 @@ def test_conv_wgrad_operand_of_two_gib_is_split_over_the_batch(dev):
     for b in range(B):                      # fp64 reference image by image (bounded memory)
         ref += gy[b].reshape(-1, Cout).double().t() @ x[b].reshape(-1, Cin).double()
     _close(dw.double(), ref, 2e-3, 2e-3 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("case", ["fwd3x3s2", "fwd1x1", "dgrad3x3s2", "concat_upsample"])
+def test_conv_input_beyond_two_gib_stays_on_the_lds_dma_kernel(dev, case):
+    """An input tensor of 2 GiB or more (34 x 512 x 512 x 128 bf16 = 2.28 GB; the boundary falls on image 32) does not fit one
+    buffer descriptor: conv_v3_kernel re-bases its descriptors at every tile.  The result must be bit-identical to the same
+    layer run on short slices of the batch (same kernel, whole tensor < 2 GiB) at the start, across the boundary and at the end."""
+    from yoloseries_amd import hipk
+    B, H, W = 34, 512, 512
+    g = torch.Generator().manual_seed(61)
+
+    def rnd(*shape):          # cheap on-device noise in bf16 range (the values only have to differ everywhere)
+        t = torch.empty(*shape, dtype=torch.bfloat16, device=dev)
+        t.uniform_(-1.0, 1.0)
+        return t
+
+    torch.manual_seed(62)
+    if case == "dgrad3x3s2":
+        Cin, Cout, k, s, p = 64, 512, 3, 2, 1
+        Ho, Wo = H // 2, W // 2
+        big = [rnd(B, Ho, Wo, Cout)]                                   # gy: 34 x 256 x 256 x 512 = 2.28 GB
+        w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cout * k * k) ** 0.5).to(torch.bfloat16).float().to(dev)
+        wp = hipk.pack_weight_dgrad(w)
+
+        def run(ins, nb):
+            out = torch.zeros(nb, H, W, Cin, dtype=torch.bfloat16, device=dev)
+            d = hipk.conv_desc([hipk.full(ins[0])], hipk.YH_CONV_DGRAD, nb, H, W, Ho, Wo, k, s, p, wp, Cin, hipk.full(out))
+            d.algo = 3
+            return d, out
+    else:
+        k, s, p = {"fwd3x3s2": (3, 2, 1), "fwd1x1": (1, 1, 0), "concat_upsample": (1, 1, 0)}[case]
+        Cout = 128
+        big = [rnd(B, H, W, 128)]
+        if case == "concat_upsample":
+            big = [rnd(B, H // 2, W // 2, 64), big[0]]                 # first segment read through the nearest-2x upsample
+        Cin = sum(t.shape[-1] for t in big)
+        w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(torch.bfloat16).float().to(dev)
+        wp = hipk.pack_weight_fwd(w)
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+
+        def run(ins, nb):
+            out = torch.zeros(nb, Ho, Wo, Cout, dtype=torch.bfloat16, device=dev)
+            segs = [hipk.full(t) for t in ins]
+            if case == "concat_upsample":
+                segs[0].ups = 1
+            d = hipk.conv_desc(segs, hipk.YH_CONV_FWD, nb, Ho, Wo, H, W, k, s, p, wp, Cout, hipk.full(out))
+            d.algo = 3
+            return d, out
+    assert big[-1].numel() * 2 >= 2 ** 31
+    d, out = run(big, B)
+    assert "conv_v3_kernel" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    assert out.float().abs().sum().item() > 0
+    for lo, hi in ((0, 2), (30, 34), (15, 17)):
+        ds, outs = run([t[lo:hi].contiguous() for t in big], hi - lo)
+        assert _kname(ds) == _kname(d)
+        hipk.conv_launch(ds)
+        torch.cuda.synchronize()
+        assert torch.equal(outs, out[lo:hi]), (case, lo, hi)
+    # one image against torch (fp32 reference of the same bf16 operands)
+    i = 32
+    if case == "dgrad3x3s2":
+        x = torch.zeros(1, Cin, H, W, device=dev, requires_grad=True)
+        (ref,) = torch.autograd.grad(F.conv2d(x, w, stride=s, padding=p), x, _nchw(big[0][i:i + 1].float()))
+        ref = ref.permute(0, 2, 3, 1)
+    else:
+        xs = [t[i:i + 1].float() for t in big]
+        if case == "concat_upsample":
+            xs[0] = xs[0].repeat_interleave(2, 1).repeat_interleave(2, 2)
+        ref = F.conv2d(_nchw(torch.cat(xs, -1)), w, None, stride=s, padding=p).permute(0, 2, 3, 1)
+    _close(out[i:i + 1], ref, 1e-2, 4e-2)

@@ -34,6 +34,11 @@ else:
               ("s3_b_3x3", 80, 320, 320, 3, 1), ("s3_cba12", 80, 640, 640, 1, 1), ("s4_conv", 80, 640, 1280, 3, 2),
               ("s4_b_3x3", 40, 640, 640, 3, 1)]
 
+B = int(os.environ.get("BA_BATCH", B))                       # BA_BATCH / BA_ONLY: another batch size / only these shapes
+if os.environ.get("BA_ONLY"):
+    shapes = [sh for sh in shapes if sh[0] in os.environ["BA_ONLY"].split(",")]
+
+
 def kname(d):
     buf = C.create_string_buffer(96)
     lib().yh_conv_kernel_name(C.byref(d), buf, 96)

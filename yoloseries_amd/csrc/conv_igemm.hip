@@ -38,6 +38,7 @@ struct ConvK {
     int fast;      // every input segment has a multiple of 32 channels: tap-major incremental loader
     int v2;        // lean buffer-load kernel eligible
     unsigned segbytes[2], wbytes;   // addressable bytes from seg[i].ptr / w (hardware range check zero-fills beyond)
+    unsigned long segbytes64[2];    // the same, unclamped: conv_v3_kernel re-bases its input descriptors at every tile
     int pointwise; // 1x1 / stride 1 / no upsample: input pixel == output pixel
     int dbg;       // YH_CONV_DBG kernel-selection switches for A/B timing: 16 generic kernel instead of v2, 64 32-channel
                    // k-steps only, 256 no stem kernel (the ablation masks are compile-time: make ablate ABL=mask)
@@ -896,10 +897,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
     const int C0 = d.seg[0].C;
     const int mtiles = (p.M + BMT - 1) / BMT;
 
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg[0].ptr, 0, p.segbytes[0], 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d.nseg > 1 ? d.seg[1].ptr : d.seg[0].ptr), 0,
-                                                                          d.nseg > 1 ? p.segbytes[1] : p.segbytes[0], 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, p.wbytes, 0x00020000);
+    // Input descriptors are re-based at every tile (to the first pixel row of a pointwise tile, else to the first image the
+    // tile touches), so the 32-bit lane offsets stay tile-relative and an input tensor may be larger than the 2 GiB one
+    // descriptor can address (the host checks that the images one tile spans fit: conv_v3_span_ok).
+    const unsigned long pimg0 = (unsigned long)(d.Hi >> d.seg[0].ups) * (d.Wi >> d.seg[0].ups) * (unsigned long)(d.seg[0].ld * 2);
+    const unsigned long pimg1 = (unsigned long)(d.Hi >> d.seg[1].ups) * (d.Wi >> d.seg[1].ups) * (unsigned long)(d.seg[1].ld * 2);
+    auto rebased = [](const void* ptr, unsigned long off, unsigned long total) {
+        const unsigned long rem = total - off;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(ptr) + off), 0,
+                                                 rem > 0x7fffffffUL ? 0x7fffffffu : (unsigned)rem, 0x00020000);
+    };
 
     // loader geometry: instruction i of this wave fills tile rows (i*NWV + wave)*RPI .. +RPI; this lane's row / chunk
     const int lrow = lane / CHR, lq = lane % CHR;
@@ -935,7 +943,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
 
     for (int mt = blockIdx.x + gridDim.x * zslot; mt < mtiles; mt += gridDim.x * zslots) {
         const int m0 = mt * BMT;
-        int hb[NA], wb[NA], img[NA];
+        const int im0 = p.pointwise ? 0 : m0 / (p.cls ? HcWc : HoWo);          // first image of the tile
+        const unsigned long off0 = p.pointwise ? (unsigned long)m0 * (unsigned long)(d.seg[0].ld * 2) : (unsigned long)im0 * pimg0;
+        const unsigned long off1 = p.pointwise ? (unsigned long)m0 * (unsigned long)(d.seg[1].ld * 2) : (unsigned long)im0 * pimg1;
+        const __amdgpu_buffer_rsrc_t rs0 = rebased(d.seg[0].ptr, off0, p.segbytes64[0]);
+        const __amdgpu_buffer_rsrc_t rs1 = rebased(d.seg[1].ptr, off1, p.segbytes64[1]);
+        int hb[NA], wb[NA], img[NA];          // img: relative to im0
         unsigned voff0[NA], voff1[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -945,8 +958,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
             img[i] = 0; hb[i] = -(1 << 28); wb[i] = -(1 << 28);
             if (m < p.M) {
                 if (p.pointwise) {
-                    voff0[i] = (unsigned)m * (unsigned)(d.seg[0].ld * 2) + chA[i];
-                    voff1[i] = (unsigned)m * (unsigned)(d.seg[1].ld * 2) + chA[i];
+                    voff0[i] = (unsigned)row * (unsigned)(d.seg[0].ld * 2) + chA[i];
+                    voff1[i] = (unsigned)row * (unsigned)(d.seg[1].ld * 2) + chA[i];
                 } else {
                     int im, ho, wo;
                     if (p.cls) {
@@ -960,7 +973,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
                         ho = rem / d.Wo;
                         wo = rem - ho * d.Wo;
                     }
-                    img[i] = im; hb[i] = ho * p.sa + p.sc; wb[i] = wo * p.sa + p.sc;
+                    img[i] = im - im0; hb[i] = ho * p.sa + p.sc; wb[i] = wo * p.sa + p.sc;
                     if (p.cls && lq == 0) sPix[row] = (im * d.Ho + ho) * d.Wo + wo;
                 }
             }
@@ -2189,17 +2202,28 @@ constexpr size_t conv_smem_bytes() {
 }
 
 // can this descriptor run on the buffer-load kernel (conv_v2_kernel)?  Shared by the grid planner and the launcher.
-bool conv_v2_ok(const yh_conv_desc* d)
+// `rebased`: the caller re-bases its input descriptors at every tile of <= 256 output rows (conv_v3_kernel), so only the images
+// one tile spans have to fit the 2 GiB a descriptor addresses; otherwise the whole segment has to.
+static bool conv_buf_ok(const yh_conv_desc* d, bool rebased)
 {
     if (d->nseg < 1 || d->nseg > 2) return false;
     if (conv_dbg_mask() & 16) return false;
     if (d->nseg > 1 && d->seg[0].C % 32) return false;                 // a first concat segment must end on a 32-channel block
-    if ((long)d->B * d->Hi * d->Wi >= (1L << 31)) return false;
+    if ((long)d->B * d->Hi * d->Wi >= (1L << 31) || (long)d->B * d->Ho * d->Wo >= (1L << 31)) return false;
     int Ctot = 0;
     for (int s2 = 0; s2 < d->nseg; ++s2) {
         const yh_seg& g = d->seg[s2];
         const unsigned long npix = (unsigned long)d->B * (d->Hi >> g.ups) * (d->Wi >> g.ups);
-        if (((npix - 1) * g.ld + g.C) * 2 >= (1ul << 31)) return false;  // buffer descriptors address < 2 GiB
+        if (!rebased) {
+            if (((npix - 1) * g.ld + g.C) * 2 >= (1ul << 31)) return false;  // buffer descriptors address < 2 GiB
+        } else {
+            // a tile of 256 rows starts in image im0 and ends at most 256 / (rows per image) + 1 images later; the rows per
+            // image are Ho*Wo, or a quarter of that for the parity classes of a stride-2 data gradient
+            const unsigned long rows_img = (unsigned long)(d->Ho / 2 > 0 ? d->Ho / 2 : 1) * (d->Wo / 2 > 0 ? d->Wo / 2 : 1);
+            const unsigned long span = 256 / rows_img + 2;
+            const unsigned long pimg = (unsigned long)(d->Hi >> g.ups) * (d->Wi >> g.ups) * g.ld * 2;
+            if (span * pimg + 256ul * g.ld * 2 >= (1ul << 31)) return false;
+        }
         Ctot += g.C;
     }
     if ((unsigned long)d->Npad * d->KH * d->KW * Ctot * 2 >= (1ul << 31)) return false;
@@ -2207,6 +2231,7 @@ bool conv_v2_ok(const yh_conv_desc* d)
     if (generic && d->stats) return false;                                // statistics of an affine / activated output
     return true;
 }
+bool conv_v2_ok(const yh_conv_desc* d) { return conv_buf_ok(d, false); }
 
 // output-channel tile (a 96-wide tile for the v5m / v5x widths was measured: +2 % on v5m training, -3 % on v5x inference)
 int pick_bn(int N) { return N <= 32 ? 32 : (N <= 64 ? 64 : 128); }
@@ -2227,7 +2252,7 @@ int conv_v3_bkt(const yh_conv_desc* d);
 // 2 = 128 x 128 (4 waves), 3 = 128 x 64 (4 waves).  d->algo: 0 library default, 1 force v2, 2..4 = variant 1..3 when eligible.
 int conv_v3_variant(const yh_conv_desc* d)
 {
-    if (d->algo == 1 || d->algo == 5 || d->algo == 6 || stem_eligible(d) || !conv_v2_ok(d)) return 0;
+    if (d->algo == 1 || d->algo == 5 || d->algo == 6 || stem_eligible(d) || !conv_buf_ok(d, true)) return 0;
     if (conv_dbg_mask() & 512) return 0;
     if (conv_v3_bkt(d) == 0) return 0;
     if (d->N <= 32) return 0;
@@ -2445,16 +2470,18 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     k.v2 = conv_v2_ok(d) ? 1 : 0;
     k.pointwise = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !k.cls) ? 1 : 0;
     for (int s2 = 0; s2 < 2; ++s2) {
-        k.segbytes[s2] = 0;
+        k.segbytes[s2] = 0; k.segbytes64[s2] = 0;
         if (s2 < d->nseg) {
             const yh_seg& g = d->seg[s2];
             if (g.ups) k.pointwise = 0;
             const unsigned long npix = (unsigned long)d->B * (d->Hi >> g.ups) * (d->Wi >> g.ups);
             const unsigned long bytes = ((npix - 1) * g.ld + g.C) * 2;
             if (bytes >= (1ul << 31)) k.v2 = 0;
-            k.segbytes[s2] = (unsigned)bytes;
+            k.segbytes[s2] = bytes >= (1ul << 31) ? 0x7fffffffu : (unsigned)bytes;          // only read where k.v2 / halo hold
+            k.segbytes64[s2] = bytes;
         }
     }
+    if (d->nseg == 1) k.segbytes64[1] = k.segbytes64[0];
     {
         const unsigned long wb = (unsigned long)d->Npad * k.Ktot * 2;
         if (wb >= (1ul << 31)) k.v2 = 0;
@@ -2483,7 +2510,7 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (ragged && !k.v2) k.fast = 0;              // the generic kernel's fast loader needs whole 32-channel blocks
     if (d->bnr_part) {
         const bool generic_na = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || k.d.nsplit < d->N;
-        YH_CHECK_ARG(k.v2 && !generic_na && !d->stats && d->mode == YH_CONV_DGRAD && !stem_eligible(d),
+        YH_CHECK_ARG((k.v2 || v3) && !generic_na && !d->stats && d->mode == YH_CONV_DGRAD && !stem_eligible(d),
                      "yh_conv_igemm: the fused BatchNorm-backward reduction needs the plain buffer-load data-gradient path");
         YH_CHECK_ARG(d->bnr_z && yh_aligned16(d->bnr_z) && d->bnr_ldz % 8 == 0 && d->bnr_ws && d->bnr_C >= d->N && d->N % 8 == 0,
                      "yh_conv_igemm: bad fused-reduction operands");
@@ -2539,8 +2566,7 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         return YH_OK;
     }
     if (v3) {
-        YH_CHECK_ARG(k.v2, "yh_conv_igemm: the LDS-DMA kernel needs the buffer-load path");
-        const int bkt3 = conv_v3_bkt(d);
+        const int bkt3 = conv_v3_bkt(d);          // conv_v3_variant already checked the addressing (conv_buf_ok, re-based)
         const bool tl3 = bkt3 == 64 && (k.Ctot % 64) != 0;
         const int epi = d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0));
         const int bmt = v3 == 1 ? 256 : 128;
