@@ -193,6 +193,25 @@ int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy,
                          const float* ws, const float* gamma, const float* coef,
                          int C, int64_t M, yh_bf16* gy, int ldgy,
                          yh_bf16* gres, int ldgres, int gres_accumulate, yh_stream stream);
+/* Stacked ConvBnAct layers — ONE convolution whose output channels belong to several BatchNorm + SiLU modules (C3 runs
+ * cba1 and cba2 on the same input: utils/layer_tools.py:106-114, stacked into one GEMM here): the apply passes of all parts
+ * as one launch over whole rows of y.  Part i covers the columns [C_0 + .. + C_{i-1}, + C_i) of y (and of gy in the backward).
+ * Forward fields: ws, C, out, ldo.  Backward fields: ws, C, ga, ldga, gamma, coef (as in yh_bn_silu_bwd_apply).  No residual. */
+#define YH_BN_MAX_PARTS 4
+typedef struct yh_bn_part {
+    const float*   ws;       /* [4*C] scale | shift | mean | invstd of this part (yh_bn_finalize)              */
+    int32_t        C;        /* channels of the part, multiple of 8                                            */
+    int32_t        ldo;      /* forward: row pitch of out                                                      */
+    yh_bf16*       out;      /* forward: activation of this part (its own tensor / slice)                      */
+    const yh_bf16* ga;       /* backward: gradient w.r.t. this part's activation                               */
+    int32_t        ldga;
+    int32_t        _pad;
+    const float*   gamma;    /* backward: BatchNorm weight of the part                                         */
+    const float*   coef;     /* backward: [2*C] from yh_bn_bwd_finalize                                        */
+} yh_bn_part;
+int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts, yh_stream stream);
+int yh_bn_silu_bwd_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts,
+                               yh_bf16* gy, int ldgy, yh_stream stream);
 /* column sums of a bf16 matrix (bias gradient of Detect): out[c] += sum_m g[m][c] */
 int yh_colsum(const yh_bf16* g, int ldg, int C, int64_t M, float* part, float* out, yh_stream stream);
 

@@ -78,6 +78,54 @@ def test_bn_silu_fwd_bwd(dev, C, M):
     _close(gres, gres0.float() + ga.float(), 8e-3, 1e-2)
 
 
+@pytest.mark.parametrize("Cs,M", [((32, 32), 4096 + 17), ((64, 40, 24), 1000), ((128, 128), 777), ((8, 16, 8, 32), 333)])
+def test_bn_silu_passes_of_a_stacked_layer_in_one_launch(dev, Cs, M):
+    """yh_bn_silu_apply_parts / yh_bn_silu_bwd_apply_parts (one pass over whole rows of a stacked ConvBnAct output) are
+    bit-identical to the per-part passes: same constants, same arithmetic, different traversal."""
+    from yoloseries_amd import hipk
+    Ct = sum(Cs)
+    ybuf = _rand_bf16((M, Ct + 16), dev, 11, 2.0)
+    y = hipk.Slice(ybuf, 8, Ct)
+    g = torch.Generator().manual_seed(12)
+    fwd_parts, bwd_parts, ref_out, ref_gy = [], [], [], torch.zeros(M, Ct, dtype=torch.bfloat16, device=dev)
+    gy = torch.full((M, Ct + 8), 3.0, dtype=torch.bfloat16, device=dev)
+    c0 = 0
+    for i, C in enumerate(Cs):
+        yp = hipk.Slice(ybuf, 8 + c0, C)
+        yv = ybuf[:, 8 + c0:8 + c0 + C].float()
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+        stats = torch.zeros(1, 2, C, device=dev)
+        stats[0, 0], stats[0, 1] = yv.sum(0), (yv ** 2).sum(0)
+        ws = torch.zeros(4 * C, device=dev)
+        hipk.bn_finalize(stats, 1, C, C, M, gamma, beta, torch.zeros(C, device=dev), torch.ones(C, device=dev),
+                         torch.zeros(1, dtype=torch.int64, device=dev), 1e-3, 0.03, ws)
+        # forward: every part has its own destination (a slice of a wider tensor)
+        obuf = torch.full((M, C + 8 * (i + 1)), 5.0, dtype=torch.bfloat16, device=dev)
+        o_ref = torch.zeros(M, C, dtype=torch.bfloat16, device=dev)
+        hipk.bn_silu_apply(yp, ws, M, hipk.full(o_ref))
+        ref_out.append((obuf, o_ref))
+        fwd_parts.append(dict(ws=ws, C=C, out=hipk.Slice(obuf, 8, C)))
+        # backward: own incoming gradient, shared gz buffer
+        ga = _rand_bf16((M, C + 8), dev, 20 + i)
+        gas = hipk.Slice(ga, 0, C)
+        nblk = hipk.ew_blocks(M)
+        part = torch.zeros(nblk, 2, C, device=dev)
+        hipk.bn_silu_bwd_reduce(gas, yp, ws, M, part)
+        dgamma, dbeta, coef = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(2 * C, device=dev)
+        hipk.bn_bwd_finalize(part, nblk, C, M, ws, dgamma, dbeta, coef)
+        hipk.bn_silu_bwd_apply(gas, yp, ws, gamma, coef, M, hipk.Slice(ref_gy, c0, C))
+        bwd_parts.append(dict(ws=ws, C=C, ga=gas, gamma=gamma, coef=coef))
+        c0 += C
+    hipk.bn_silu_apply_parts(y, M, fwd_parts)
+    hipk.bn_silu_bwd_apply_parts(y, M, bwd_parts, hipk.Slice(gy, 0, Ct))
+    torch.cuda.synchronize()
+    for (obuf, o_ref), C in zip(ref_out, Cs):
+        assert torch.equal(obuf[:, 8:8 + C], o_ref)
+        assert (obuf[:, :8] == 5.0).all() and (obuf[:, 8 + C:] == 5.0).all()          # nothing outside the slice
+    assert torch.equal(gy[:, :Ct], ref_gy) and (gy[:, Ct:] == 3.0).all()
+    assert ref_gy.float().abs().sum().item() > 0
+
+
 def test_bn_fold_and_colsum(dev):
     from yoloseries_amd import hipk
     C, M = 264, 5000

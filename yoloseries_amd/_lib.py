@@ -97,6 +97,13 @@ class BnFoldItem(C.Structure):
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("eps", C.c_float), ("C", C.c_int32)]
 
 
+class BnPart(C.Structure):
+    """yh_bn_part: one BatchNorm of a stacked ConvBnAct layer for yh_bn_silu_apply_parts / yh_bn_silu_bwd_apply_parts"""
+    _fields_ = [("ws", C.c_void_p), ("C", C.c_int32), ("ldo", C.c_int32), ("out", C.c_void_p), ("ga", C.c_void_p),
+                ("ldga", C.c_int32), ("_pad", C.c_int32), ("gamma", C.c_void_p), ("coef", C.c_void_p)]
+
+
+YH_BN_MAX_PARTS = 4
 YH_CMD_SLOTS, YH_CMD_EVENT_RECORD, YH_CMD_STREAM_WAIT = 16, -1, -2
 
 
@@ -133,6 +140,8 @@ _SIGS = {
     "yh_ew_blocks": (_i32, [_i64]),
     "yh_bn_silu_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp]),
     "yh_bn_bwd_finalize": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "yh_bn_silu_apply_parts": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp]),
+    "yh_bn_silu_bwd_apply_parts": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
     "yh_bn_silu_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _vp]),
     "yh_colsum": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp]),
     "yh_maxpool5_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),

@@ -152,6 +152,49 @@ __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, co
     }
 }
 
+// Stacked ConvBnAct layers (one conv, several BatchNorms over consecutive channel ranges of its output: C3's cba1 | cba2): ONE pass
+// over the whole rows of y instead of one per part (a part's slice is half a row: 64-byte pieces of 128-byte lines).  A thread's
+// 8 channels lie in one part; it picks that part's constants and destination once.
+static_assert(sizeof(yh_bn_part) == 56, "yh_bn_part layout is part of the C ABI (yoloseries_amd/_lib.py: BnPart)");
+struct PartsK { yh_bn_part p[YH_BN_MAX_PARTS]; int cend[YH_BN_MAX_PARTS]; int n; };
+
+__device__ __forceinline__ int part_of(const PartsK& P, int c, int& c_in)
+{
+    int k = 0, c0 = 0;
+#pragma unroll
+    for (int i = 0; i < YH_BN_MAX_PARTS - 1; ++i)
+        if (i + 1 < P.n && c >= P.cend[i]) { k = i + 1; c0 = P.cend[i]; }
+    c_in = c - c0;
+    return k;
+}
+
+__global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M)
+{
+    const long T = (long)gridDim.x * blockDim.x;
+    const long rstep = T / cpr;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rstep * cpr) return;
+    long m = gid / cpr;
+    const int c = (int)(gid - m * cpr) * 8;
+    int cp;
+    const int k = part_of(P, c, cp);
+    const float* __restrict__ ws = P.p[k].ws;
+    const int Cp = P.p[k].C;
+    uint16_t* __restrict__ out = P.p[k].out + cp;
+    const int ldo = P.p[k].ldo;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = ws[cp + e]; sh[e] = ws[Cp + cp + e]; }
+    for (; m < M; m += rstep) {
+        uint4 v = *reinterpret_cast<const uint4*>(y + m * ldy + c);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e] * sc[e] + sh[e]);
+        *reinterpret_cast<uint4*>(out + m * ldo) = pack8(f);
+    }
+}
+
 // The same pass fed by int64 fixed-point accumulators (yh_conv_desc.acc_rows): every block first reduces the few accumulator rows
 // for all C channels (rows * 2 * C 8-byte loads, L2 resident) into scale / shift in LDS — the former yh_bn_finalize launch; block 0
 // additionally publishes ws (scale | shift | mean | invstd) for the backward and updates the running statistics.
@@ -397,6 +440,53 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
                 *reinterpret_cast<uint4*>(dst) = gv;
             }
         }
+    }
+}
+
+// bn_silu_bwd_apply over all parts of a stacked layer in one pass (see bn_silu_apply_parts_kernel): a part brings its own incoming
+// gradient tensor; gz of all parts is one buffer.
+__global__ void bn_silu_bwd_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M,
+                                               uint16_t* __restrict__ gy, int ldgy)
+{
+    const long T = (long)gridDim.x * blockDim.x;
+    const long rstep = T / cpr;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rstep * cpr) return;
+    long m = gid / cpr;
+    const int c = (int)(gid - m * cpr) * 8;
+    int cp;
+    const int k = part_of(P, c, cp);
+    const float* __restrict__ ws = P.p[k].ws;
+    const float* __restrict__ gamma = P.p[k].gamma;
+    const float* __restrict__ coef = P.p[k].coef;
+    const int Cp = P.p[k].C;
+    const uint16_t* __restrict__ ga = P.p[k].ga + cp;
+    const int ldga = P.p[k].ldga;
+    float sc[8], sh[8], A[8], Bc[8], D[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = ws[cp + e]; sh[e] = ws[Cp + cp + e];
+        const float mu = ws[2 * Cp + cp + e], is = ws[3 * Cp + cp + e];
+        const float gi = gamma[cp + e] * is;
+        const float c1 = coef[cp + e], c2 = coef[Cp + cp + e];
+        A[e] = gi;
+        Bc[e] = -gi * is * c2;
+        D[e] = gi * (mu * is * c2 - c1);
+    }
+    for (; m < M; m += rstep) {
+        uint4 gv = ld_nt(ga + m * ldga);
+        uint4 yv = ld_nt(y + m * ldy + c);
+        float g[8], yy[8], o[8];
+        unpack8(gv, g);
+        unpack8(yv, yy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float z = yy[e] * sc[e] + sh[e];
+            float sg = sigmoid_fast(z);
+            float dz = g[e] * (sg * (1.f + z * (1.f - sg)));
+            o[e] = A[e] * dz + (Bc[e] * yy[e] + D[e]);
+        }
+        *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
     }
 }
 
@@ -786,6 +876,61 @@ extern "C" int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* 
     hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        ga, ldga, y, ldy, ws, gamma, coef, C, cpr, (long)M, gy, ldgy, gres, ldgres, gres_accumulate);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply");
+    return YH_OK;
+}
+
+static int parts_pack(const char* who, const yh_bn_part* parts, int nparts, bool bwd, PartsK* P, int* Ctot)
+{
+    YH_CHECK_ARG(parts && nparts >= 1 && nparts <= YH_BN_MAX_PARTS, "%s: 1..%d parts", who, YH_BN_MAX_PARTS);
+    int c = 0;
+    for (int i = 0; i < nparts; ++i) {
+        const yh_bn_part& q = parts[i];
+        YH_CHECK_ARG(q.C > 0 && q.C % 8 == 0 && q.ws && yh_aligned16(q.ws), "%s: part %d: bad C / ws", who, i);
+        if (bwd) {
+            YH_CHECK_ARG(q.gamma && q.coef, "%s: part %d: gamma / coef missing", who, i);
+            YH_CHECK_ARG(q.ga && yh_aligned16(q.ga) && q.ldga % 8 == 0 && q.ldga >= q.C, "%s: part %d: ga null/unaligned (ld=%d C=%d)", who, i, q.ldga, q.C);
+        } else {
+            YH_CHECK_ARG(q.out && yh_aligned16(q.out) && q.ldo % 8 == 0 && q.ldo >= q.C, "%s: part %d: out null/unaligned (ld=%d C=%d)", who, i, q.ldo, q.C);
+        }
+        c += q.C;
+        P->p[i] = q;
+        P->cend[i] = c;
+    }
+    for (int i = nparts; i < YH_BN_MAX_PARTS; ++i) { P->p[i] = parts[nparts - 1]; P->cend[i] = c; }
+    P->n = nparts;
+    *Ctot = c;
+    YH_CHECK_ARG(c <= 2048, "%s: more than 2048 channels", who);
+    return YH_OK;
+}
+
+extern "C" int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts, yh_stream stream)
+{
+    PartsK P;
+    int C = 0;
+    const int rc = parts_pack("yh_bn_silu_apply_parts", parts, nparts, false, &P, &C);
+    if (rc != YH_OK) return rc;
+    YH_CHECK_ARG(M > 0, "yh_bn_silu_apply_parts: bad M");
+    YH_CHECK_SLICE("yh_bn_silu_apply_parts", y, ldy, C);
+    const int cpr = C / 8;
+    hipLaunchKernelGGL(bn_silu_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, ldy, P, cpr, (long)M);
+    YH_CHECK_LAUNCH("yh_bn_silu_apply_parts");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_silu_bwd_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts,
+                                          yh_bf16* gy, int ldgy, yh_stream stream)
+{
+    PartsK P;
+    int C = 0;
+    const int rc = parts_pack("yh_bn_silu_bwd_apply_parts", parts, nparts, true, &P, &C);
+    if (rc != YH_OK) return rc;
+    YH_CHECK_ARG(M > 0, "yh_bn_silu_bwd_apply_parts: bad M");
+    YH_CHECK_SLICE("yh_bn_silu_bwd_apply_parts", y, ldy, C);
+    YH_CHECK_SLICE("yh_bn_silu_bwd_apply_parts", gy, ldgy, C);
+    const int cpr = C / 8;
+    hipLaunchKernelGGL(bn_silu_bwd_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       y, ldy, P, cpr, (long)M, gy, ldgy);
+    YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply_parts");
     return YH_OK;
 }
 

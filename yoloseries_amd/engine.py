@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import hipk
-from ._lib import (BnFoldItem, Cmd, ConvDesc, WgradDesc, YH_CMD_EVENT_RECORD, YH_CMD_SLOTS, YH_CMD_STREAM_WAIT, YH_ACT_NONE, YH_ACT_SILU, YH_CONV_DGRAD, YH_CONV_FWD, YoloHipError, check, lib)
+from ._lib import (BnFoldItem, BnPart, Cmd, ConvDesc, YH_BN_MAX_PARTS, WgradDesc, YH_CMD_EVENT_RECORD, YH_CMD_SLOTS, YH_CMD_STREAM_WAIT, YH_ACT_NONE, YH_ACT_SILU, YH_CONV_DGRAD, YH_CONV_FWD, YoloHipError, check, lib)
 from .hipk import Slice
 
 BN_EPS_DEFAULT = 1e-3
@@ -85,6 +85,7 @@ def _tune_cache_save():
 BN_ACC = os.environ.get("YH_BN_ACC", "0") == "1"
 TUNE_ITERS = max(1, int(os.environ.get("YH_TUNE_ITERS", "3")))   # launches timed per candidate (tools/make_tune_defaults.sh: 12)
 ACC_ROWS = int(os.environ.get("YH_ACC_ROWS", "8"))
+MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct layers: one BN+SiLU pass for all parts
 NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weight gradients may lag behind by
 
 
@@ -109,7 +110,7 @@ def _slot(v):
         return 0
     if isinstance(v, float):
         return struct.unpack("<Q", struct.pack("<d", v))[0]
-    if isinstance(v, C.Structure):
+    if isinstance(v, (C.Structure, C.Array)):
         return C.addressof(v)
     return int(v) & 0xFFFFFFFFFFFFFFFF
 
@@ -665,6 +666,8 @@ class Program:
             self.cmd_train.append((L.yh_conv_igemm, (d,), op.name, self._fam_conv(op, d)))
             st['ws'] = []
             c0 = 0
+            merged = MERGE_PARTS and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and op.res is None
+            parts_arr = (BnPart * len(op.parts))() if merged else None
             for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
                 ws = torch.zeros(4 * n, dtype=torch.float32, device=self.dev)
                 st['ws'].append(ws)
@@ -675,10 +678,18 @@ class Program:
                     float(bn.eps), float(mom), ws.data_ptr()), op.name, ('yh_bn_finalize', 0, 8.0 * nblk * n)))
                 dst = op.outs[pi].sl()
                 res = op.res.sl() if (op.res is not None and pi == 0) else None
-                self.cmd_train.append((L.yh_bn_silu_apply, (
-                    op.y.t.data_ptr() + 2 * c0, op.y.C, ws.data_ptr(), n, M, dst.ptr(), dst.ld,
-                    res.ptr() if res else None, res.ld if res else 0), op.name, ('yh_bn_silu_apply', 0, (6.0 if res else 4.0) * M * n)))
+                if merged:
+                    pa = parts_arr[pi]
+                    pa.ws, pa.C, pa.out, pa.ldo = ws.data_ptr(), n, dst.ptr(), dst.ld
+                else:
+                    self.cmd_train.append((L.yh_bn_silu_apply, (
+                        op.y.t.data_ptr() + 2 * c0, op.y.C, ws.data_ptr(), n, M, dst.ptr(), dst.ld,
+                        res.ptr() if res else None, res.ld if res else 0), op.name, ('yh_bn_silu_apply', 0, (6.0 if res else 4.0) * M * n)))
                 c0 += n
+            if merged:          # one pass over the whole rows of y for all parts (yh_bn_silu_apply_parts)
+                self._keep.append(parts_arr)
+                self.cmd_train.append((L.yh_bn_silu_apply_parts, (op.y.t.data_ptr(), op.y.C, M, parts_arr, len(op.parts)), op.name,
+                                       ('yh_bn_silu_apply_parts', 0, 4.0 * M * op.N)))
 
         if BN_ACC:
             self.acc_fwd = torch.zeros(max(self._acc_fwd_elems, 2), dtype=torch.int64, device=self.dev)
@@ -889,6 +900,9 @@ class Program:
                 gy_sl = None
             else:
                 c0 = 0
+                merged = (MERGE_PARTS and not BN_ACC and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and
+                          not (op.res is not None and op.res.buf.needs_grad))
+                bwd_parts = (BnPart * len(op.parts))() if merged else None
                 for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
                     require(op.outs[pi], op.name)
                     ga = op.outs[pi].sl(True)
@@ -930,11 +944,20 @@ class Program:
                         gres_acc = claim(op.res)
                         gr = op.res.sl(True)
                         gres_ptr, gres_ld = gr.ptr(), gr.ld
-                    cmds.append((L.yh_bn_silu_bwd_apply, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), bn.weight.data_ptr(),
-                                                          coef.data_ptr(), n, M, gys.data_ptr() + 2 * c0, op.N,
-                                                          gres_ptr, gres_ld, gres_acc), op.name,
-                                 ('yh_bn_silu_bwd_apply', 0, (6.0 + (4.0 if gres_acc else 2.0) * (gres_ptr is not None)) * M * n)))
+                    if bwd_parts is not None:
+                        pa = bwd_parts[pi]
+                        pa.ws, pa.C, pa.ga, pa.ldga = ws.data_ptr(), n, ga.ptr(), ga.ld
+                        pa.gamma, pa.coef = bn.weight.data_ptr(), coef.data_ptr()
+                    else:
+                        cmds.append((L.yh_bn_silu_bwd_apply, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), bn.weight.data_ptr(),
+                                                              coef.data_ptr(), n, M, gys.data_ptr() + 2 * c0, op.N,
+                                                              gres_ptr, gres_ld, gres_acc), op.name,
+                                     ('yh_bn_silu_bwd_apply', 0, (6.0 + (4.0 if gres_acc else 2.0) * (gres_ptr is not None)) * M * n)))
                     c0 += n
+                if bwd_parts is not None:          # the parts' reductions are done: one pass writes gz of the whole stacked layer
+                    self._keep.append(bwd_parts)
+                    cmds.append((L.yh_bn_silu_bwd_apply_parts, (op.y.t.data_ptr(), op.y.C, M, bwd_parts, len(op.parts), gys.data_ptr(), op.N),
+                                 op.name, ('yh_bn_silu_bwd_apply_parts', 0, 6.0 * M * op.N)))
                 gy_ld, gyN = op.N, op.N
             # wgrad per segment (side stream: starts when gz is ready)
             cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))

@@ -149,6 +149,30 @@ def bn_silu_bwd_apply(ga: Slice, y: Slice, ws, gamma, coef, M, gy: Slice, gres: 
                                      gres_acc, _st()), "yh_bn_silu_bwd_apply")
 
 
+def _bn_parts(parts):
+    """parts: dicts with ws, C and (forward) out: Slice or (backward) ga: Slice, gamma, coef"""
+    from ._lib import BnPart
+    arr = (BnPart * len(parts))()
+    for a, q in zip(arr, parts):
+        a.ws, a.C = q["ws"].data_ptr(), q["C"]
+        if "out" in q:
+            a.out, a.ldo = q["out"].ptr(), q["out"].ld
+        if "ga" in q:
+            a.ga, a.ldga = q["ga"].ptr(), q["ga"].ld
+            a.gamma, a.coef = q["gamma"].data_ptr(), q["coef"].data_ptr()
+    return arr
+
+
+def bn_silu_apply_parts(y: Slice, M, parts):
+    arr = _bn_parts(parts)
+    check(lib().yh_bn_silu_apply_parts(y.ptr(), y.ld, M, arr, len(parts), _st()), "yh_bn_silu_apply_parts")
+
+
+def bn_silu_bwd_apply_parts(y: Slice, M, parts, gy: Slice):
+    arr = _bn_parts(parts)
+    check(lib().yh_bn_silu_bwd_apply_parts(y.ptr(), y.ld, M, arr, len(parts), gy.ptr(), gy.ld, _st()), "yh_bn_silu_bwd_apply_parts")
+
+
 def colsum(g: Slice, M, part, out):
     check(lib().yh_colsum(g.ptr(), g.ld, g.C, M, _p(part), _p(out), _st()), "yh_colsum")
 
