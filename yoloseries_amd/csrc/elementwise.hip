@@ -584,16 +584,27 @@ __global__ void maxpool5_fwd_kernel(const uint16_t* __restrict__ x, int ldx, int
         int bi[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+        // a window row's five loads are issued together from clamped addresses (the pass is latency bound: 25 dependent round
+        // trips otherwise); positions outside the image are skipped when comparing.  Scan order (i, j) as before: first maximum wins.
         bool any = false;
+#pragma unroll
         for (int i = 0; i < 5; ++i) {
-            int hh = h - 2 + i;
-            if (hh < 0 || hh >= H) continue;
+            const int hh = h - 2 + i;
+            const bool rok = hh >= 0 && hh < H;
+            const int hc = hh < 0 ? 0 : (hh >= H ? H - 1 : hh);
+            uint4 v[5];
+#pragma unroll
             for (int j = 0; j < 5; ++j) {
-                int ww = w - 2 + j;
-                if (ww < 0 || ww >= W) continue;
-                uint4 v = *reinterpret_cast<const uint4*>(x + ((b * H + hh) * W + ww) * ldx + c);
+                const int ww = w - 2 + j;
+                const int wc = ww < 0 ? 0 : (ww >= W ? W - 1 : ww);
+                v[j] = *reinterpret_cast<const uint4*>(x + ((b * H + hc) * W + wc) * ldx + c);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int ww = w - 2 + j;
+                if (!(rok && ww >= 0 && ww < W)) continue;
                 float f[8];
-                unpack8(v, f);
+                unpack8(v[j], f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (!any || f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; bi[e] = i * 5 + j; }
@@ -626,21 +637,31 @@ __global__ void maxpool5_bwd_kernel(const uint16_t* __restrict__ gout, int ldgo,
         float s[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = 0.f;
-        for (int i = 0; i < 5; ++i) {
-            int oh = h + 2 - i;
-            if (oh < 0 || oh >= H) continue;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {          // the five (index, gradient) pairs of a row in flight together, see the forward
+            const int oh = h + 2 - i;
+            const bool rok = oh >= 0 && oh < H;
+            const int hc = oh < 0 ? 0 : (oh >= H ? H - 1 : oh);
+            uint2 pk[5];
+            uint4 gv[5];
+#pragma unroll
             for (int j = 0; j < 5; ++j) {
-                int ow = w + 2 - j;
-                if (ow < 0 || ow >= W) continue;
-                long op = (b * H + oh) * W + ow;
-                uint2 pk = *reinterpret_cast<const uint2*>(idx + op * C + c);
-                uint4 gv = *reinterpret_cast<const uint4*>(gout + op * ldgo + c);
+                const int ow = w + 2 - j;
+                const int wc = ow < 0 ? 0 : (ow >= W ? W - 1 : ow);
+                const long op = (b * H + hc) * W + wc;
+                pk[j] = *reinterpret_cast<const uint2*>(idx + op * C + c);
+                gv[j] = *reinterpret_cast<const uint4*>(gout + op * ldgo + c);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int ow = w + 2 - j;
+                if (!(rok && ow >= 0 && ow < W)) continue;
                 float g[8];
-                unpack8(gv, g);
+                unpack8(gv[j], g);
                 const int want = i * 5 + j;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    int k = (int)(((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xff);
+                    int k = (int)(((e < 4 ? pk[j].x : pk[j].y) >> (8 * (e & 3))) & 0xff);
                     if (k == want) s[e] += g[e];
                 }
             }
