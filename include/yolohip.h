@@ -196,19 +196,35 @@ int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy,
 /* Stacked ConvBnAct layers — ONE convolution whose output channels belong to several BatchNorm + SiLU modules (C3 runs
  * cba1 and cba2 on the same input: utils/layer_tools.py:106-114, stacked into one GEMM here): the apply passes of all parts
  * as one launch over whole rows of y.  Part i covers the columns [C_0 + .. + C_{i-1}, + C_i) of y (and of gy in the backward).
- * Forward fields: ws, C, out, ldo.  Backward fields: ws, C, ga, ldga, gamma, coef (as in yh_bn_silu_bwd_apply).  No residual. */
+ * The passes read: forward ws, C, out, ldo; backward ws, C, ga, ldga, gamma, coef (as in yh_bn_silu_bwd_apply).  No residual. */
 #define YH_BN_MAX_PARTS 4
 typedef struct yh_bn_part {
-    const float*   ws;       /* [4*C] scale | shift | mean | invstd of this part (yh_bn_finalize)              */
+    float*         ws;       /* [4*C] scale | shift | mean | invstd of this part (written by the finalize, read by the passes) */
     int32_t        C;        /* channels of the part, multiple of 8                                            */
-    int32_t        ldo;      /* forward: row pitch of out                                                      */
-    yh_bf16*       out;      /* forward: activation of this part (its own tensor / slice)                      */
-    const yh_bf16* ga;       /* backward: gradient w.r.t. this part's activation                               */
+    int32_t        ldo;      /* forward pass: row pitch of out                                                 */
+    yh_bf16*       out;      /* forward pass: activation of this part (its own tensor / slice)                 */
+    const yh_bf16* ga;       /* backward pass: gradient w.r.t. this part's activation                          */
     int32_t        ldga;
+    int32_t        nblk;     /* finalize: rows of `slab`                                                       */
+    const float*   gamma;    /* BatchNorm weight of the part (forward finalize, backward pass)                 */
+    float*         coef;     /* [2*C]: written by the backward finalize, read by the backward pass             */
+    const float*   slab;     /* finalize: partial sums of THIS part — forward [nblk][2][ldslab] at its first channel
+                                (yh_conv_desc.stats + channel offset), backward [nblk][2][C]                   */
+    int32_t        ldslab;   /* forward finalize: row pitch of slab (Npad of the convolution)                  */
+    float          eps;
+    const float*   beta;     /* forward finalize */
+    float*         running_mean;
+    float*         running_var;
+    int64_t*       num_batches;
+    float          momentum;
     int32_t        _pad;
-    const float*   gamma;    /* backward: BatchNorm weight of the part                                         */
-    const float*   coef;     /* backward: [2*C] from yh_bn_bwd_finalize                                        */
+    float*         dgamma;   /* backward finalize */
+    float*         dbeta;
 } yh_bn_part;
+/* yh_bn_finalize / yh_bn_bwd_finalize of every part in one launch (the kernels are latency bound: a launch per part costs the
+ * same ~6 us as one for all) */
+int yh_bn_finalize_parts(const yh_bn_part* parts, int nparts, int64_t count, yh_stream stream);
+int yh_bn_bwd_finalize_parts(const yh_bn_part* parts, int nparts, int64_t M, yh_stream stream);
 int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts, yh_stream stream);
 int yh_bn_silu_bwd_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts,
                                yh_bf16* gy, int ldgy, yh_stream stream);

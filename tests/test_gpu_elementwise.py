@@ -88,6 +88,7 @@ def test_bn_silu_passes_of_a_stacked_layer_in_one_launch(dev, Cs, M):
     y = hipk.Slice(ybuf, 8, Ct)
     g = torch.Generator().manual_seed(12)
     fwd_parts, bwd_parts, ref_out, ref_gy = [], [], [], torch.zeros(M, Ct, dtype=torch.bfloat16, device=dev)
+    fin_args, bfin_args = [], []
     gy = torch.full((M, Ct + 8), 3.0, dtype=torch.bfloat16, device=dev)
     c0 = 0
     for i, C in enumerate(Cs):
@@ -97,8 +98,9 @@ def test_bn_silu_passes_of_a_stacked_layer_in_one_launch(dev, Cs, M):
         stats = torch.zeros(1, 2, C, device=dev)
         stats[0, 0], stats[0, 1] = yv.sum(0), (yv ** 2).sum(0)
         ws = torch.zeros(4 * C, device=dev)
-        hipk.bn_finalize(stats, 1, C, C, M, gamma, beta, torch.zeros(C, device=dev), torch.ones(C, device=dev),
-                         torch.zeros(1, dtype=torch.int64, device=dev), 1e-3, 0.03, ws)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        hipk.bn_finalize(stats, 1, C, C, M, gamma, beta, rm, rv, torch.zeros(1, dtype=torch.int64, device=dev), 1e-3, 0.03, ws)
+        fin_args.append(dict(C=C, stats=stats, gamma=gamma, beta=beta, ws=ws, rm=rm, rv=rv))
         # forward: every part has its own destination (a slice of a wider tensor)
         obuf = torch.full((M, C + 8 * (i + 1)), 5.0, dtype=torch.bfloat16, device=dev)
         o_ref = torch.zeros(M, C, dtype=torch.bfloat16, device=dev)
@@ -114,11 +116,28 @@ def test_bn_silu_passes_of_a_stacked_layer_in_one_launch(dev, Cs, M):
         dgamma, dbeta, coef = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(2 * C, device=dev)
         hipk.bn_bwd_finalize(part, nblk, C, M, ws, dgamma, dbeta, coef)
         hipk.bn_silu_bwd_apply(gas, yp, ws, gamma, coef, M, hipk.Slice(ref_gy, c0, C))
+        bfin_args.append(dict(part=part, nblk=nblk, dgamma=dgamma, dbeta=dbeta, coef=coef))
         bwd_parts.append(dict(ws=ws, C=C, ga=gas, gamma=gamma, coef=coef))
         c0 += C
     hipk.bn_silu_apply_parts(y, M, fwd_parts)
     hipk.bn_silu_bwd_apply_parts(y, M, bwd_parts, hipk.Slice(gy, 0, Ct))
+    # the finalize kernels of all parts in one launch: same statistics, running buffers, step counters, coefficients
+    fin, bfin, refs = [], [], []
+    for q, qb in zip(fin_args, bfin_args):
+        C = q["C"]
+        new = dict(ws=torch.zeros(4 * C, device=dev), rm=torch.zeros(C, device=dev), rv=torch.ones(C, device=dev),
+                   nbt=torch.zeros(1, dtype=torch.int64, device=dev), dgamma=torch.zeros(C, device=dev), dbeta=torch.zeros(C, device=dev),
+                   coef=torch.zeros(2 * C, device=dev))
+        refs.append((q, qb, new))
+        fin.append(dict(ws=new["ws"], C=C, slab=q["stats"].data_ptr(), nblk=1, ldslab=C, gamma=q["gamma"], beta=q["beta"],
+                        running_mean=new["rm"], running_var=new["rv"], num_batches=new["nbt"], eps=1e-3, momentum=0.03))
+        bfin.append(dict(ws=q["ws"], C=C, slab=qb["part"].data_ptr(), nblk=qb["nblk"], dgamma=new["dgamma"], dbeta=new["dbeta"], coef=new["coef"]))
+    hipk.bn_finalize_parts(fin, M)
+    hipk.bn_bwd_finalize_parts(bfin, M)
     torch.cuda.synchronize()
+    for q, qb, new in refs:
+        assert torch.equal(new["ws"], q["ws"]) and torch.equal(new["rm"], q["rm"]) and torch.equal(new["rv"], q["rv"]) and new["nbt"].item() == 1
+        assert torch.equal(new["dgamma"], qb["dgamma"]) and torch.equal(new["dbeta"], qb["dbeta"]) and torch.equal(new["coef"], qb["coef"])
     for (obuf, o_ref), C in zip(ref_out, Cs):
         assert torch.equal(obuf[:, 8:8 + C], o_ref)
         assert (obuf[:, :8] == 5.0).all() and (obuf[:, 8 + C:] == 5.0).all()          # nothing outside the slice

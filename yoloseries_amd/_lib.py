@@ -100,7 +100,10 @@ class BnFoldItem(C.Structure):
 class BnPart(C.Structure):
     """yh_bn_part: one BatchNorm of a stacked ConvBnAct layer for yh_bn_silu_apply_parts / yh_bn_silu_bwd_apply_parts"""
     _fields_ = [("ws", C.c_void_p), ("C", C.c_int32), ("ldo", C.c_int32), ("out", C.c_void_p), ("ga", C.c_void_p),
-                ("ldga", C.c_int32), ("_pad", C.c_int32), ("gamma", C.c_void_p), ("coef", C.c_void_p)]
+                ("ldga", C.c_int32), ("nblk", C.c_int32), ("gamma", C.c_void_p), ("coef", C.c_void_p),
+                ("slab", C.c_void_p), ("ldslab", C.c_int32), ("eps", C.c_float), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches", C.c_void_p),
+                ("momentum", C.c_float), ("_pad", C.c_int32), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
 
 
 YH_BN_MAX_PARTS = 4
@@ -140,6 +143,8 @@ _SIGS = {
     "yh_ew_blocks": (_i32, [_i64]),
     "yh_bn_silu_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp]),
     "yh_bn_bwd_finalize": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "yh_bn_finalize_parts": (_i32, [_vp, _i32, _i64, _vp]),
+    "yh_bn_bwd_finalize_parts": (_i32, [_vp, _i32, _i64, _vp]),
     "yh_bn_silu_apply_parts": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp]),
     "yh_bn_silu_bwd_apply_parts": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
     "yh_bn_silu_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _vp]),

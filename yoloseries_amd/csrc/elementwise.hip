@@ -69,12 +69,12 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
     }
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int ldstat, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* running_mean, float* running_var, int64_t* num_batches,
-                                   float eps, float momentum, float* ws)
+__device__ __forceinline__ void bn_finalize_body(int cb, const float* __restrict__ stats, int nblk, int ldstat, int C, double count,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float* running_mean, float* running_var, int64_t* num_batches,
+                                                 float eps, float momentum, float* ws)
 {
-    const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
+    const int c = cb * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
     double sq[2];
     slab_colsum<2>(stats, nblk, ldstat, C, c, sq);
     if (threadIdx.x >= FIN_CPB) return;
@@ -95,6 +95,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int ldstat, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, int64_t* num_batches,
+                                   float eps, float momentum, float* ws)
+{
+    bn_finalize_body(blockIdx.x, stats, nblk, ldstat, C, count, gamma, beta, running_mean, running_var, num_batches, eps, momentum, ws);
 }
 
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -155,8 +163,27 @@ __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, co
 // Stacked ConvBnAct layers (one conv, several BatchNorms over consecutive channel ranges of its output: C3's cba1 | cba2): ONE pass
 // over the whole rows of y instead of one per part (a part's slice is half a row: 64-byte pieces of 128-byte lines).  A thread's
 // 8 channels lie in one part; it picks that part's constants and destination once.
-static_assert(sizeof(yh_bn_part) == 56, "yh_bn_part layout is part of the C ABI (yoloseries_amd/_lib.py: BnPart)");
-struct PartsK { yh_bn_part p[YH_BN_MAX_PARTS]; int cend[YH_BN_MAX_PARTS]; int n; };
+static_assert(sizeof(yh_bn_part) == 128, "yh_bn_part layout is part of the C ABI (yoloseries_amd/_lib.py: BnPart)");
+struct PartsK { yh_bn_part p[YH_BN_MAX_PARTS]; int cend[YH_BN_MAX_PARTS]; int bend[YH_BN_MAX_PARTS]; int n; };   // cend: channels, bend: finalize blocks (cumulative)
+
+// part and block-within-part of a finalize block (block-uniform)
+__device__ __forceinline__ int fin_part_of(const PartsK& P, int blk, int& cb)
+{
+    int k = 0, b0 = 0;
+#pragma unroll
+    for (int i = 0; i < YH_BN_MAX_PARTS - 1; ++i)
+        if (i + 1 < P.n && blk >= P.bend[i]) { k = i + 1; b0 = P.bend[i]; }
+    cb = blk - b0;
+    return k;
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_parts_kernel(const PartsK P, double count)
+{
+    int cb;
+    const yh_bn_part& q = P.p[fin_part_of(P, blockIdx.x, cb)];
+    bn_finalize_body(cb, q.slab, q.nblk, q.ldslab, q.C, count, q.gamma, q.beta, q.running_mean, q.running_var, q.num_batches,
+                     q.eps, q.momentum, q.ws);
+}
 
 __device__ __forceinline__ int part_of(const PartsK& P, int c, int& c_in)
 {
@@ -365,10 +392,10 @@ __global__ __launch_bounds__(RED_THREADS, 4) void col_reduce_kernel(const uint16
     }
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
-                                       const float* __restrict__ ws, float* dgamma, float* dbeta, float* coef)
+__device__ __forceinline__ void bn_bwd_finalize_body(int cb, const float* __restrict__ part, int nblk, int C, double M,
+                                                     const float* __restrict__ ws, float* dgamma, float* dbeta, float* coef)
 {
-    const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
+    const int c = cb * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
     double s[2];
     slab_colsum<2>(part, nblk, C, C, c, s);
     if (threadIdx.x >= FIN_CPB || c >= C) return;
@@ -376,6 +403,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     if (dbeta) dbeta[c] = (float)s[0];
     if (dgamma) dgamma[c] = (float)s[1];
     if (coef) { coef[c] = (float)(s[0] / M); coef[C + c] = (float)(s[1] / M); }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
+                                       const float* __restrict__ ws, float* dgamma, float* dbeta, float* coef)
+{
+    bn_bwd_finalize_body(blockIdx.x, part, nblk, C, M, ws, dgamma, dbeta, coef);
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_parts_kernel(const PartsK P, double M)
+{
+    int cb;
+    const yh_bn_part& q = P.p[fin_part_of(P, blockIdx.x, cb)];
+    bn_bwd_finalize_body(cb, q.slab, q.nblk, q.C, M, q.ws, q.dgamma, q.dbeta, q.coef);
 }
 
 __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out)
@@ -900,27 +940,58 @@ extern "C" int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* 
     return YH_OK;
 }
 
-static int parts_pack(const char* who, const yh_bn_part* parts, int nparts, bool bwd, PartsK* P, int* Ctot)
+// mode: 0 forward pass, 1 backward pass, 2 forward finalize, 3 backward finalize
+static int parts_pack(const char* who, const yh_bn_part* parts, int nparts, int mode, PartsK* P, int* Ctot)
 {
     YH_CHECK_ARG(parts && nparts >= 1 && nparts <= YH_BN_MAX_PARTS, "%s: 1..%d parts", who, YH_BN_MAX_PARTS);
-    int c = 0;
+    int c = 0, nb = 0;
     for (int i = 0; i < nparts; ++i) {
         const yh_bn_part& q = parts[i];
         YH_CHECK_ARG(q.C > 0 && q.C % 8 == 0 && q.ws && yh_aligned16(q.ws), "%s: part %d: bad C / ws", who, i);
-        if (bwd) {
+        if (mode == 2) {
+            YH_CHECK_ARG(q.slab && q.nblk > 0 && q.ldslab >= q.C && q.gamma && q.beta, "%s: part %d: bad slab / gamma / beta", who, i);
+        } else if (mode == 3) {
+            YH_CHECK_ARG(q.slab && q.nblk > 0, "%s: part %d: bad slab", who, i);
+        } else if (mode == 1) {
             YH_CHECK_ARG(q.gamma && q.coef, "%s: part %d: gamma / coef missing", who, i);
             YH_CHECK_ARG(q.ga && yh_aligned16(q.ga) && q.ldga % 8 == 0 && q.ldga >= q.C, "%s: part %d: ga null/unaligned (ld=%d C=%d)", who, i, q.ldga, q.C);
         } else {
             YH_CHECK_ARG(q.out && yh_aligned16(q.out) && q.ldo % 8 == 0 && q.ldo >= q.C, "%s: part %d: out null/unaligned (ld=%d C=%d)", who, i, q.ldo, q.C);
         }
         c += q.C;
+        nb += (q.C + FIN_CPB - 1) / FIN_CPB;
         P->p[i] = q;
         P->cend[i] = c;
+        P->bend[i] = nb;
     }
-    for (int i = nparts; i < YH_BN_MAX_PARTS; ++i) { P->p[i] = parts[nparts - 1]; P->cend[i] = c; }
+    for (int i = nparts; i < YH_BN_MAX_PARTS; ++i) { P->p[i] = parts[nparts - 1]; P->cend[i] = c; P->bend[i] = nb; }
     P->n = nparts;
     *Ctot = c;
     YH_CHECK_ARG(c <= 2048, "%s: more than 2048 channels", who);
+    return YH_OK;
+}
+
+extern "C" int yh_bn_finalize_parts(const yh_bn_part* parts, int nparts, int64_t count, yh_stream stream)
+{
+    PartsK P;
+    int C = 0;
+    const int rc = parts_pack("yh_bn_finalize_parts", parts, nparts, 2, &P, &C);
+    if (rc != YH_OK) return rc;
+    YH_CHECK_ARG(count > 0, "yh_bn_finalize_parts: bad count");
+    hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(1024), 0, (hipStream_t)stream, P, (double)count);
+    YH_CHECK_LAUNCH("yh_bn_finalize_parts");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_bwd_finalize_parts(const yh_bn_part* parts, int nparts, int64_t M, yh_stream stream)
+{
+    PartsK P;
+    int C = 0;
+    const int rc = parts_pack("yh_bn_bwd_finalize_parts", parts, nparts, 3, &P, &C);
+    if (rc != YH_OK) return rc;
+    YH_CHECK_ARG(M > 0, "yh_bn_bwd_finalize_parts: bad M");
+    hipLaunchKernelGGL(bn_bwd_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(1024), 0, (hipStream_t)stream, P, (double)M);
+    YH_CHECK_LAUNCH("yh_bn_bwd_finalize_parts");
     return YH_OK;
 }
 
@@ -928,7 +999,7 @@ extern "C" int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, cons
 {
     PartsK P;
     int C = 0;
-    const int rc = parts_pack("yh_bn_silu_apply_parts", parts, nparts, false, &P, &C);
+    const int rc = parts_pack("yh_bn_silu_apply_parts", parts, nparts, 0, &P, &C);
     if (rc != YH_OK) return rc;
     YH_CHECK_ARG(M > 0, "yh_bn_silu_apply_parts: bad M");
     YH_CHECK_SLICE("yh_bn_silu_apply_parts", y, ldy, C);
@@ -943,7 +1014,7 @@ extern "C" int yh_bn_silu_bwd_apply_parts(const yh_bf16* y, int ldy, int64_t M, 
 {
     PartsK P;
     int C = 0;
-    const int rc = parts_pack("yh_bn_silu_bwd_apply_parts", parts, nparts, true, &P, &C);
+    const int rc = parts_pack("yh_bn_silu_bwd_apply_parts", parts, nparts, 1, &P, &C);
     if (rc != YH_OK) return rc;
     YH_CHECK_ARG(M > 0, "yh_bn_silu_bwd_apply_parts: bad M");
     YH_CHECK_SLICE("yh_bn_silu_bwd_apply_parts", y, ldy, C);

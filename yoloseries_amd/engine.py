@@ -672,22 +672,29 @@ class Program:
                 ws = torch.zeros(4 * n, dtype=torch.float32, device=self.dev)
                 st['ws'].append(ws)
                 mom = bn.momentum if bn.momentum is not None else 0.1
-                self.cmd_train.append((L.yh_bn_finalize, (
-                    st['stats'].data_ptr() + 4 * c0, nblk, op.Npad, n, M, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(),
-                    float(bn.eps), float(mom), ws.data_ptr()), op.name, ('yh_bn_finalize', 0, 8.0 * nblk * n)))
                 dst = op.outs[pi].sl()
                 res = op.res.sl() if (op.res is not None and pi == 0) else None
                 if merged:
                     pa = parts_arr[pi]
                     pa.ws, pa.C, pa.out, pa.ldo = ws.data_ptr(), n, dst.ptr(), dst.ld
-                else:
-                    self.cmd_train.append((L.yh_bn_silu_apply, (
-                        op.y.t.data_ptr() + 2 * c0, op.y.C, ws.data_ptr(), n, M, dst.ptr(), dst.ld,
-                        res.ptr() if res else None, res.ld if res else 0), op.name, ('yh_bn_silu_apply', 0, (6.0 if res else 4.0) * M * n)))
+                    pa.slab, pa.nblk, pa.ldslab = st['stats'].data_ptr() + 4 * c0, nblk, op.Npad
+                    pa.gamma, pa.beta, pa.eps, pa.momentum = bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(mom)
+                    pa.running_mean, pa.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                    pa.num_batches = bn.num_batches_tracked.data_ptr()
+                    c0 += n
+                    continue
+                self.cmd_train.append((L.yh_bn_finalize, (
+                    st['stats'].data_ptr() + 4 * c0, nblk, op.Npad, n, M, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(),
+                    float(bn.eps), float(mom), ws.data_ptr()), op.name, ('yh_bn_finalize', 0, 8.0 * nblk * n)))
+                self.cmd_train.append((L.yh_bn_silu_apply, (
+                    op.y.t.data_ptr() + 2 * c0, op.y.C, ws.data_ptr(), n, M, dst.ptr(), dst.ld,
+                    res.ptr() if res else None, res.ld if res else 0), op.name, ('yh_bn_silu_apply', 0, (6.0 if res else 4.0) * M * n)))
                 c0 += n
-            if merged:          # one pass over the whole rows of y for all parts (yh_bn_silu_apply_parts)
+            if merged:          # one finalize launch and one pass over the whole rows of y for all parts
                 self._keep.append(parts_arr)
+                self.cmd_train.append((L.yh_bn_finalize_parts, (parts_arr, len(op.parts), M), op.name,
+                                       ('yh_bn_finalize', 0, 8.0 * nblk * op.N)))
                 self.cmd_train.append((L.yh_bn_silu_apply_parts, (op.y.t.data_ptr(), op.y.C, M, parts_arr, len(op.parts)), op.name,
                                        ('yh_bn_silu_apply_parts', 0, 4.0 * M * op.N)))
 
@@ -903,6 +910,7 @@ class Program:
                 merged = (MERGE_PARTS and not BN_ACC and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and
                           not (op.res is not None and op.res.buf.needs_grad))
                 bwd_parts = (BnPart * len(op.parts))() if merged else None
+                scratch_off = 0
                 for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
                     require(op.outs[pi], op.name)
                     ga = op.outs[pi].sl(True)
@@ -933,12 +941,21 @@ class Program:
                     if fused is not None:          # the consumer's data gradient already left the partial sums in its own slab
                         part_ptr, nblk = fused[0].data_ptr(), fused[1]
                     else:
+                        if bwd_parts is not None:  # the merged finalize reads every part's rows: they may not share the scratch slab
+                            part_ptr += 4 * scratch_off
+                            scratch_off += nblk * 2 * n
+                            assert scratch_off <= self.part_scratch.numel()
                         cmds.append((L.yh_bn_silu_bwd_reduce, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), n, M,
                                                                part_ptr), op.name, ('yh_bn_silu_bwd_reduce', 0, 4.0 * M * n)))
                     goff, boff = pk.bn_g[(op.name, pi)]
-                    cmds.append((L.yh_bn_bwd_finalize, (part_ptr, nblk, n, M, ws.data_ptr(),
-                                                        pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
-                                                        coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0, 8.0 * nblk * n)))
+                    if bwd_parts is not None:
+                        pa = bwd_parts[pi]
+                        pa.slab, pa.nblk = part_ptr, nblk
+                        pa.dgamma, pa.dbeta = pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff
+                    else:
+                        cmds.append((L.yh_bn_bwd_finalize, (part_ptr, nblk, n, M, ws.data_ptr(),
+                                                            pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
+                                                            coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0, 8.0 * nblk * n)))
                     gres_ptr, gres_ld, gres_acc = None, 0, 0
                     if op.res is not None and pi == 0 and op.res.buf.needs_grad:
                         gres_acc = claim(op.res)
@@ -954,8 +971,10 @@ class Program:
                                                               gres_ptr, gres_ld, gres_acc), op.name,
                                      ('yh_bn_silu_bwd_apply', 0, (6.0 + (4.0 if gres_acc else 2.0) * (gres_ptr is not None)) * M * n)))
                     c0 += n
-                if bwd_parts is not None:          # the parts' reductions are done: one pass writes gz of the whole stacked layer
+                if bwd_parts is not None:          # the parts' reductions are done: one finalize, one pass writes gz of the whole stacked layer
                     self._keep.append(bwd_parts)
+                    cmds.append((L.yh_bn_bwd_finalize_parts, (bwd_parts, len(op.parts), M), op.name,
+                                 ('yh_bn_bwd_finalize', 0, 8.0 * sum(int(q.nblk) * int(q.C) for q in bwd_parts))))
                     cmds.append((L.yh_bn_silu_bwd_apply_parts, (op.y.t.data_ptr(), op.y.C, M, bwd_parts, len(op.parts), gys.data_ptr(), op.N),
                                  op.name, ('yh_bn_silu_bwd_apply_parts', 0, 6.0 * M * op.N)))
                 gy_ld, gyN = op.N, op.N

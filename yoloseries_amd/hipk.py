@@ -160,7 +160,23 @@ def _bn_parts(parts):
         if "ga" in q:
             a.ga, a.ldga = q["ga"].ptr(), q["ga"].ld
             a.gamma, a.coef = q["gamma"].data_ptr(), q["coef"].data_ptr()
+        if "slab" in q:          # finalize: forward (gamma, beta, rm, rv, nbt, eps, momentum, ldslab) or backward (dgamma, dbeta, coef)
+            a.slab, a.nblk, a.ldslab = q["slab"], q["nblk"], q.get("ldslab", q["C"])
+            for k in ("gamma", "beta", "running_mean", "running_var", "num_batches", "dgamma", "dbeta", "coef"):
+                if k in q:
+                    setattr(a, k, q[k].data_ptr())
+            a.eps, a.momentum = q.get("eps", 0.0), q.get("momentum", 0.0)
     return arr
+
+
+def bn_finalize_parts(parts, count):
+    arr = _bn_parts(parts)
+    check(lib().yh_bn_finalize_parts(arr, len(parts), count, _st()), "yh_bn_finalize_parts")
+
+
+def bn_bwd_finalize_parts(parts, M):
+    arr = _bn_parts(parts)
+    check(lib().yh_bn_bwd_finalize_parts(arr, len(parts), M, _st()), "yh_bn_bwd_finalize_parts")
 
 
 def bn_silu_apply_parts(y: Slice, M, parts):
