@@ -145,13 +145,16 @@ typedef struct yh_wgrad_desc {
     int32_t  B, Ho, Wo, Hi, Wi, KH, KW, stride, pad;
     float*   dw;                      /* [N][KH*KW*Ctot] fp32, accumulated          */
     int32_t  splits;                  /* split of the M (pixel) reduction, >=1      */
-    int32_t  tile_k;                  /* launch tuning: 64 = 64-pixel k-steps on the wide 64-row tilings (0 / 32: default) */
+    int32_t  tile_k;                  /* launch tuning: 64 = 64-pixel k-steps on the wide 64-row tilings (0 / 32: default);
+                                         128 = the general 128-column tiling also where KH*KW*C <= 384 (needs >= 128 columns) */
 } yh_wgrad_desc;
 int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
-const char* yh_conv_wgrad_kernel_name(int N, int Kseg);   /* instantiation used for a layer, profiler spelling */
+const char* yh_conv_wgrad_kernel_name(int N, int Kseg);   /* instantiation used for a layer (tile_k 0), profiler spelling */
+const char* yh_conv_wgrad_kernel_name2(int N, int Kseg, int tile_k);
 /* number of (out-channel x im2col-column) tiles the kernel uses for a layer; callers size `splits` so that
  * tiles*splits is about one resident wave of blocks */
 int yh_conv_wgrad_tiles(int N, int Kseg);
+int yh_conv_wgrad_tiles2(int N, int Kseg, int tile_k);
 
 /* ------------------------------------------------------------------------ *
  * BatchNorm (training statistics) + SiLU, forward and backward

@@ -43,6 +43,7 @@ CASES = [
     (2, 24, 24, 48, 96, 3, 2, 1),
     (2, 16, 16, 80, 80, 1, 1, 0),
     (2, 10, 10, 512, 128, 1, 1, 0),      # pointwise layer on the general (K > 384) weight-gradient tiling
+    (2, 20, 20, 256, 256, 1, 1, 0),      # C3 1x1 layer: wide tiling by default, the general one on request (tile_k 128)
 ]
 
 
@@ -123,7 +124,7 @@ def test_conv_dgrad(dev, B, H, W, Cin, Cout, k, s, p):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CASES)
-@pytest.mark.parametrize("splits,tile_k", [(1, 0), (5, 0), (3, 64)])
+@pytest.mark.parametrize("splits,tile_k", [(1, 0), (5, 0), (3, 64), (4, 128)])
 def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits, tile_k):
     from yoloseries_amd import hipk
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
@@ -133,7 +134,8 @@ def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits, tile_k):
     x = _nhwc(B, H, W, Cin, dev, 11)
     dw = torch.zeros(Cout, k * k * Cin, device=dev)
     d = hipk.wgrad_desc(hipk.full(gyb), Cout, hipk.full(x), 0, Cin, B, Ho, Wo, H, W, k, s, p, dw, splits)
-    d.tile_k = tile_k                    # 64-pixel k-steps where the layer's tiling has that variant, ignored elsewhere
+    d.tile_k = tile_k                    # 64: 64-pixel k-steps where the layer's tiling has that variant; 128: the general 128-column
+                                         # tiling on layers with 128..384 im2col columns; ignored elsewhere
     hipk.wgrad_launch(d)
     torch.cuda.synchronize()
     w = torch.zeros(Cout, Cin, k, k, device=dev, requires_grad=True)

@@ -25,7 +25,11 @@ shapes = [("focus",         320, 16,  32,  3, 1),
           ("s4_conv",       40,  256, 512, 3, 2),
           ("s4_b_3x3",      20,  256, 256, 3, 1),
           ("s4_cba3",       20,  512, 512, 1, 1),
-          ("spp_cba2",      20,  1024, 512, 1, 1)]
+          ("spp_cba2",      20,  1024, 512, 1, 1),
+          ("h2_cba12_seg",  80,  128, 128, 1, 1), ("s3_cba3_seg", 40, 128, 256, 1, 1), ("s4_cba12_seg", 20, 256, 512, 1, 1),
+          ("s4_b_1x1",      20,  256, 256, 1, 1)]
+if os.environ.get("WG_ONLY"):
+    shapes = [sh for sh in shapes if sh[0] in os.environ["WG_ONLY"].split(",")]
 L = lib()
 for name, H, Cin, Cout, k, s in shapes:
     p = k // 2

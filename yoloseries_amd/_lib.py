@@ -130,7 +130,9 @@ _SIGS = {
     "yh_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp]),
     "yh_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "yh_conv_wgrad_tiles": (_i32, [_i32, _i32]),
+    "yh_conv_wgrad_tiles2": (_i32, [_i32, _i32, _i32]),
     "yh_conv_wgrad_kernel_name": (C.c_char_p, [_i32, _i32]),
+    "yh_conv_wgrad_kernel_name2": (C.c_char_p, [_i32, _i32, _i32]),
     "yh_conv_bnr_rows": (_i32, [C.POINTER(ConvDesc)]),
     "yh_conv_kernel_name": (_i32, [C.POINTER(ConvDesc), C.c_char_p, _i32]),
     "yh_bn_finalize": (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),

@@ -1065,11 +1065,14 @@ class Program:
         total block count depends on the tile configuration's residency and on how the atomics of the epilogue amortise
         (measured 256..1024 blocks, up to 1.6x apart), so it is timed once per layer when the backward program is built
         (YH_WGRAD_TUNE=0: fixed 512-block rule).  Sets wd.tile_k, returns the split factor."""
-        def splits_for(total):
-            return max(1, min((M + 255) // 256, (total + ntile - 1) // ntile))
+        Kseg = wd.KH * wd.KW * wd.seg.C
+
+        def splits_for(total, tk=0):
+            nt = self.L.yh_conv_wgrad_tiles2(wd.N, Kseg, tk) if tk == 128 else ntile
+            return max(1, min((M + 255) // 256, (total + nt - 1) // nt))
         if os.environ.get("YH_WGRAD_TUNE", "1") == "0":
             return splits_for(512)
-        key = "wgrad4:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
+        key = "wgrad5:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
                                                           wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad))
         cache = _tune_cache()
         if key in cache:
@@ -1083,10 +1086,12 @@ class Program:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         name = self.L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
         tks = (0, 64) if name in _WGRAD_TK64 else (0,)
+        if 128 <= Kseg <= 384 and wd.N > 32:
+            tks = tks + (128,)              # the general 128-column tiling on a layer that defaults to a wide one
         best, best_ms = None, None
         for tk in tks:
             wd.tile_k = tk
-            for sp in sorted({splits_for(t) for t in (256, 512, 768, 1024, 1536)}):
+            for sp in sorted({splits_for(t, tk) for t in (256, 512, 768, 1024, 1536)}):
                 wd.splits = sp
                 check(self.L.yh_conv_wgrad(C.byref(wd), st), f"yh_conv_wgrad tune [{op.name}]")
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1109,7 +1114,7 @@ class Program:
     def _wgrad_name(L, wd):
         """instantiation yh_conv_wgrad launches for this descriptor, profiler spelling (64-pixel k-steps on the wide tilings:
         csrc/conv_wgrad.hip, yh_conv_wgrad)"""
-        name = L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
+        name = L.yh_conv_wgrad_kernel_name2(wd.N, wd.KH * wd.KW * wd.seg.C, wd.tile_k).decode()
         if wd.tile_k == 64:
             name = _WGRAD_TK64.get(name, name)
         return name
