@@ -162,9 +162,10 @@ def test_bn_fold_and_colsum(dev):
     assert torch.allclose(out, g.float().sum(0), rtol=1e-4, atol=1e-2)
 
 
-def test_maxpool5_fwd_bwd(dev):
+@pytest.mark.parametrize("B,H,W,C", [(2, 20, 20, 64), (2, 40, 40, 24), (1, 13, 17, 8), (1, 7, 128, 16), (1, 3, 5, 8), (1, 9, 130, 8)])
+def test_maxpool5_fwd_bwd(dev, B, H, W, C):
+    """first maximum in window order on ties, NaNs propagate, backward plain and accumulating, ragged / tiny / wide images"""
     from yoloseries_amd import hipk
-    B, H, W, C = 2, 20, 20, 64
     x = _rand_bf16((B, H, W, C), dev, 6)
     # coarse values create ties, which must resolve to the first maximum in window order
     x = (x.float() * 2).round().div(2).to(torch.bfloat16)
@@ -181,6 +182,23 @@ def test_maxpool5_fwd_bwd(dev):
     hipk.maxpool5_bwd(hipk.full(go), idx, B, H, W, hipk.full(gin), 0)
     torch.cuda.synchronize()
     _close(gin, gref.permute(0, 2, 3, 1), 8e-3, 2e-2)
+    # accumulate on top of an existing gradient
+    gin2 = _rand_bf16((B, H, W, C), dev, 8)
+    g0 = gin2.clone()
+    hipk.maxpool5_bwd(hipk.full(go), idx, B, H, W, hipk.full(gin2), 1)
+    torch.cuda.synchronize()
+    _close(gin2, gref.permute(0, 2, 3, 1) + g0.float(), 8e-3, 3e-2)
+    # NaNs propagate to every window that contains one
+    xn2 = x.clone()
+    xn2[0, H // 2, W // 2, :] = float("nan")
+    xn2[0, 0, 0, 0] = float("nan")
+    out2 = torch.zeros_like(x)
+    hipk.maxpool5_fwd(hipk.full(xn2), B, H, W, hipk.full(out2), idx)
+    torch.cuda.synchronize()
+    ref2 = F.max_pool2d(xn2.float().permute(0, 3, 1, 2), 5, 1, 2).permute(0, 2, 3, 1)
+    assert torch.equal(torch.isnan(out2.float()), torch.isnan(ref2))
+    ok = ~torch.isnan(ref2)
+    assert torch.equal(out2.float()[ok], ref2[ok])
 
 
 def test_upsample2_bwd_and_s2d(dev):
