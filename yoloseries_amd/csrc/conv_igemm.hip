@@ -28,6 +28,16 @@ constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDSP = 40;   // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
 
+typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_nt16(const uint16_t* p) {
+    u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_nt16(uint16_t* p, uint4 v) {
+    u32x4_nt w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_nt*>(p));
+}
+
 struct ConvK {
     yh_conv_desc d;
     int M, Ctot, Ktot, nkt, mtiles;
@@ -482,13 +492,22 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
     int zph = 0, zpw = 0, zslot = 0, zslots = 1;
     if (zcls) cls_slot(d, blockIdx.z, zph, zpw, zslot, zslots);
     const int csh = (p.cls && !zcls) ? 2 : 0;
+    // With a multiple of 32 blocks the four classes of a region go to four blocks of ONE XCD at the same time instead (blocks b,
+    // b+8, b+16, b+24 form a group; the class rotates per step so that every block carries the same work): the shared gy rows are
+    // still in that XCD's L2 when the other three classes ask for them (a lone block comes back to them after ~8 MB of other
+    // blocks' traffic: PMC showed gy fetched 4.6 times).  +3 / +7 / +21 % on the YOLOv5s stage-1 / 2 / 3 layers.
+    const bool grp = p.cls && !zcls && (gridDim.x % 32 == 0);
+    const int g_q = (blockIdx.x >> 3) & 3;
+    const int g_idx = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5);
+    const int g_n = gridDim.x >> 2;
     for (int it = 0;; ++it) {
-        const int mt = blockIdx.x + gridDim.x * (zcls ? zslot + zslots * it : (it >> csh));
+        const int mt = grp ? g_idx + g_n * it : blockIdx.x + gridDim.x * (zcls ? zslot + zslots * it : (it >> csh));
         if (mt >= p.mtiles) break;
 #ifdef YH_CONV_STAMPS
         long long st_t = __builtin_amdgcn_s_memtime();
 #endif
-        const int ph = zcls ? zph : (p.cls ? ((it >> 1) & 1) : 0), pw = zcls ? zpw : (p.cls ? (it & 1) : 0);
+        const int gc = (g_q + it) & 3;
+        const int ph = zcls ? zph : (p.cls ? ((grp ? gc >> 1 : it >> 1) & 1) : 0), pw = zcls ? zpw : (p.cls ? ((grp ? gc : it) & 1) : 0);
         const int kh0 = (ph + d.pad) & 1, kw0 = (pw + d.pad) & 1;
         const int nkw = p.cls ? (d.KW - kw0 + 1) / 2 : d.KW;
         const int nkh = p.cls ? (d.KH - kh0 + 1) / 2 : d.KH;
@@ -689,7 +708,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
                 zpre[i] = make_uint4(0, 0, 0, 0);
                 if (m < p.M && n < d.N) {
                     const size_t orow = p.cls ? (size_t)sPix[row] : (size_t)m;
-                    zpre[i] = *reinterpret_cast<const uint4*>(d.bnr_z + orow * d.bnr_ldz + n);
+                    zpre[i] = ld_nt16(d.bnr_z + orow * d.bnr_ldz + n);          // last reader of z
                 }
             }
         }
@@ -778,7 +797,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
                         for (int e = 0; e < 8; ++e) f[e] += g0[e];
                         v = pack8(f);
                     }
-                    *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
+                    // EPI 3 streams its output (non-temporal): the gradient is read next by a whole-tensor pass, and the stride-2
+                    // classes write 64-byte halves of lines — kept in L2 they cost a line fill each and push out the gy rows the
+                    // classes share (PMC on the YOLOv5s stage-1 layer: 1.99 -> 1.39 GB fetched; +1.5 % on the train step)
+                    if (EPI == 3) st_nt16(d.out0 + orow * d.ld0 + n, v);
+                    else *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
                     if (EPI == 3) {
                         const uint4 zv = zpre[i];
                         float g[8], z[8];
@@ -1623,7 +1646,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
                             for (int e = 0; e < 8; ++e) f[e] += g0[e];
                             v = pack8(f);
                         }
-                        *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
+                            *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
                         if (EPI == 1) {
                             float f[8];
                             unpack8(v, f);
@@ -2397,6 +2420,7 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
 // nine taps spread over the four classes): with a multiple of 8 blocks per slot they share an XCD (workgroups go round-robin
 // to the 8 XCDs by linear id) and the rows are fetched from HBM once per XCD-L2 instead of once per class (measured on the
 // YOLOv5s stage-1 / stage-2 layers: +10 % / +7 %).  Rounded DOWN so that the launch still fits one resident wave of blocks.
+int cls_inner_blocks(int gx) { return gx >= 32 ? gx / 32 * 32 : gx; }          // whole groups of 4 blocks x 8 XCDs (conv_v2_kernel)
 constexpr int CLS_INNER_MIN_TILES = 256;          // conv_v2_kernel: regions per class from which a block walks the four classes itself
 int cls_blocks_per_slot(int gx_total, int zslots, long mtiles_cls)
 {
@@ -2638,7 +2662,7 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     if (k.v2) {
         hipStream_t st2 = (hipStream_t)stream;
         const int epi = d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0));
-        if (k.cls && k.mtiles >= CLS_INNER_MIN_TILES) grid = dim3(gx_all, gy, 1);
+        if (k.cls && k.mtiles >= CLS_INNER_MIN_TILES) grid = dim3(cls_inner_blocks(gx_all), gy, 1);
 #define YH_LAUNCH_V2(BN_, WM_, WN_, MINW_, BKT_)                                                               \
         do {                                                                                                   \
             const size_t sm = conv_smem_bytes<BN_, WM_, WN_, BKT_>();                                          \
@@ -2699,7 +2723,7 @@ extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
     if (conv_v3_variant(d)) return cls ? gx * zslots : gx;
     if (cls) {
         const long mt = ((long)(M / 4) + BM - 1) / BM;          // conv_v2_kernel (the only non-v3 kernel with this epilogue): one row per block
-        if (mt >= CLS_INNER_MIN_TILES) return gx < mt ? gx : (int)mt;
+        if (mt >= CLS_INNER_MIN_TILES) return cls_inner_blocks(gx < mt ? gx : (int)mt);
         return cls_blocks_per_slot(gx, zslots, mt) * zslots;
     }
     return gx;
