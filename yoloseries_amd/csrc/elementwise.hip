@@ -19,11 +19,12 @@ __device__ __forceinline__ uint4 ld_nt(const uint16_t* p) {
 // ---------------------------------------------------------------- BN finalize
 // Deterministic column sums of a [nblk][nwhich][ld] partial slab.  These kernels sit on the layer chain's critical path
 // (conv -> finalize -> apply) and move little data, so they are built for latency: one block = FIN_CPB channels
-// (a quarter wave reads 64 contiguous bytes of a slab row), 64 row groups (16 waves x 4 quarter waves) with 8 independent
+// (a quarter wave reads 64 contiguous bytes of a slab row), 32 row groups (8 waves x 4 quarter waves) with 8 independent
 // row loads in flight per lane, fixed-order combine through LDS in fp64.  C / 16 blocks spread the slab over the CUs
 // (the 64-channel, 4-in-flight version took 7-24 us per launch, 114 launches per train step).
 constexpr int FIN_CPB = 16;
-constexpr int FIN_RG = 64;
+constexpr int FIN_RG = 32;             // 512 threads: measured against 1024 / 256 / 128 threads and 8 / 32 channels per block on the train step
+constexpr int FIN_NT = FIN_CPB * FIN_RG;
 
 template <int NW>
 __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int nblk, int ld, int C, int c, double* out /*NW*/)
@@ -97,7 +98,7 @@ __device__ __forceinline__ void bn_finalize_body(int cb, const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int ldstat, int C, double count,
+__global__ __launch_bounds__(FIN_NT) void bn_finalize_kernel(const float* __restrict__ stats, int nblk, int ldstat, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, int64_t* num_batches,
                                    float eps, float momentum, float* ws)
@@ -177,7 +178,7 @@ __device__ __forceinline__ int fin_part_of(const PartsK& P, int blk, int& cb)
     return k;
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_parts_kernel(const PartsK P, double count)
+__global__ __launch_bounds__(FIN_NT) void bn_finalize_parts_kernel(const PartsK P, double count)
 {
     int cb;
     const yh_bn_part& q = P.p[fin_part_of(P, blockIdx.x, cb)];
@@ -405,20 +406,20 @@ __device__ __forceinline__ void bn_bwd_finalize_body(int cb, const float* __rest
     if (coef) { coef[c] = (float)(s[0] / M); coef[C + c] = (float)(s[1] / M); }
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double M,
                                        const float* __restrict__ ws, float* dgamma, float* dbeta, float* coef)
 {
     bn_bwd_finalize_body(blockIdx.x, part, nblk, C, M, ws, dgamma, dbeta, coef);
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_parts_kernel(const PartsK P, double M)
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_parts_kernel(const PartsK P, double M)
 {
     int cb;
     const yh_bn_part& q = P.p[fin_part_of(P, blockIdx.x, cb)];
     bn_bwd_finalize_body(cb, q.slab, q.nblk, q.C, M, q.ws, q.dgamma, q.dbeta, q.coef);
 }
 
-__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out)
+__global__ __launch_bounds__(FIN_NT) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out)
 {
     const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
     double s[2];
@@ -789,7 +790,7 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n)
 
 inline int ew_grid(long nthreads) {
     long g = (nthreads + EW_THREADS - 1) / EW_THREADS;
-    if (g > 256 * 16) g = 256 * 16;
+    if (g > 256 * 8) g = 256 * 8;          // 8 blocks of 256 threads per CU: measured against 4 / 6 / 10 / 16 / 32 and 128- / 512-thread blocks on the train step
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -808,7 +809,7 @@ extern "C" int yh_bn_finalize(const float* stats, int nblk, int ldstat, int C, i
                               int64_t* num_batches, float eps, float momentum, float* ws, yh_stream stream)
 {
     YH_CHECK_ARG(stats && gamma && beta && ws && nblk > 0 && C > 0 && count > 0 && ldstat >= C, "yh_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(1024), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(FIN_NT), 0, (hipStream_t)stream,
                        stats, nblk, ldstat, C, (double)count, gamma, beta, running_mean, running_var, num_batches, eps, momentum, ws);
     YH_CHECK_LAUNCH("yh_bn_finalize");
     return YH_OK;
@@ -916,7 +917,7 @@ extern "C" int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M,
                                   float* dgamma, float* dbeta, float* coef, yh_stream stream)
 {
     YH_CHECK_ARG(part && ws && nblk > 0 && C > 0 && M > 0, "yh_bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(1024), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(FIN_NT), 0, (hipStream_t)stream,
                        part, nblk, C, (double)M, ws, dgamma, dbeta, coef);
     YH_CHECK_LAUNCH("yh_bn_bwd_finalize");
     return YH_OK;
@@ -978,7 +979,7 @@ extern "C" int yh_bn_finalize_parts(const yh_bn_part* parts, int nparts, int64_t
     const int rc = parts_pack("yh_bn_finalize_parts", parts, nparts, 2, &P, &C);
     if (rc != YH_OK) return rc;
     YH_CHECK_ARG(count > 0, "yh_bn_finalize_parts: bad count");
-    hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(1024), 0, (hipStream_t)stream, P, (double)count);
+    hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(FIN_NT), 0, (hipStream_t)stream, P, (double)count);
     YH_CHECK_LAUNCH("yh_bn_finalize_parts");
     return YH_OK;
 }
@@ -990,7 +991,7 @@ extern "C" int yh_bn_bwd_finalize_parts(const yh_bn_part* parts, int nparts, int
     const int rc = parts_pack("yh_bn_bwd_finalize_parts", parts, nparts, 3, &P, &C);
     if (rc != YH_OK) return rc;
     YH_CHECK_ARG(M > 0, "yh_bn_bwd_finalize_parts: bad M");
-    hipLaunchKernelGGL(bn_bwd_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(1024), 0, (hipStream_t)stream, P, (double)M);
+    hipLaunchKernelGGL(bn_bwd_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(FIN_NT), 0, (hipStream_t)stream, P, (double)M);
     YH_CHECK_LAUNCH("yh_bn_bwd_finalize_parts");
     return YH_OK;
 }
@@ -1034,7 +1035,7 @@ extern "C" int yh_colsum(const yh_bf16* g, int ldg, int C, int64_t M, float* par
     long rpb = (M + nblk - 1) / nblk;
     hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
                        g, ldg, (const uint16_t*)nullptr, 0, (const float*)nullptr, C, C / 8, (long)M, rpb, part, 0);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(1024), 0, (hipStream_t)stream, part, nblk, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(FIN_NT), 0, (hipStream_t)stream, part, nblk, C, out);
     YH_CHECK_LAUNCH("yh_colsum");
     return YH_OK;
 }
