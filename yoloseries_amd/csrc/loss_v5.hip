@@ -251,6 +251,7 @@ struct Stage {
     void* gpred;
     int s, H, W, ld;
 };
+struct Stages { Stage s[4]; };
 
 // Decode the predicted box of one positive and evaluate CIoU (+ grads w.r.t. the 4 logits)
 __device__ __forceinline__ float pos_box(const yh_v5loss_desc& d, int s, int anc, const float* lg, const float* tb,
@@ -279,11 +280,12 @@ __device__ __forceinline__ float pos_box(const yh_v5loss_desc& d, int s, int anc
 
 // ---------------------------------------------------------------- positives, forward
 template <typename T>
-__global__ __launch_bounds__(256) void v5_pos_fwd_kernel(const LossK p, const Stage st, const int32_t* __restrict__ count,
+__global__ __launch_bounds__(256) void v5_pos_fwd_kernel(const LossK p, const Stages sts, const int32_t* __restrict__ count,
                                                          const float* __restrict__ tbox, const int32_t* __restrict__ tidx,
                                                          float* __restrict__ ciou_out, int32_t* __restrict__ next,
                                                          int32_t* __restrict__ head, double* __restrict__ part)
 {
+    const Stage st = sts.s[blockIdx.y];          // one launch for all stages: they are independent of each other
     __shared__ double sred[2][4];
     const yh_v5loss_desc& d = p.d;
     const int s = st.s;
@@ -345,10 +347,11 @@ __device__ __forceinline__ int list_max(const int32_t* next, int h) {
 
 // ---------------------------------------------------------------- objectness, forward
 template <typename T>
-__global__ __launch_bounds__(256) void v5_obj_fwd_kernel(const LossK p, const Stage st, const float* __restrict__ ciou,
+__global__ __launch_bounds__(256) void v5_obj_fwd_kernel(const LossK p, const Stages sts, const float* __restrict__ ciou,
                                                          const int32_t* __restrict__ next, const int32_t* __restrict__ head,
                                                          double* __restrict__ part)
 {
+    const Stage st = sts.s[blockIdx.y];          // one launch for all stages: they are independent of each other
     __shared__ double sred[4];
     const yh_v5loss_desc& d = p.d;
     const int s = st.s, A = d.num_anchor, E = 5 + d.num_class;
@@ -436,10 +439,11 @@ __global__ __launch_bounds__(1024) void v5_finalize_kernel(const LossK p, const 
 // then all threads stream the tile's 16-byte chunks.  (One thread per chunk with the objectness math inlined left
 // 6 of 64 lanes busy in that branch while every wave paid for it: 0.5 ms for the stride-8 head.)
 template <typename T>
-__global__ __launch_bounds__(256) void v5_obj_bwd_kernel(const LossK p, const Stage st, const float* __restrict__ gout,
+__global__ __launch_bounds__(256) void v5_obj_bwd_kernel(const LossK p, const Stages sts, const float* __restrict__ gout,
                                                          const double* __restrict__ bal_used, const float* __restrict__ ciou,
                                                          const int32_t* __restrict__ next, const int32_t* __restrict__ head)
 {
+    const Stage st = sts.s[blockIdx.y];          // one launch for all stages: they are independent of each other
     constexpr int TP = 64;                 // pixels per tile
     __shared__ float sG[TP * 4];
     const yh_v5loss_desc& d = p.d;
@@ -506,11 +510,12 @@ __global__ __launch_bounds__(256) void v5_obj_bwd_kernel(const LossK p, const St
 // The member with the largest row index of each cell list sums the gradients of all
 // members (ascending row order) and writes the cell's (5+nc)-1 non-objectness channels.
 template <typename T>
-__global__ __launch_bounds__(256) void v5_pos_bwd_kernel(const LossK p, const Stage st, const float* __restrict__ gout,
+__global__ __launch_bounds__(256) void v5_pos_bwd_kernel(const LossK p, const Stages sts, const float* __restrict__ gout,
                                                          const int32_t* __restrict__ count, const float* __restrict__ tbox,
                                                          const int32_t* __restrict__ tidx, const int32_t* __restrict__ next,
                                                          const int32_t* __restrict__ head)
 {
+    const Stage st = sts.s[blockIdx.y];          // one launch for all stages: they are independent of each other
     const yh_v5loss_desc& d = p.d;
     const int s = st.s;
     const int N = count[s];
@@ -635,15 +640,19 @@ extern "C" int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds,
     int nb_pos = (k.L.cap + 15) / 16;
     if (nb_pos > PART_BLOCKS) nb_pos = PART_BLOCKS;
     int nb_obj = PART_BLOCKS;
-    for (int s = 0; s < d->num_stage; ++s) {
-        Stage sg; sg.pred = preds[s]; sg.gpred = nullptr; sg.s = s; sg.H = d->H[s]; sg.W = d->W[s]; sg.ld = d->ldp[s];
-        if (d->pred_is_f32) {
-            hipLaunchKernelGGL((v5_pos_fwd_kernel<float>), dim3(nb_pos), dim3(256), 0, st, k, sg, count, tbox, tidx, ciou, next, head, part);
-            hipLaunchKernelGGL((v5_obj_fwd_kernel<float>), dim3(nb_obj), dim3(256), 0, st, k, sg, ciou, next, head, part);
-        } else {
-            hipLaunchKernelGGL((v5_pos_fwd_kernel<uint16_t>), dim3(nb_pos), dim3(256), 0, st, k, sg, count, tbox, tidx, ciou, next, head, part);
-            hipLaunchKernelGGL((v5_obj_fwd_kernel<uint16_t>), dim3(nb_obj), dim3(256), 0, st, k, sg, ciou, next, head, part);
-        }
+    Stages all;
+    for (int s = 0; s < 4; ++s) {
+        const int q = s < d->num_stage ? s : 0;
+        Stage& sg = all.s[s];
+        sg.pred = preds[q]; sg.gpred = nullptr; sg.s = q; sg.H = d->H[q]; sg.W = d->W[q]; sg.ld = d->ldp[q];
+    }
+    // positives of every stage, then the objectness pass of every stage (it reads the stage's CIoU values): two launches
+    if (d->pred_is_f32) {
+        hipLaunchKernelGGL((v5_pos_fwd_kernel<float>), dim3(nb_pos, d->num_stage), dim3(256), 0, st, k, all, count, tbox, tidx, ciou, next, head, part);
+        hipLaunchKernelGGL((v5_obj_fwd_kernel<float>), dim3(nb_obj, d->num_stage), dim3(256), 0, st, k, all, ciou, next, head, part);
+    } else {
+        hipLaunchKernelGGL((v5_pos_fwd_kernel<uint16_t>), dim3(nb_pos, d->num_stage), dim3(256), 0, st, k, all, count, tbox, tidx, ciou, next, head, part);
+        hipLaunchKernelGGL((v5_obj_fwd_kernel<uint16_t>), dim3(nb_obj, d->num_stage), dim3(256), 0, st, k, all, ciou, next, head, part);
     }
     hipLaunchKernelGGL(v5_finalize_kernel, dim3(1), dim3(1024), 0, st, k, count, part, nb_pos, nb_obj, balances, bal_used, result);
     YH_CHECK_LAUNCH("yh_v5_loss_fwd");
@@ -669,18 +678,24 @@ extern "C" int yh_v5_loss_bwd(const yh_v5loss_desc* d, const void* const* preds,
     const int32_t* head = (const int32_t*)(sv + k.L.head);
     int nb_pos = (k.L.cap + 15) / 16;
     if (nb_pos > PART_BLOCKS) nb_pos = PART_BLOCKS;
-    for (int s = 0; s < d->num_stage; ++s) {
-        YH_CHECK_ARG(preds[s] && gpreds[s] && yh_aligned16(gpreds[s]), "yh_v5_loss_bwd: stage %d pointers null/unaligned", s);
-        Stage sg; sg.pred = preds[s]; sg.gpred = gpreds[s]; sg.s = s; sg.H = d->H[s]; sg.W = d->W[s]; sg.ld = d->ldp[s];
+    Stages all;
+    long ntile_max = 1;
+    for (int s = 0; s < d->num_stage; ++s) YH_CHECK_ARG(preds[s] && gpreds[s] && yh_aligned16(gpreds[s]), "yh_v5_loss_bwd: stage %d pointers null/unaligned", s);
+    for (int s = 0; s < 4; ++s) {
+        const int q = s < d->num_stage ? s : 0;
+        Stage& sg = all.s[s];
+        sg.pred = preds[q]; sg.gpred = gpreds[q]; sg.s = q; sg.H = d->H[q]; sg.W = d->W[q]; sg.ld = d->ldp[q];
         const long ntile = ((long)d->B * sg.H * sg.W + 63) / 64;
-        int gb = (int)(ntile > 4096 ? 4096 : ntile);
-        if (d->pred_is_f32) {
-            hipLaunchKernelGGL((v5_obj_bwd_kernel<float>), dim3(gb), dim3(256), 0, st, k, sg, gout, bal_used, ciou, next, head);
-            hipLaunchKernelGGL((v5_pos_bwd_kernel<float>), dim3(nb_pos), dim3(256), 0, st, k, sg, gout, count, tbox, tidx, next, head);
-        } else {
-            hipLaunchKernelGGL((v5_obj_bwd_kernel<uint16_t>), dim3(gb), dim3(256), 0, st, k, sg, gout, bal_used, ciou, next, head);
-            hipLaunchKernelGGL((v5_pos_bwd_kernel<uint16_t>), dim3(nb_pos), dim3(256), 0, st, k, sg, gout, count, tbox, tidx, next, head);
-        }
+        if (s < d->num_stage && ntile > ntile_max) ntile_max = ntile;
+    }
+    const int gb = (int)(ntile_max > 4096 ? 4096 : ntile_max);
+    // the objectness pass writes every stage's whole gradient tensor, then the positives fill their channels: two launches
+    if (d->pred_is_f32) {
+        hipLaunchKernelGGL((v5_obj_bwd_kernel<float>), dim3(gb, d->num_stage), dim3(256), 0, st, k, all, gout, bal_used, ciou, next, head);
+        hipLaunchKernelGGL((v5_pos_bwd_kernel<float>), dim3(nb_pos, d->num_stage), dim3(256), 0, st, k, all, gout, count, tbox, tidx, next, head);
+    } else {
+        hipLaunchKernelGGL((v5_obj_bwd_kernel<uint16_t>), dim3(gb, d->num_stage), dim3(256), 0, st, k, all, gout, bal_used, ciou, next, head);
+        hipLaunchKernelGGL((v5_pos_bwd_kernel<uint16_t>), dim3(nb_pos, d->num_stage), dim3(256), 0, st, k, all, gout, count, tbox, tidx, next, head);
     }
     YH_CHECK_LAUNCH("yh_v5_loss_bwd");
     return YH_OK;
