@@ -621,10 +621,11 @@ __device__ __forceinline__ float focal_factor(float x, float t, float gamma, flo
 
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void yolox_fg_kernel(const XK p, const StageX st, const float* __restrict__ targets,
+__global__ __launch_bounds__(256) void yolox_fg_kernel(const XK p, const StagesX sts, const float* __restrict__ targets,
                                                        const unsigned char* __restrict__ svb, double* __restrict__ part,
                                                        const float* __restrict__ gout)
 {
+    const StageX st = sts.s[blockIdx.z];          // one launch for all stages
     __shared__ double sred[3][4];
     const yh_yolox_desc& d = p.d;
     const int s = st.s, n = st.H * st.W, nc = d.num_class, E = 5 + nc;
@@ -720,9 +721,10 @@ __global__ __launch_bounds__(256) void yolox_fg_kernel(const XK p, const StageX 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void yolox_obj_fwd_kernel(const XK p, const StageX st, const unsigned char* __restrict__ svb,
+__global__ __launch_bounds__(256) void yolox_obj_fwd_kernel(const XK p, const StagesX sts, const unsigned char* __restrict__ svb,
                                                             double* __restrict__ part)
 {
+    const StageX st = sts.s[blockIdx.y];          // one launch for all stages
     __shared__ double sred[4];
     const yh_yolox_desc& d = p.d;
     const int s = st.s, n = st.H * st.W;
@@ -809,9 +811,10 @@ __global__ __launch_bounds__(1024) void yolox_finalize_kernel(const XK p, const 
 // Tiles of 256 cells: one thread per cell evaluates the objectness gradient (dense lanes) into LDS, then the block
 // streams the tile's 16-byte chunks.
 template <typename T>
-__global__ __launch_bounds__(256) void yolox_obj_bwd_kernel(const XK p, const StageX st, const unsigned char* __restrict__ svb,
+__global__ __launch_bounds__(256) void yolox_obj_bwd_kernel(const XK p, const StagesX sts, const unsigned char* __restrict__ svb,
                                                             const float* __restrict__ gout)
 {
+    const StageX st = sts.s[blockIdx.y];          // one launch for all stages
     constexpr int TP = 256;
     __shared__ float sG[TP];
     const yh_yolox_desc& d = p.d;
@@ -910,15 +913,14 @@ extern "C" int yh_yolox_loss_fwd(const yh_yolox_desc* d, const void* const* pred
     }
     if (d->pred_is_f32) hipLaunchKernelGGL((yolox_assign_kernel<float>), dim3(d->B, d->num_stage), dim3(1024), 0, st, k, all, targets_xywh, wsb, sv);
     else                hipLaunchKernelGGL((yolox_assign_kernel<uint16_t>), dim3(d->B, d->num_stage), dim3(1024), 0, st, k, all, targets_xywh, wsb, sv);
-    for (int s = 0; s < d->num_stage; ++s) {
-        const StageX sg = all.s[s];
-        if (d->pred_is_f32) {
-            hipLaunchKernelGGL((yolox_fg_kernel<float, false>), fg_grid, dim3(256), 0, st, k, sg, targets_xywh, sv, part, (const float*)nullptr);
-            hipLaunchKernelGGL((yolox_obj_fwd_kernel<float>), dim3(nb_obj), dim3(256), 0, st, k, sg, sv, part);
-        } else {
-            hipLaunchKernelGGL((yolox_fg_kernel<uint16_t, false>), fg_grid, dim3(256), 0, st, k, sg, targets_xywh, sv, part, (const float*)nullptr);
-            hipLaunchKernelGGL((yolox_obj_fwd_kernel<uint16_t>), dim3(nb_obj), dim3(256), 0, st, k, sg, sv, part);
-        }
+    for (int s = d->num_stage; s < MAXS; ++s) all.s[s] = all.s[0];
+    const dim3 fg_grid3(fg_grid.x, fg_grid.y, d->num_stage);
+    if (d->pred_is_f32) {
+        hipLaunchKernelGGL((yolox_fg_kernel<float, false>), fg_grid3, dim3(256), 0, st, k, all, targets_xywh, sv, part, (const float*)nullptr);
+        hipLaunchKernelGGL((yolox_obj_fwd_kernel<float>), dim3(nb_obj, d->num_stage), dim3(256), 0, st, k, all, sv, part);
+    } else {
+        hipLaunchKernelGGL((yolox_fg_kernel<uint16_t, false>), fg_grid3, dim3(256), 0, st, k, all, targets_xywh, sv, part, (const float*)nullptr);
+        hipLaunchKernelGGL((yolox_obj_fwd_kernel<uint16_t>), dim3(nb_obj, d->num_stage), dim3(256), 0, st, k, all, sv, part);
     }
     hipLaunchKernelGGL(yolox_finalize_kernel, dim3(1), dim3(1024), 0, st, k, part, nb_fg, nb_obj, targets_xywh, sv, balances, result);
     YH_CHECK_LAUNCH("yh_yolox_loss_fwd");
@@ -934,19 +936,25 @@ extern "C" int yh_yolox_loss_bwd(const yh_yolox_desc* d, const void* const* pred
     hipStream_t st = (hipStream_t)stream;
     XK k; k.d = *d; k.L = make_xlayout(*d);
     const unsigned char* sv = (const unsigned char*)saved;
-    for (int s = 0; s < d->num_stage; ++s) {
-        YH_CHECK_ARG(preds[s] && gpreds[s] && yh_aligned16(gpreds[s]), "yh_yolox_loss_bwd: stage %d pointers null/unaligned", s);
-        StageX sg; sg.pred = preds[s]; sg.gpred = gpreds[s]; sg.s = s; sg.H = d->H[s]; sg.W = d->W[s]; sg.ld = d->ldp[s];
-        sg.stride = d->img_size0 / (float)d->H[s];
+    StagesX all;
+    long ntile_max = 1;
+    for (int s = 0; s < d->num_stage; ++s) YH_CHECK_ARG(preds[s] && gpreds[s] && yh_aligned16(gpreds[s]), "yh_yolox_loss_bwd: stage %d pointers null/unaligned", s);
+    for (int s = 0; s < MAXS; ++s) {
+        const int q = s < d->num_stage ? s : 0;
+        StageX& sg = all.s[s];
+        sg.pred = preds[q]; sg.gpred = gpreds[q]; sg.s = q; sg.H = d->H[q]; sg.W = d->W[q]; sg.ld = d->ldp[q];
+        sg.stride = d->img_size0 / (float)d->H[q];
         const long ntile = ((long)d->B * sg.H * sg.W + 255) / 256;
-        int gb = (int)(ntile > 4096 ? 4096 : ntile);
-        if (d->pred_is_f32) {
-            hipLaunchKernelGGL((yolox_obj_bwd_kernel<float>), dim3(gb), dim3(256), 0, st, k, sg, sv, gout);
-            hipLaunchKernelGGL((yolox_fg_kernel<float, true>), dim3(4, 64), dim3(256), 0, st, k, sg, targets_xywh, sv, (double*)nullptr, gout);
-        } else {
-            hipLaunchKernelGGL((yolox_obj_bwd_kernel<uint16_t>), dim3(gb), dim3(256), 0, st, k, sg, sv, gout);
-            hipLaunchKernelGGL((yolox_fg_kernel<uint16_t, true>), dim3(4, 64), dim3(256), 0, st, k, sg, targets_xywh, sv, (double*)nullptr, gout);
-        }
+        if (s < d->num_stage && ntile > ntile_max) ntile_max = ntile;
+    }
+    const int gb = (int)(ntile_max > 4096 ? 4096 : ntile_max);
+    // objectness pass (writes every stage's whole gradient tensor), then the foreground cells fill their channels: two launches
+    if (d->pred_is_f32) {
+        hipLaunchKernelGGL((yolox_obj_bwd_kernel<float>), dim3(gb, d->num_stage), dim3(256), 0, st, k, all, sv, gout);
+        hipLaunchKernelGGL((yolox_fg_kernel<float, true>), dim3(4, 64, d->num_stage), dim3(256), 0, st, k, all, targets_xywh, sv, (double*)nullptr, gout);
+    } else {
+        hipLaunchKernelGGL((yolox_obj_bwd_kernel<uint16_t>), dim3(gb, d->num_stage), dim3(256), 0, st, k, all, sv, gout);
+        hipLaunchKernelGGL((yolox_fg_kernel<uint16_t, true>), dim3(4, 64, d->num_stage), dim3(256), 0, st, k, all, targets_xywh, sv, (double*)nullptr, gout);
     }
     YH_CHECK_LAUNCH("yh_yolox_loss_bwd");
     return YH_OK;
