@@ -1,0 +1,75 @@
+// What does a grid-wide barrier cost against a kernel boundary (gfx950)?  A chain of N dependent steps, each "phase A on a few
+// blocks, then phase B on all blocks" (the BN finalize -> apply pattern), run (1) as two launches per step and (2) as one
+// cooperative launch per step with cooperative_groups::grid_group::sync() between the phases.  Grid 2048 x 256 threads.
+//   hipcc --offload-arch=gfx950 -O2 tools/micro/coop_sync.hip -o /tmp/coop_sync && /tmp/coop_sync
+#include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
+#include <stdio.h>
+namespace cg = cooperative_groups;
+
+__global__ void phase_a(float* ws, const float* slab, int n)          // a few blocks: reduce n rows of 16 floats
+{
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    float s = 0.f;
+    for (int r = threadIdx.x >> 4; r < n; r += blockDim.x >> 4) s += slab[r * 1024 + c];
+    __shared__ float red[64][16];
+    red[threadIdx.x >> 4][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (threadIdx.x < 16) { float t = 0.f; for (int i = 0; i < (int)(blockDim.x >> 4); ++i) t += red[i][threadIdx.x]; ws[c] = t; }
+}
+__global__ void phase_b(const float* ws, float* out, long n)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = out[i] * 0.5f + ws[i & 63];
+}
+__global__ void fused(float* ws, const float* slab, int nrows, float* out, long n)
+{
+    cg::grid_group g = cg::this_grid();
+    if (blockIdx.x < 4) {
+        const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+        float s = 0.f;
+        for (int r = threadIdx.x >> 4; r < nrows; r += blockDim.x >> 4) s += slab[r * 1024 + c];
+        __shared__ float red[16][16];
+        red[threadIdx.x >> 4][threadIdx.x & 15] = s;
+        __syncthreads();
+        if (threadIdx.x < 16) { float t = 0.f; for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x]; ws[c] = t; }
+    }
+    g.sync();
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = out[i] * 0.5f + ws[i & 63];
+}
+
+int main()
+{
+    float *ws, *slab, *out;
+    const long n = 1 << 22;          // 16 MB pass
+    const int nrows = 512;
+    hipMalloc(&ws, 4096); hipMalloc(&slab, 512 * 1024 * 4); hipMalloc(&out, n * 4);
+    hipMemset(slab, 0, 512 * 1024 * 4); hipMemset(out, 0, n * 4);
+    hipStream_t st; hipStreamCreate(&st);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int N = 2000;
+    float ms;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0, st);
+        for (int i = 0; i < N; ++i) { phase_a<<<4, 512, 0, st>>>(ws, slab, nrows); phase_b<<<2048, 256, 0, st>>>(ws, out, n); }
+        hipEventRecord(e1, st); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("two launches per step : %.2f us per step\n", ms * 1000.f / N);
+    void* args[] = {&ws, &slab, (void*)&nrows, &out, (void*)&n};
+    int nr = nrows; long nn = n;
+    void* args2[] = {&ws, &slab, &nr, &out, &nn};
+    (void)args;
+    hipError_t e = hipSuccess;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0, st);
+        for (int i = 0; i < N; ++i) { e = hipLaunchCooperativeKernel((const void*)fused, dim3(2048), dim3(256), args2, 0, st); if (e != hipSuccess) break; }
+        hipEventRecord(e1, st); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("cooperative, grid.sync : %.2f us per step (%s)\n", ms * 1000.f / N, hipGetErrorString(e));
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0, st);
+        for (int i = 0; i < N; ++i) phase_b<<<2048, 256, 0, st>>>(ws, out, n);
+        hipEventRecord(e1, st); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("phase B alone          : %.2f us per step\n", ms * 1000.f / N);
+    return 0;
+}
