@@ -1,6 +1,7 @@
 // What does a grid-wide barrier cost against a kernel boundary (gfx950)?  A chain of N dependent steps, each "phase A on a few
-// blocks, then phase B on all blocks" (the BN finalize -> apply pattern), run (1) as two launches per step and (2) as one
-// cooperative launch per step with cooperative_groups::grid_group::sync() between the phases.  Grid 2048 x 256 threads.
+// blocks, then phase B on all blocks" (the BN finalize -> apply pattern), run (1) as two launches per step, (2) as one
+// cooperative launch per step with cooperative_groups::grid_group::sync() between the phases and (3) as one plain launch with
+// leader blocks and a polled flag.  Grid 2048 x 256 threads.  Measured: 8.4 / 217 / 445 us per step (phase B alone: 4.9).
 //   hipcc --offload-arch=gfx950 -O2 tools/micro/coop_sync.hip -o /tmp/coop_sync && /tmp/coop_sync
 #include <hip/hip_runtime.h>
 #include <hip/hip_cooperative_groups.h>
@@ -37,6 +38,32 @@ __global__ void fused(float* ws, const float* slab, int nrows, float* out, long 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = out[i] * 0.5f + ws[i & 63];
 }
 
+// (3) one plain launch: blocks 0..3 are "leaders" (phase A, then release a flag), every block waits for the flag before phase B.
+// Blocks are dispatched in index order, so the leaders are resident before any waiter exists; the spin is bounded anyway.
+__global__ void leader_waiter(float* ws, const float* slab, int nrows, float* out, long n, unsigned* flag, unsigned epoch, unsigned* err)
+{
+    if (blockIdx.x < 4) {
+        const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+        float s = 0.f;
+        for (int r = threadIdx.x >> 4; r < nrows; r += blockDim.x >> 4) s += slab[r * 1024 + c];
+        __shared__ float red[16][16];
+        red[threadIdx.x >> 4][threadIdx.x & 15] = s;
+        __syncthreads();
+        if (threadIdx.x < 16) { float t = 0.f; for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x]; ws[c] = t; }
+        __syncthreads();
+        if (threadIdx.x == 0) { __threadfence(); __hip_atomic_store(flag + blockIdx.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+    if (threadIdx.x < 4) {
+        int spins = 0;
+        while (__hip_atomic_load(flag + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            if (++spins > (1 << 22)) { *err = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = out[i] * 0.5f + ws[i & 63];
+}
+
 int main()
 {
     float *ws, *slab, *out;
@@ -65,6 +92,16 @@ int main()
         hipEventRecord(e1, st); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     }
     printf("cooperative, grid.sync : %.2f us per step (%s)\n", ms * 1000.f / N, hipGetErrorString(e));
+    unsigned *flag, *err;
+    hipMalloc(&flag, 64); hipMalloc(&err, 4); hipMemset(flag, 0, 64); hipMemset(err, 0, 4);
+    unsigned epoch = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0, st);
+        for (int i = 0; i < N; ++i) leader_waiter<<<2048, 256, 0, st>>>(ws, slab, nrows, out, n, flag, ++epoch, err);
+        hipEventRecord(e1, st); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    unsigned herr = 0; hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost);
+    printf("leaders + waiters      : %.2f us per step (spin limit hit: %u)\n", ms * 1000.f / N, herr);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0, st);
         for (int i = 0; i < N; ++i) phase_b<<<2048, 256, 0, st>>>(ws, out, n);
