@@ -81,7 +81,7 @@ def cpu_baseline(budget_s=20.0, batch=4, img=640):
             f"torch-CPU fp32 oracle, after 1 warm-up"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -97,22 +97,52 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "yolox", "infer"],
                     help="train: YOLOv5 train step (BASELINE configs[1], the default and the judged metric); yolox: YOLOXs + SimOTA "
                          "train step (configs[2]); infer: YOLOv5 eval forward + decode + class-aware NMS (configs[4]: --model xlarge --img 1280)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rehearse the multi-rank launch only (rendezvous, barrier, max-over-ranks timing, rank 0's JSON line) with an empty "
+                         "step: runs without a GPU under YH_DIST_BACKEND=gloo; `value` is null")
+    return ap.parse_args(argv)
+
+
+def main():
+    """`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself, the way the reference's
+    driver does (train_yolov5.py:858-870 -> utils/launch.py:39-110), BEFORE anything here touches the GPU — the parent only
+    spawns fresh interpreters (multiprocessing `spawn`, never an exec of a process that has initialised HIP), waits for them, and
+    fails if any rank fails; rank 0 prints the JSON line.  Under torch.distributed.run (WORLD_SIZE set) the process is one rank."""
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    backend = os.environ.get("YH_DIST_BACKEND", "nccl")      # "gloo" only to rehearse N>1 without N GPUs
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
+        return worker(args)
+    if args.gpus == 1:
+        return worker(args)
+    ndev = torch.cuda.device_count()                          # counting devices does not initialise HIP
+    if backend == "nccl" and args.gpus > ndev:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible (one rank per GPU over RCCL)")
+    from yoloseries_amd.utils.launch import launch
+    launch(worker, args.gpus, num_machines=1, machine_rank=0, backend=backend, dist_url="auto", args=(args,))
+
+
+def worker(args):
     global PMC_WORKLOAD
     PMC_WORKLOAD = f"{args.workload}:{args.model}:{args.batch}:{args.img}"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("YH_DIST_BACKEND", "nccl")
+    import torch.distributed as dist
+    if args.launch_check:
+        return launch_check(args, world, rank, backend)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (the product path has no CPU fallback)")
     ndev = torch.cuda.device_count()
-    backend = os.environ.get("YH_DIST_BACKEND", "nccl")      # "gloo" only to rehearse N>1 on a one-GPU box
     if world > 1 and backend == "nccl" and local_rank >= ndev:
         sys.exit(f"bench.py: rank {local_rank} has no GPU ({ndev} visible)")
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
-    import torch.distributed as dist
     # YH_FORCE_DP=1: run the data-parallel path (RCCL communicator, overlapped gradient buckets) on a single rank too
     force_dp = world == 1 and os.environ.get("YH_FORCE_DP") == "1"
     if force_dp:
@@ -120,7 +150,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or force_dp:
+    own_group = (world > 1 or force_dp) and not dist.is_initialized()     # launch() initialises the group of self-started ranks
+    if own_group:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
@@ -290,7 +321,7 @@ def main():
             "config": {"workload": workload, "global_batch": B * world, "parallelism": f"dp{world}" + (" (forced RCCL path)" if force_dp else "")},
             "train_tflops": round(ips * gflop_img / 1000.0, 2),
             "mfma_frac_step": round(ips * gflop_img / 1000.0 / (MFMA_PEAK_TFLOPS * world), 4),
-            "final_loss": round(loss_val, 4), "launch": launch_mode,
+            "final_loss": round(loss_val, 4), "launch": launch_mode, "tuning": _tuning(),
             "hbm_frac_step": (round(roof["hbm_bytes_per_step"] / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4)
                               if roof and roof.get("hbm_bytes_per_step") else None), **extra,
             "roofline": roof, "cpu_baseline": cpu,
@@ -298,7 +329,50 @@ def main():
         print(json.dumps(res))
     if world > 1 or force_dp:
         dist.barrier()
-        dist.destroy_process_group()
+        if own_group:
+            dist.destroy_process_group()
+
+
+def launch_check(args, world, rank, backend):
+    """the multi-rank plumbing of the bench without the GPU work: group (from launch() or the environment), the barrier-bracketed
+    timed region with an empty step, MAX over ranks, one JSON line on rank 0.  CPU-runnable (gloo): tests/test_dist_gloo.py."""
+    import torch.distributed as dist
+    own_group = world > 1 and not dist.is_initialized()
+    if own_group:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ranks = torch.ones(1, dtype=torch.float64)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks)
+        dt = tt.item()
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no GPU work)", "value": None, "unit": "images/sec", "n_gpus": world, "ranks_seen": int(ranks.item()),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * dt / max(args.steps, 1), 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "launch check", "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                          "backend": backend}), flush=True)
+    if world > 1:
+        dist.barrier()
+        if own_group:
+            dist.destroy_process_group()
+
+
+def _tuning():
+    """where the per-layer launch parameters came from: the table shipped with the package (yoloseries_amd/tune_defaults.json, built
+    on an MI355X by tools/make_tune_defaults.sh and selected by its score on this very bench line), this machine's cache, or timed now"""
+    from yoloseries_amd.engine import tuning_source
+    src = tuning_source()
+    kind = "shipped table" if src["timed_now"] == 0 and src["local_cache"] == 0 else "shipped table + timed on this machine"
+    return {"kind": kind, **src}
 
 
 def _instrument(prog, step, nsteps):

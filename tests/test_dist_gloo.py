@@ -80,3 +80,26 @@ def test_data_parallel_exchange_world2():
         assert p.exitcode == 0
     for rank, res in out:
         assert all(res.values()), (rank, res)
+
+
+def test_bench_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it) must start two ranks itself — before any GPU call —
+    and report n_gpus == 2 / dp2, as the reference's driver does (train_yolov5.py:858-870, utils/launch.py:39-110).  No GPU
+    here: --launch-check runs the same launch / rendezvous / timing / JSON plumbing with an empty step over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["YH_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--steps", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout              # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["config"]["parallelism"] == "dp2"
+    # more ranks than devices over RCCL is refused with a clear message, before anything is started
+    env["YH_DIST_BACKEND"] = "nccl"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--launch-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr

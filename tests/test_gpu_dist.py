@@ -189,3 +189,23 @@ def test_rccl_single_rank_bucket_path(dev):
     assert res["err_fp32"] < 1e-3, res                       # sum over one rank / 1 == the plain gradient (atomics noise only)
     assert res["err_bf16"] < 2e-2, res                       # bf16 buckets: one rounding of every element
     assert res["nosync_fp32"] and res["nosync_bf16"], res
+
+
+def test_bench_gpus2_real_step_two_ranks_one_gpu(dev):
+    """the judged entry point as a plain command: `python bench.py --gpus 2` starts its two ranks itself (utils/launch.py, spawn
+    before any GPU call) and runs the real data-parallel train step — two ranks sharing this box's GPU over gloo (RCCL refuses
+    two ranks on one device) at a small batch; rank 0 alone prints the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["YH_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "4", "--img", "256", "--steps", "2",
+                        "--warmup", "1", "--no-roofline", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 8
+    assert j["value"] > 0 and j["final_loss"] == j["final_loss"]

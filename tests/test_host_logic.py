@@ -181,9 +181,9 @@ DRIVER_IMPORTS = {
     "config": ["Config"],
     "loss": ["YOLOV5Loss", "YOLOXLoss"],
     "trainer": ["YOLOV5Evaluator", "YOLOXEvaluator", "ExponentialMovingAverageModel"],
-    "dataset": ["build_dataloader", "build_test_dataloader"],
+    "dataset": ["build_dataloader", "build_test_dataloader", "build_val_dataloader"],
     "models": ["YOLOV5Small", "YOLOV5Middle", "YOLOV5Large", "YOLOV5XLarge", "YOLOXSmall"],
-    "utils": ["cv2_save_img", "maybe_mkdir", "clear_dir", "time_synchronize", "summary_model", "mAP_v2", "configure_nccl",
+    "utils": ["cv2_save_img", "cv2_save_img_plot_pred_gt", "maybe_mkdir", "clear_dir", "time_synchronize", "summary_model", "mAP_v2", "configure_nccl",
               "configure_omp", "get_local_rank", "print_config", "get_rank", "get_world_size", "occupy_mem", "padding",
               "MeterBuffer", "all_reduce_norm", "is_parallel", "adjust_status", "synchronize", "configure_module", "launch",
               "get_num_devices", "gpu_nms", "gpu_linear_soft_nms", "gpu_exponential_soft_nms", "numba_nms", "gpu_iou",
@@ -221,15 +221,16 @@ def test_driver_import_surface_resolves():
         exec("from models import *", ns)
         assert callable(ns["launch"]) and callable(ns["YOLOV5Small"])
         # when the reference tree is present (build container), its own import statements are executed against the aliases
-        ref = "/root/reference/train_yolov5.py"
-        if os.path.exists(ref):
-            import ast
-            tree = ast.parse(open(ref).read())
-            ours = set(DRIVER_IMPORTS)
-            for node in tree.body:
-                if isinstance(node, ast.ImportFrom) and node.module in ours:
-                    code = ast.unparse(node)
-                    exec(code, {})           # raises ImportError if a name the reference's driver needs is missing
+        for ref in ("/root/reference/train_yolov5.py", "/root/reference/val_yolov5.py", "/root/reference/train_yolox.py",
+                    "/root/reference/val_yolox.py"):
+            if os.path.exists(ref):
+                import ast
+                tree = ast.parse(open(ref).read())
+                ours = set(DRIVER_IMPORTS)
+                for node in tree.body:
+                    if isinstance(node, ast.ImportFrom) and node.module in ours:
+                        code = ast.unparse(node)
+                        exec(code, {})           # raises ImportError if a name the reference's driver needs is missing
     finally:
         _restore_modules(saved)
 
@@ -258,6 +259,16 @@ def test_runtime_helpers_behaviour(tmp_path):
     assert all(x.training for x in m.modules())
     sm = U.summary_model(m, [640, 640])
     assert sm["number_params"] == 7235389 and abs(sm["flops"] * 2 - 8.217) < 0.01      # MACs / 2e9 like the reference's thop line
+    # drawing helpers of the val driver (val_yolov5.py:21-22): files are written, boxes change pixels, the blend keeps the size
+    import numpy as np
+    from PIL import Image
+    pic = np.full((64, 96, 3), 90, dtype=np.uint8)
+    U.cv2_save_img(pic, [[10, 20, 50, 60]], [3], [0.9], str(tmp_path / "v" / "p.png"))
+    U.cv2_save_img_plot_pred_gt(pic, [[10, 20, 50, 60]], [3], [0.9], [[30, 25, 80, 50]], [1], str(tmp_path / "v" / "pg.png"))
+    U.cv2_save_img_plot_pred_gt(pic, [], [], [], [], [], str(tmp_path / "v" / "none.png"))
+    a, b, c0 = (np.asarray(Image.open(tmp_path / "v" / n)) for n in ("p.png", "pg.png", "none.png"))
+    assert a.shape == b.shape == c0.shape == pic.shape and (a != pic).any() and (b != a).any() and (c0 == pic).all()
+    assert tuple(a[40, 10]) == (0, 238, 238)                     # left edge of the predicted box
     table = U.print_config({"lr": 0.01, "_hidden": 1, "name": "x"})
     assert "lr" in table and "_hidden" not in table
     import os as _os

@@ -29,11 +29,17 @@ class Training(train_yolov5.Training):
     # train_yolox.py:328-329 comments clip_grad_norm_ out and leans on the AMP GradScaler, which skips a step whose gradients
     # overflow.  The bf16 path has no scaler (nothing overflows in bf16's range, so nothing would be skipped): the first steps
     # of a fresh YOLOX (objectness loss ~2e3 against bias learning rates warmed DOWN from 0.1) diverge without a guard.  The
-    # v5 driver's clipping is kept as that guard — a documented deviation; None restores the reference's behaviour.
+    # v5 driver's clipping is kept as that guard — a documented deviation.  hyp['clip_grad_norm'] (config/train_yolox.yaml)
+    # sets the bound; `null` there restores the reference's behaviour (no clipping).
     CLIP_GRAD_NORM = 10.0
 
     def __init__(self, hyp):
         super().__init__(None, hyp)
+        if 'clip_grad_norm' in hyp:
+            self.CLIP_GRAD_NORM = None if hyp['clip_grad_norm'] is None else float(hyp['clip_grad_norm'])
+        if self.rank == 0:
+            print("YOLOX driver: " + ("no gradient clipping (reference behaviour, train_yolox.py:328-329)" if self.CLIP_GRAD_NORM is None
+                                      else f"clip_grad_norm_({self.CLIP_GRAD_NORM}) — bf16 path has no GradScaler to skip diverging steps"))
 
     def select_model(self):
         """train_yolox.py:112-123; YOLOXSmall is the family member inside the hot-path scope"""

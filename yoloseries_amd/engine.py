@@ -38,44 +38,81 @@ def _rup(x, m):
 
 
 def _tune_cache_path():
-    return os.environ.get("YH_TUNE_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), ".tune_cache.json"))
+    """per-machine timings live in the user's cache directory, not in the package (YH_TUNE_CACHE overrides)"""
+    base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+    return os.environ.get("YH_TUNE_CACHE", os.path.join(base, "yoloseries_amd", "tune_cache.json"))
+
+
+class _TuneTable:
+    """launch parameters per layer shape.  Two layers, never mixed: the shipped table for the BASELINE configurations
+    (tune_defaults.json, timed on an MI355X with tools/make_tune_defaults.sh: the same choices on every box, no tuning launches in
+    the first steps; read-only) and what THIS machine timed itself for other shapes (a small JSON file, kept across processes).
+    A lookup asks the local layer first, then the shipped one; only locally timed keys are ever written back, so a later
+    release of tune_defaults.json is not shadowed by a frozen copy of the old one.  YH_TUNE_DEFAULTS=0 ignores the shipped table."""
+
+    def __init__(self):
+        self.shipped, self.local, self.dirty = {}, {}, False
+        if os.environ.get("YH_TUNE_DEFAULTS", "1") != "0":
+            self.shipped = self._read(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_defaults.json"))
+        self.local = self._read(_tune_cache_path())
+        self.hits_shipped = self.hits_local = self.timed = 0
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return dict(json.load(f))
+        except (OSError, ValueError):
+            return {}
+
+    def __contains__(self, key):
+        return key in self.local or key in self.shipped
+
+    def __getitem__(self, key):
+        if key in self.local:
+            self.hits_local += 1
+            return self.local[key]
+        self.hits_shipped += 1
+        return self.shipped[key]
+
+    def __setitem__(self, key, value):
+        self.local[key] = value
+        self.timed += 1
+        self.dirty = True
+
+    def save(self):
+        if not self.dirty:
+            return
+        self.dirty = False
+        path = _tune_cache_path()
+        try:
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                json.dump(self.local, f, indent=0, sort_keys=True)
+            os.replace(tmp, path)
+        except OSError:
+            pass                               # read-only install: tune again next time
 
 
 def _tune_cache():
-    """launch parameters per layer shape: the shipped table for the BASELINE configurations (tune_defaults.json, timed on an
-    MI355X with tools/make_tune_defaults.sh: the same choices on every box, no tuning launches in the first steps), overlaid by
-    what this machine timed itself for other shapes (kept across processes in a small JSON file).  YH_TUNE_DEFAULTS=0 ignores
-    the shipped table."""
     if _tune_cache.data is None:
-        _tune_cache.data = {}
-        paths = [_tune_cache_path()]
-        if os.environ.get("YH_TUNE_DEFAULTS", "1") != "0":
-            paths.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_defaults.json"))
-        for pth in paths:
-            try:
-                with open(pth) as f:
-                    _tune_cache.data.update(dict(json.load(f)))
-            except (OSError, ValueError):
-                pass
+        _tune_cache.data = _TuneTable()
     return _tune_cache.data
 
 
 _tune_cache.data = None
-_tune_cache.dirty = False
 
 
 def _tune_cache_save():
-    if not _tune_cache.dirty:
-        return
-    _tune_cache.dirty = False
-    path = _tune_cache_path()
-    try:
-        tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "w") as f:
-            json.dump(_tune_cache.data, f, indent=0, sort_keys=True)
-        os.replace(tmp, path)
-    except OSError:
-        pass                               # read-only install: tune again next time
+    if _tune_cache.data is not None:
+        _tune_cache.data.save()
+
+
+def tuning_source():
+    """where the launch parameters of this process came from (reported by bench.py)"""
+    t = _tune_cache()
+    return {"shipped_table": t.hits_shipped, "local_cache": t.hits_local, "timed_now": t.timed}
 
 
 # YH_BN_ACC=1: BatchNorm statistics / backward sums leave the conv kernels as int64 fixed-point accumulator rows that the BN+SiLU
@@ -555,7 +592,6 @@ class Program:
         d.seg[0].ptr, d.stats = saved
         d.bnr_part = saved_part
         cache[key] = [int(best[0]), int(best[1]), int(best[2])]
-        _tune_cache.dirty = True
 
     def _build_forward(self):
         """inference program (folded BatchNorm + SiLU in the conv epilogue).  The training program — raw conv outputs,
@@ -1107,7 +1143,6 @@ class Program:
         wd.tile_k = best[1]
         self.wgrad_tuned[(op.name, wd.coff_k)] = (best[0], best_ms / TUNE_ITERS)
         cache[key] = [int(best[0]), int(best[1])]
-        _tune_cache.dirty = True
         return best[0]
 
     @staticmethod
@@ -1358,6 +1393,9 @@ class _NetFn(torch.autograd.Function):
                 head_grads.append(g.permute(0, 2, 3, 1).to(torch.bfloat16) if g is not None else torch.zeros(
                     shape[0], shape[2], shape[3], shape[1], dtype=torch.bfloat16, device=prog.dev))
         bucket_hook = getattr(ctx.host, "_yh_bucket_hook", None)   # data-parallel all-reduce, overlapped (utils/dist.py)
+        owner = getattr(bucket_hook, "__self__", None)
+        if owner is not None and not getattr(owner, "buckets_active", True):
+            bucket_hook = None                                      # no_sync / accumulation boundary: no per-bucket segmentation
         flat_g, pgrads = prog.backward(head_grads, bucket_hook)
         ctx.host._yh_last_flat_grad = flat_g
         # whole-gradient hook of the data-parallel exchange: all-reduces flat_g when no bucket hook ran, keeps the

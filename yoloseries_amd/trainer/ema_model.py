@@ -55,6 +55,15 @@ class ExponentialMovingAverageModel:
         if self._dev_state is not None:
             self._dev_state[2] = self.update_num
 
+    def graph_snapshot(self):
+        return self.update_num
+
+    def graph_restore(self, snap):
+        """a capture failed after update() had counted an update whose kernels never ran: back to the count the device holds;
+        the device counter / decay pair is rebuilt by the next eager update"""
+        self.update_num = snap
+        self._dev_state = None
+
     def update(self, model):
         with torch.no_grad():
             self.update_num += 1

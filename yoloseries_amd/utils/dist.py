@@ -137,7 +137,8 @@ class DataParallelGrads:
         """async all-reduce of one contiguous slice of the packed gradient arena; returns the finisher that
         makes the compute stream wait for it and turns the sum into the mean"""
         world = self._world()
-        if not self.enabled or self._local_acc is not None or world == 1 and not os.environ.get("YH_FORCE_DP") or part.numel() == 0:
+        single = world == 1 and not os.environ.get("YH_FORCE_DP")
+        if (not self.enabled) or (self._local_acc is not None) or single or part.numel() == 0:
             return None
         if self.bucket_dtype is not None and self.bucket_dtype != part.dtype:
             low = part.to(self.bucket_dtype)
@@ -145,6 +146,9 @@ class DataParallelGrads:
 
             def finish_low():
                 work.wait()
+                # `low` was allocated in the caller's (side-stream) context and is consumed on the current stream
+                if low.is_cuda:
+                    low.record_stream(torch.cuda.current_stream())
                 part.copy_(low)
                 part.div_(world)
             return finish_low
@@ -161,7 +165,8 @@ class DataParallelGrads:
 
     @property
     def buckets_active(self):
-        """True when the next backward exchanges its gradient bucket by bucket (engine.Program.backward asks)"""
+        """True when the next backward exchanges its gradient bucket by bucket; the engine's autograd node asks and otherwise runs
+        the backward without bucket segmentation (no_sync and accumulation-boundary steps: every hook would return None)"""
         return self.overlap and self.enabled and self._local_acc is None
 
     class _NoSync:
@@ -181,7 +186,9 @@ class DataParallelGrads:
 def all_reduce_norm(module):
     """average every BatchNorm state (weight, bias, running_mean, running_var) over the ranks before
     evaluation — utils/allreduce_norm.py:56-98.  With the engine's arenas this is one collective on the
-    float-buffer arena plus one on the gathered affine parameters."""
+    float-buffer arena plus one on the gathered affine parameters.  The reference also averages `num_batches_tracked`
+    (utils/allreduce_norm.py:32-38 walks the whole state_dict): every rank counts the same forwards, so its mean is the
+    value each rank already holds and it is left alone here."""
     if get_world_size() == 1 and not (_on() and os.environ.get("YH_FORCE_DP")):
         return
     states = []

@@ -15,6 +15,8 @@ dicts of tensors: the returned objects are the static outputs, refreshed by ever
 the host before each replay: the Python-side bookkeeping that the captured kernels cannot do (step counters, pushing a
 changed learning rate into the device scalars).
 """
+import warnings
+
 import torch
 
 from .._lib import YoloHipError
@@ -36,8 +38,19 @@ class GraphedStep:
     def mode(self):
         return "hipGraph replay" if self.graph is not None else "eager"
 
+    def _owners(self):
+        return [o for o in (getattr(fn, "__self__", None) for fn in self.pre_replay) if o is not None]
+
     def _capture(self):
         g = torch.cuda.CUDAGraph()
+        # host -> device traffic the captured kernels depend on (a learning rate the warm-up has just moved) is pushed now,
+        # outside the capture; the owners' host counters are remembered so that a failed capture — which ran step_fn's Python
+        # bookkeeping but no kernel — can be undone
+        owners = self._owners()
+        for o in owners:
+            if hasattr(o, "graph_pre_capture"):
+                o.graph_pre_capture()
+        snaps = [(o, o.graph_snapshot()) for o in owners if hasattr(o, "graph_snapshot")]
         torch.cuda.synchronize()
         try:
             with torch.cuda.graph(g):
@@ -46,6 +59,9 @@ class GraphedStep:
             self.failed = f"{type(e).__name__}: {e}"
             self.enabled = False
             torch.cuda.synchronize()
+            for o, snap in snaps:
+                o.graph_restore(snap)
+            warnings.warn(f"hipGraph capture of the train step failed, continuing with eager launches: {self.failed}", RuntimeWarning)
             return None
         self.graph, self.static_out = g, out
         return out

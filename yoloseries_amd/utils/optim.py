@@ -127,6 +127,19 @@ class FlatSGD:
         self._sync_scalars()
         self.steps += 1
 
+    def graph_pre_capture(self):
+        """push the device scalars outside the capture that is about to start"""
+        self._pack()
+        self._sync_scalars()
+
+    def graph_snapshot(self):
+        return (self.steps, self._use_scale)
+
+    def graph_restore(self, snap):
+        """a capture failed after step() had advanced the host counters without running a kernel"""
+        self.steps, self._use_scale = snap
+        self._lr_host = None                      # rewrite the device scalars at the next step
+
     def zero_grad(self, set_to_none=True):
         self._gacc, self._nacc = None, 0
         self.model._yh_last_flat_grad = None
