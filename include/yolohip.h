@@ -100,7 +100,9 @@ typedef struct yh_conv_desc {
                            * 128-wide tile on the register-staged kernel)                                               */
     int32_t  algo;        /* kernel family: 0 library default, 1 register-staged (conv_v2_kernel), 2..4 LDS-DMA ring
                            * (conv_v3_kernel) with a 256x128 / 128x128 / 128x64 tile, 5 the 3x3 halo kernel (conv_halo_kernel), 6 its
-                           * 160-channel-wide variant (conv_halo160_kernel: N % 160 == 0, no statistics), when the shape is eligible */
+                           * 160-channel-wide variant (conv_halo160_kernel: N % 160 == 0, no statistics), when the shape is eligible;
+                           * 7 the stride-2 data-gradient kernel (conv_dg2_kernel: DGRAD of a 3x3 / s2 / p1 layer with even output
+                           * dims and gz channels in a multiple of 32: the four parity classes from one LDS patch of gz) */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
      * contributions already in out0 are added first and the sums are taken over the rounded total):
@@ -147,8 +149,15 @@ typedef struct yh_wgrad_desc {
     int32_t  splits;                  /* split of the M (pixel) reduction, >=1      */
     int32_t  tile_k;                  /* launch tuning: 64 = 64-pixel k-steps on the wide 64-row tilings (0 / 32: default);
                                          128 = the general 128-column tiling also where KH*KW*C <= 384 (needs >= 128 columns) */
+    /* optional workspace of >= yh_conv_wgrad_ws_bytes() bytes (16-byte aligned, caller-owned, may be shared by launches on ONE
+     * stream): the split-M partial tiles are written there with plain stores and summed into dw by a second kernel in split
+     * order — bit-reproducible, and faster than the fp32 atomics of the default form (NULL), which are bound by the atomic rate
+     * of L2.  dw is read-modify-written by that kernel: launches that share dw columns must be stream-ordered. */
+    float*   partial;
+    uint64_t partial_bytes;
 } yh_wgrad_desc;
 int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
+size_t yh_conv_wgrad_ws_bytes(const yh_wgrad_desc* d);
 const char* yh_conv_wgrad_kernel_name(int N, int Kseg);   /* instantiation used for a layer (tile_k 0), profiler spelling */
 const char* yh_conv_wgrad_kernel_name2(int N, int Kseg, int tile_k);
 /* number of (out-channel x im2col-column) tiles the kernel uses for a layer; callers size `splits` so that

@@ -144,6 +144,26 @@ def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits, tile_k):
     ref = ref.permute(0, 2, 3, 1).reshape(Cout, -1)
     scale = ref.abs().max().item()
     _close(dw, ref, 2e-3, 2e-3 * scale)
+    # the workspace form: partial tiles by plain stores, summed in split order by a second kernel — same values within fp32
+    # summation noise, and bit-identical from run to run (the atomic form is not)
+    import ctypes as C
+    from yoloseries_amd._lib import lib
+    need = lib().yh_conv_wgrad_ws_bytes(C.byref(d))
+    assert need >= Cout * k * k * Cin * 4
+    ws = torch.full((need // 4 + 64,), float("nan"), device=dev)
+    d.partial, d.partial_bytes = ws.data_ptr(), need
+    outs = []
+    for _ in range(2):
+        dw2 = torch.full_like(dw, 0.25)            # the reduce adds onto what dw holds
+        d.dw = dw2.data_ptr()
+        hipk.wgrad_launch(d)
+        torch.cuda.synchronize()
+        outs.append(dw2)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isnan(ws[need // 4:]).all()       # nothing written past the advertised size
+    _close(outs[0] - 0.25, ref, 2e-3, 2e-3 * scale)
+    d.partial_bytes = need - 4
+    assert lib().yh_conv_wgrad(C.byref(d), None) != 0      # a workspace that is too small is refused
 
 
 @pytest.mark.parametrize("C0,C1,Cout", [(32, 64, 64), (512, 448, 128)])
@@ -196,6 +216,8 @@ def _expect_family(d, algo):
         assert "conv_v3_kernel" in kn, kn
     if algo == 5 and "conv_halo_kernel" not in kn:
         pytest.skip("shape not eligible for the halo kernel")
+    if algo == 7:
+        assert "conv_dg2_kernel" in kn, kn
 
 
 @pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])
@@ -245,6 +267,30 @@ def test_conv_fwd_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
 def test_conv_dgrad_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
     """data gradient (stride-2 layers run as four parity classes), plain and accumulating, plus the fused
     BatchNorm+SiLU backward reduction of the producer layer (EPI 3) against a torch reference"""
+    _dgrad_check(dev, B, H, W, Cin, Cout, k, s, p, algo)
+
+
+DG2_CASES = [
+    # B, H, W, Cin, Cout: data gradient of ConvBnAct(Cin, Cout, 3, 2, 1) on an H x W input (gz is H/2 x W/2 x Cout)
+    (2, 64, 64, 32, 64),        # YOLOv5s stage-1 shape class: one 32-channel tile, one 64-channel block, weights resident in LDS
+    (1, 48, 80, 64, 128),       # two channel tiles (8 waves), two 64-channel blocks
+    (2, 40, 24, 128, 256),      # two blocks along the output channels, ragged regions (20 x 12 map)
+    (1, 32, 32, 48, 96),        # YOLOv5m widths: 48 of 64 channels used, 32-channel steps (96 % 64 != 0)
+    (3, 16, 16, 256, 512),      # 8 x 8 map: a region covers half an image
+    (1, 24, 40, 40, 64),        # channel count that is not a multiple of 32 (masked chunk columns)
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", DG2_CASES)
+def test_conv_dgrad_stride2_kernel(dev, B, H, W, Cin, Cout):
+    """conv_dg2_kernel (algo 7): the four parity classes of a 3x3 / stride-2 data gradient from ONE LDS patch of gz — plain,
+    accumulating and with the fused BatchNorm-backward reduction, against torch; also with 32-channel steps where 64 is the default"""
+    _dgrad_check(dev, B, H, W, Cin, Cout, 3, 2, 1, 7)
+    if Cout % 64 == 0:
+        _dgrad_check(dev, B, H, W, Cin, Cout, 3, 2, 1, 7, tile_k=32)
+
+
+def _dgrad_check(dev, B, H, W, Cin, Cout, k, s, p, algo, tile_k=0):
     from yoloseries_amd import hipk
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     gy = _nhwc(B, Ho, Wo, Cout, dev, 27)
@@ -258,7 +304,7 @@ def test_conv_dgrad_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
     gx = _nhwc(B, H, W, Cin, dev, 29)
     gx0 = gx.clone()
     d = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, Ho, Wo, k, s, p, wd, Cin, hipk.full(gx), accumulate=1)
-    d.algo = algo
+    d.algo, d.tile_k = algo, tile_k
     _expect_family(d, algo)
     hipk.conv_launch(d)
     torch.cuda.synchronize()
@@ -270,7 +316,7 @@ def test_conv_dgrad_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
     ws = torch.cat([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)]).to(dev)
     gx2 = torch.zeros(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
     d2 = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, Ho, Wo, k, s, p, wd, Cin, hipk.full(gx2))
-    d2.algo = algo
+    d2.algo, d2.tile_k = algo, tile_k
     rows = lib().yh_conv_bnr_rows(C.byref(d2))
     assert rows > 0
     slab = torch.zeros(rows, 2, Cin, device=dev)

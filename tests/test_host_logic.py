@@ -306,17 +306,12 @@ def test_launch_two_ranks_gloo(tmp_path):
 def test_shipped_tuning_table_matches_the_engine_key_versions():
     """yoloseries_amd/tune_defaults.json (tools/make_tune_defaults.sh) must be regenerated whenever the meaning of a tuned value
     changes: its keys carry the same version prefixes the engine asks for"""
-    import inspect
     import json
-    import re
     from yoloseries_amd import engine
     path = os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), "tune_defaults.json")
     table = json.load(open(path))
-    src = inspect.getsource(engine)
-    conv_prefix = re.search(r'key = f"(conv\d+):', src).group(1)
-    wgrad_prefix = re.search(r'key = "(wgrad\d+):', src).group(1)
     prefixes = {k.split(":", 1)[0] for k in table}
-    assert prefixes == {conv_prefix, wgrad_prefix}, (prefixes, conv_prefix, wgrad_prefix)
+    assert prefixes <= engine.TUNE_KEY_VERSIONS and engine.KEY_CONV in prefixes, (prefixes, engine.TUNE_KEY_VERSIONS)
     assert len(table) > 300
     assert all(isinstance(v, list) and all(isinstance(x, int) for x in v) for v in table.values())
 

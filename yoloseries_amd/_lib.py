@@ -47,6 +47,7 @@ class WgradDesc(C.Structure):
         ("B", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("dw", C.c_void_p), ("splits", C.c_int32), ("tile_k", C.c_int32),
+        ("partial", C.c_void_p), ("partial_bytes", C.c_uint64),
     ]
 
 
@@ -129,6 +130,7 @@ _SIGS = {
     "yh_conv_stat_blocks": (_i32, [C.POINTER(ConvDesc)]),
     "yh_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp]),
     "yh_conv_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
+    "yh_conv_wgrad_ws_bytes": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "yh_conv_wgrad_tiles": (_i32, [_i32, _i32]),
     "yh_conv_wgrad_tiles2": (_i32, [_i32, _i32, _i32]),
     "yh_conv_wgrad_kernel_name": (C.c_char_p, [_i32, _i32]),

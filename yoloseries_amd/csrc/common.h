@@ -81,4 +81,8 @@ void yh_set_error(const char* fmt, ...);
 #define YH_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) { yh_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return YH_ELAUNCH; } } while (0)
 
+// conv_dg2.hip: the stride-2 data-gradient kernel behind yh_conv_igemm (algo 7)
+int yh_dg2_rows(const yh_conv_desc* d);                 // grid rows (== slab rows of the fused reduction); 0 = not eligible
+int yh_dg2_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
+
 static inline bool yh_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -2478,6 +2478,12 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     }
     long M = (long)d->B * d->Ho * d->Wo;
     YH_CHECK_ARG(M < (1L << 31) - BM, "yh_conv_igemm: too many output pixels");
+    if (d->algo == 7) {                       // stride-2 data-gradient kernel (conv_dg2.hip) where eligible, else the library default
+        if (yh_dg2_rows(d) > 0) return yh_dg2_run(d, stream, name_out, name_len);
+        yh_conv_desc d0 = *d;
+        d0.algo = 0;
+        return conv_run(&d0, stream, name_out, name_len);
+    }
 
     ConvK k;
     k.d = *d;
@@ -2710,6 +2716,13 @@ extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
     if (!conv_desc_plannable(d) || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 8 || d->seg[0].ups || d->N % 8) return 0;
     if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N || d->stats) return 0;
     if (conv_dbg_mask() & 16) return 0;
+    if (d->algo == 7) {
+        const int r7 = yh_dg2_rows(d);
+        if (r7 > 0) return r7;
+        yh_conv_desc d0 = *d;
+        d0.algo = 0;
+        return yh_conv_bnr_rows(&d0);
+    }
     const unsigned long M = (unsigned long)d->B * d->Ho * d->Wo;
     if (M >= (1ul << 31) - BM) return 0;
     const unsigned long npix = (unsigned long)d->B * d->Hi * d->Wi;

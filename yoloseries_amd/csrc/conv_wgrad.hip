@@ -28,6 +28,11 @@ struct WgK {
     yh_wgrad_desc d;
     int M, Ktot, Kseg, rows_per_split, ctiles, pointwise;
     unsigned gybytes, xbytes;
+    // split-M partial tiles leave the kernel either as fp32 atomics into dw (part == nullptr) or as plain stores into the
+    // workspace part[split][pn][pk], summed afterwards in split order by wgrad_reduce_kernel (deterministic; the L2 atomic
+    // unit — one 4-byte add per channel and clock — is what bounds the atomic form)
+    float* part;
+    int pn, pk;
 };
 
 // transposing read: 16-lane group reads a 4(row) x 16(col) block of 16-bit elements; lane i of the group gets
@@ -241,6 +246,23 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
     }
 
     // C[n][col]: lane holds column (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5)
+    if (p.part) {
+        float* const pb = p.part + (size_t)split * p.pn * p.pk;
+#pragma unroll
+        for (int j = 0; j < TCW; ++j) {
+            const int col = col0 + (wc * TCW + j) * 32 + (lane & 31);
+            if (col >= p.Kseg) continue;
+#pragma unroll
+            for (int i = 0; i < TNW; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + (wn * TNW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (n < d.N) __builtin_nontemporal_store(acc[i][j][r], pb + (size_t)n * p.pk + col);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TCW; ++j) {
         const int col = col0 + (wc * TCW + j) * 32 + (lane & 31);
@@ -256,6 +278,59 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
                 if (n < d.N) atomicAdd(base + (size_t)n * p.Ktot, acc[i][j][r]);
             }
         }
+    }
+}
+
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4nt(const float* p) {
+    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// dw[n][tap*Ctot + coff_k + c] += sum over the splits (in split order) of part[s][n][col].  A block sums 64 groups of 4 columns;
+// its SG wave-rows take the splits s = sg, sg + SG, ... and meet in LDS (fixed order: the result does not depend on timing).
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int pn, int pk, int N, int Kseg,
+                                                            int C, int Ctot, int coff_k, int Ktot, float* __restrict__ dw)
+{
+    __shared__ float4 sred[16][64];
+    const int SG = blockDim.y;
+    const int kq = Kseg >> 2;                              // float4 groups per row
+    const long item = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool ok = item < (long)N * kq;
+    const int n = ok ? (int)(item / kq) : 0;
+    const int col = ok ? (int)(item - (long)n * kq) * 4 : 0;
+    const float* src = part + (size_t)n * pk + col;
+    const size_t sstride = (size_t)pn * pk;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        int s = threadIdx.y;
+        for (; s + 3 * SG < splits; s += 4 * SG) {
+            const float4 v0 = ld4nt((src + (size_t)s * sstride));
+            const float4 v1 = ld4nt((src + (size_t)(s + SG) * sstride));
+            const float4 v2 = ld4nt((src + (size_t)(s + 2 * SG) * sstride));
+            const float4 v3 = ld4nt((src + (size_t)(s + 3 * SG) * sstride));
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+            a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+            a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+        }
+        for (; s < splits; s += SG) {
+            const float4 v0 = ld4nt((src + (size_t)s * sstride));
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+        }
+    }
+    sred[threadIdx.y][threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.y == 0 && ok) {
+        for (int g = 1; g < SG; ++g) {
+            const float4 v = sred[g][threadIdx.x];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        const int tap = col / C;
+        float4* dst = reinterpret_cast<float4*>(dw + (size_t)n * Ktot + (size_t)tap * Ctot + coff_k + (col - tap * C));
+        float4 o = *dst;
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        *dst = o;
     }
 }
 
@@ -302,6 +377,32 @@ extern "C" int yh_conv_wgrad_tiles(int N, int Kseg) { return yh_conv_wgrad_tiles
 
 static int conv_wgrad_launch(const yh_wgrad_desc* d, yh_stream stream);
 
+// pixels per k-step / effective split count of a launch (shared by the launcher and the workspace query)
+static void wg_split_plan(const yh_wgrad_desc* d, long M, int* tk_out, int* rps_out, int* splits_out)
+{
+    const int Kseg = d->KH * d->KW * d->seg.C;
+    const bool wide = wg_wide(Kseg, d->tile_k);
+    const int cfg = wg_config(d->N, Kseg, d->tile_k);
+    const bool tk64 = wide && d->tile_k == 64 && cfg <= 3;
+    const int TK = (wide && !tk64) ? 32 : 64;
+    int splits = d->splits < 1 ? 1 : d->splits;
+    int rps = (int)((M + splits - 1) / splits);
+    rps = ((rps + TK - 1) / TK) * TK;
+    splits = (int)((M + rps - 1) / rps);
+    *tk_out = TK; *rps_out = rps; *splits_out = splits;
+}
+
+/* bytes of workspace (yh_wgrad_desc.partial) a launch with these dims / splits needs for the plain-store partial tiles */
+extern "C" size_t yh_conv_wgrad_ws_bytes(const yh_wgrad_desc* d)
+{
+    if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->N <= 0 || d->seg.C <= 0 || d->KH <= 0 || d->KW <= 0) return 0;
+    const long M = (long)d->B * d->Ho * d->Wo;
+    int tk, rps, splits;
+    wg_split_plan(d, M, &tk, &rps, &splits);
+    const size_t pn = ((size_t)d->N + 7) / 8 * 8, pk = (size_t)d->KH * d->KW * d->seg.C;
+    return (size_t)splits * pn * pk * sizeof(float);
+}
+
 /* The kernels address gy and the input segment with 32-bit buffer offsets.  A launch whose operands reach 2 GiB is split over the
  * batch: every part is a launch of its own on a sub-range of images (pointers advanced, dw accumulated by the same atomics). */
 extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
@@ -310,6 +411,7 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     const unsigned long gy_img = (unsigned long)d->Ho * d->Wo * d->ldg * 2;
     const unsigned long x_img = (unsigned long)(d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups) * d->seg.ld * 2;
     const unsigned long lim = (1ul << 31) - 4096;
+    if (d->partial) YH_CHECK_ARG(yh_aligned16(d->partial) && d->partial_bytes >= yh_conv_wgrad_ws_bytes(d), "yh_conv_wgrad: workspace too small / unaligned");
     if (gy_img * d->B < lim && x_img * d->B < lim) return conv_wgrad_launch(d, stream);
     const unsigned long per = gy_img > x_img ? gy_img : x_img;
     YH_CHECK_ARG(per < lim, "yh_conv_wgrad: a single image needs a 2 GiB operand");
@@ -360,13 +462,14 @@ static int conv_wgrad_launch(const yh_wgrad_desc* d, yh_stream stream)
     // twice the loads in flight per thread; the engine times both per layer) and for the general tiles
     const int cfg = wg_config(d->N, k.Kseg, d->tile_k);
     const bool tk64 = wide && d->tile_k == 64 && cfg <= 3;
-    const int TK = (wide && !tk64) ? 32 : 64;
-    int splits = d->splits;
-    int rps = (int)((M + splits - 1) / splits);
-    rps = ((rps + TK - 1) / TK) * TK;
+    int TK, rps, splits;
+    wg_split_plan(d, M, &TK, &rps, &splits);
     k.rows_per_split = rps;
-    splits = (int)((M + rps - 1) / rps);
     YH_CHECK_ARG(splits <= 65528, "yh_conv_wgrad: too many splits");
+    // a single split needs no reduction: its tile goes straight to dw (the atomic form is then a plain add per element)
+    k.part = (d->partial && splits > 1) ? d->partial : nullptr;
+    k.pn = (d->N + 7) / 8 * 8;
+    k.pk = k.Kseg;
 #define YH_WG(WN_, WC_, TNW_, TCW_, TK_, MINW_, NT_, PF2_)                                                      \
     do {                                                                                                        \
         dim3 grid((NT_) * k.ctiles, (splits + 7) / 8 * 8);                                                      \
@@ -387,5 +490,13 @@ static int conv_wgrad_launch(const yh_wgrad_desc* d, yh_stream stream)
     }
 #undef YH_WG
     YH_CHECK_LAUNCH("yh_conv_wgrad");
+    if (k.part) {
+        const long items = (long)d->N * (k.Kseg / 4);
+        int sg = 1;
+        while (sg < 16 && sg * 8 < splits) sg *= 2;
+        wgrad_reduce_kernel<<<dim3((unsigned)((items + 63) / 64)), dim3(64, sg), 0, st>>>(k.part, splits, k.pn, k.pk, d->N, k.Kseg, d->seg.C, d->Ctot,
+                                                                                        d->coff_k, k.Ktot, d->dw);
+        YH_CHECK_LAUNCH("yh_conv_wgrad(reduce)");
+    }
     return YH_OK;
 }
