@@ -38,14 +38,9 @@ def make_hyp(dev, img, batch):
                 loss_items_on_device=True)
 
 
-def cpu_baseline(budget_s=20.0, batch=4, img=640):
-    """torch-CPU fp32 port (oracle/) of the same train step on a bounded sample: B=4 (BASELINE config #1)."""
-    from oracle.v5loss import V5LossOracle
-    from oracle.v5net import V5NetOracle
-    from yoloseries_amd import models
-    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
-    # the threads this process may actually run on (a 1-GPU box shares its host: affinity / cgroup share, not the
-    # socket's core count — 256 OpenMP threads on a 16-CPU share ran 40x slower than 16), capped at 16
+def _host_threads():
+    """the threads this process may actually run on (a 1-GPU box shares its host: affinity / cgroup share, not the socket's core
+    count — 256 OpenMP threads on a 16-CPU share ran 40x slower than 16), capped at 16"""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -57,7 +52,19 @@ def cpu_baseline(budget_s=20.0, batch=4, img=640):
                 cores = min(cores, max(1, int(int(q) / int(per))))
     except (OSError, ValueError):
         pass
-    cores = max(1, min(cores, 16))
+    return max(1, min(cores, 16))
+
+
+def cpu_baseline(budget_s=14.0, batch=4, img=640):
+    """torch-CPU / NumPy fp32 port (oracle/) of the same path on a bounded sample at B=4 (BASELINE config #1), both legs of
+    BASELINE.md section 4: (fwd + loss + bwd + SGD) and (decode + candidate filter + class-aware NMS on the synthetic NMS stress
+    heads), each 1 warm-up + the median of up to 5 runs inside the time budget."""
+    from oracle import postproc as opp
+    from oracle.v5loss import V5LossOracle
+    from oracle.v5net import V5NetOracle
+    from yoloseries_amd import models
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_nms_heads, synth_targets
+    cores = _host_threads()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = V5NetOracle(models.YOLOV5Small(3, 80).state_dict(), train=True)
@@ -67,7 +74,7 @@ def cpu_baseline(budget_s=20.0, batch=4, img=640):
     t = synth_targets(batch, img, 80, 20, seed=1)
     times = []
     t_begin = time.time()
-    for it in range(4):
+    for it in range(6):
         t0 = time.time()
         out = lossf(net(x), t)
         out["tot_loss"].backward()
@@ -76,9 +83,25 @@ def cpu_baseline(budget_s=20.0, batch=4, img=640):
         if it >= 1 and time.time() - t_begin > budget_s:
             break
     steady = times[1:] if len(times) > 1 else times
+    # decode + filter + NMS (NumPy fp32, one thread: the reference's evaluator is a per-image Python / numba loop)
+    heads = synth_nms_heads(batch, img, 80, 3, seed=2, wh_shift=1.2)
+    ntimes, kept = [], 0
+    t_begin = time.time()
+    for it in range(6):
+        t0 = time.time()
+        dec = opp.decode_v5(heads, COCO_ANCHORS, (8, 16, 32))
+        res = opp.postprocess_v5(dec, 0.001, 0.001, 0.65)
+        ntimes.append(time.time() - t0)
+        kept = sum(0 if r is None else len(r) for r in res)
+        if it >= 1 and time.time() - t_begin > 0.6 * budget_s:
+            break
+    nsteady = ntimes[1:] if len(ntimes) > 1 else ntimes
     return {"value": round(batch / float(np.median(steady)), 3), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{len(steady)} train steps (fwd+loss+bwd+SGD) of YOLOv5s at batch {batch}, {img}x{img}, "
-            f"torch-CPU fp32 oracle, after 1 warm-up"}
+            "kind": "port", "sample": f"median of {len(steady)} train steps (fwd+loss+bwd+SGD) of YOLOv5s at batch {batch}, {img}x{img}, "
+            f"torch-CPU fp32 oracle, after 1 warm-up",
+            "decode_nms": {"value": round(batch / float(np.median(nsteady)), 3), "unit": "images/sec", "cores": 1,
+                           "sample": f"median of {len(nsteady)} runs of decode + filter(conf 0.001) + class-aware NMS(0.65) on {batch} synthetic "
+                           f"head sets at {img}x{img} (~1 % of the anchors are candidates, {kept // batch} boxes kept per image), NumPy fp32 oracle"}}
 
 
 def parse_args(argv=None):
@@ -405,19 +428,41 @@ def _lib_sha16():
 PMC_WORKLOAD = None      # "<workload>:<model>:<batch>:<img>" of this run, set by main()
 
 
-def _pmc_traffic():
-    """per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py): counters cannot be read from
-    inside the process.  The file is stamped with the hash of the libyolohip.so it was collected with and with the workload
-    it was collected on; a different library or workload means the numbers describe other kernels / other shapes, and they
-    are dropped (null) instead of being reported stale."""
+def _pmc_file(fname):
+    """a committed PMC summary (profiles/<fname>) if it was collected with THIS library on THIS workload, else None"""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fname)) as f:
             j = json.load(f)
     except (OSError, ValueError):
         return None
     if j.get("lib_sha16") != _lib_sha16() or j.get("workload", "train:small:64:640") != PMC_WORKLOAD:
         return None
     return j
+
+
+def _pmc_mfma_util(pmc, name):
+    """matrix-unit utilisation of an engine kernel family from the MFMA PMC pass (tools/pmc_mfma.py)"""
+    if pmc is None:
+        return None
+    for n in _PMC_ALIAS.get(name, (name.replace("yh_", "") + "_kernel", name)):
+        if n in pmc["kernels"]:
+            return pmc["kernels"][n]["mfma_util"]
+    return None
+
+
+def _pmc_traffic():
+    """per-kernel HBM bytes from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py): counters cannot be read from
+    inside the process.  The file is stamped with the hash of the libyolohip.so it was collected with and with the workload
+    it was collected on; a different library or workload means the numbers describe other kernels / other shapes, and they
+    are dropped (null) instead of being reported stale."""
+    return _pmc_file(_pmc_name("pmc_traffic"))
+
+
+def _pmc_name(stem):
+    """profiles/pmc_traffic.json belongs to the judged line; the other workloads keep theirs next to it"""
+    if PMC_WORKLOAD in (None, "train:small:64:640"):
+        return stem + ".json"
+    return stem + "_" + PMC_WORKLOAD.replace(":", "_") + ".json"
 
 
 _PMC_ALIAS = {"yh_bn_silu_bwd_reduce": ("col_reduce_kernel<0>",), "yh_colsum": ("col_reduce_kernel<1>", "colsum_finalize_kernel"),
@@ -433,7 +478,22 @@ def _pmc_bytes(pmc, name):
     return sum(vals) if vals else None
 
 
-def _family_roofline(name, d, pmc):
+def _limiter(name, f_mfma, f_hbm, traffic, algo_bytes):
+    """what binds a kernel family that sits under 30 % of BOTH roofs (measured in DESIGN.md section 5, not inferred here)"""
+    if max(f_mfma, f_hbm) >= 0.3:
+        return "mfma" if f_mfma >= f_hbm else "hbm"
+    if name.startswith("conv_wgrad"):
+        return "split-M epilogue: fp32 atomics / partial tiles per block (work per block too small to amortise a 64 KB tile)"
+    if name.startswith(("yh_bn_finalize", "yh_bn_bwd_finalize", "yh_colsum")):
+        return "launch latency (a few microseconds of work per launch)"
+    if traffic and algo_bytes and traffic > 1.5 * algo_bytes:
+        return "hbm re-reads (traffic well above the algorithmic bytes)"
+    if name.startswith(("conv_v2", "conv_v3", "conv_halo", "conv_dg2", "conv_stem", "conv_igemm")):
+        return "issue / barrier per k-step and per-tile fixed costs (ablation builds, DESIGN.md section 5)"
+    return "latency"
+
+
+def _family_roofline(name, d, pmc, pmc_mfma=None):
     """roofline entry of one kernel family from its algorithmic work and measured duration: the bound is the roof the family sits
     closer to (conv tiles with little reuse — 1x1 layers, the stage-1 layers — are HBM-bound, K-heavy ones MFMA-bound)"""
     sec = d["ms"] * 1e-3
@@ -443,7 +503,8 @@ def _family_roofline(name, d, pmc):
     traffic = _pmc_bytes(pmc, name)
     common = {"kernel": name, "traffic": traffic, "avg_launch_us": round(1000 * d["ms"] / d["launches"], 2),
               "flops_per_launch": round(d["flops"] / d["launches"]), "bytes_per_launch": round(d["bytes"] / d["launches"]),
-              "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4)}
+              "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4), "mfma_util": _pmc_mfma_util(pmc_mfma, name),
+              "limiter": _limiter(name, f_mfma, f_hbm, traffic, d["bytes"] / d["launches"])}
     if f_mfma >= f_hbm:
         return {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f_mfma, 4), **common}
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_hbm, 4), **common}
@@ -472,8 +533,9 @@ def measure_roofline(model, step, B, nsteps=3):
     if not work:
         return None
     pmc = _pmc_traffic()
+    pmc_mfma = _pmc_file(_pmc_name("pmc_mfma"))
     dom = max(work, key=lambda k: work[k]["ms"])
-    roof = _family_roofline(dom, work[dom], pmc)
+    roof = _family_roofline(dom, work[dom], pmc, pmc_mfma)
     mfma_fams = {k: v for k, v in work.items() if v["flops"] > 0 and
                  v["flops"] / MFMA_PEAK_TFLOPS / 1e12 >= v["bytes"] / HBM_PEAK_GBS / 1e9}
     conv_dom = max(mfma_fams, key=lambda k: mfma_fams[k]["ms"]) if mfma_fams else None
@@ -489,7 +551,7 @@ def measure_roofline(model, step, B, nsteps=3):
     roof.update({"mode": "kernels back to back (side stream off)", "launches_per_step": work[dom]["launches"] // nsteps,
                  "overlapped": overlapped})
     if conv_dom is not None:
-        roof["conv"] = _family_roofline(conv_dom, mfma_fams[conv_dom], pmc)
+        roof["conv"] = _family_roofline(conv_dom, mfma_fams[conv_dom], pmc, pmc_mfma)
         roof["conv"]["ms_per_step"] = round(mfma_fams[conv_dom]["ms"] / nsteps, 3)
     # all MFMA work of the step against the time its kernels take (weighted mean over the conv / wgrad families)
     cf = sum(v["flops"] for v in work.values())
@@ -498,6 +560,7 @@ def measure_roofline(model, step, B, nsteps=3):
     roof["algorithmic_hbm_bytes_per_step"] = round(sum(v["bytes"] for v in work.values()) / nsteps)
     # whole step (engine kernels + loss + optimizer + packing) as the PMC passes saw it; null when the file is stale or absent
     roof["hbm_bytes_per_step"] = round(pmc["hbm_bytes_per_step"]) if pmc is not None and pmc.get("hbm_bytes_per_step") else None
+    roof["mfma_util_step"] = pmc_mfma.get("mfma_util_all_kernels") if pmc_mfma else None
     roof["family_ms_per_step"] = {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
     roof["engine_kernel_ms_per_step"] = round(total_ms, 3)
     return roof

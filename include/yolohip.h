@@ -179,6 +179,11 @@ int yh_bn_finalize(const float* stats, int nblk, int ldstat, int C, int64_t coun
 /* inference fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale         */
 int yh_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv,
                float eps, int C, float* scale, float* shift, yh_stream stream);
+/* BatchNorm in evaluation mode inside a differentiable forward (nn.BatchNorm2d.eval() with autograd on): the workspace the
+ * BN+SiLU passes read — scale | shift | mean | invstd, 4*C floats like yh_bn_finalize's — from the RUNNING statistics; the running
+ * statistics are not updated.  The backward of such a layer is yh_bn_bwd_finalize with its `coef` output zeroed (no batch-mean
+ * terms: gz = gamma * invstd * dz).  utils/layer_tools.py:90-91 under model.eval() */
+int yh_bn_frozen(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* ws, yh_stream stream);
 /* the same for every BatchNorm of a network in one launch: `items_dev` is a table of nitems entries in DEVICE memory
  * (the pointers inside it are device pointers; built once per program by the caller)                                 */
 typedef struct yh_bn_fold_item {
@@ -405,7 +410,9 @@ int yh_decode_filter(const yh_decode_desc* d, const void* const* preds, float co
  *  the predictions (same result; for small heads).                                                                     */
 size_t yh_decode_filter_ws_bytes(const yh_decode_desc* d);
 /* The same filter applied to an already decoded (B, N, 5+nc) fp32 tensor — the argument of
- * YOLOV5Evaluator.numba_nms (trainer/eval_yolov5.py:261-286); used after TTA merging.      */
+ * YOLOV5Evaluator.numba_nms (trainer/eval_yolov5.py:261-286); used after TTA merging.  `yolox`: 0 YOLOv5 single label,
+ * 1 YOLOX, 2 YOLOv5 multi-label (hyp['mutil_label'], :276-279: one candidate per (prediction, class) with cls*obj >= cls_thr,
+ * in (prediction, class) order; ncand may exceed cap — rows past cap are counted, not stored: the caller re-runs with more). */
 int yh_filter_decoded(const float* dec, int B, int N, int num_class, float conf_thr, float cls_thr, int yolox,
                       float* cand, int32_t* ncand, int cap, yh_stream stream);
 /* Greedy NMS per image on candidate lists, selection order = reference order.

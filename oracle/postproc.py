@@ -90,15 +90,20 @@ def decode_yolox(stage_preds, img_h):
     return np.concatenate(outs, axis=1)
 
 
-def candidates_v5(x_img, conf_thr, cls_thr):
+def candidates_v5(x_img, conf_thr, cls_thr, multi_label=False):
     """Rows of one image (N, 5+nc) -> candidate table (M,6) [xmin,ymin,xmax,ymax,conf,cls]
-    trainer/eval_yolov5.py:266-286 (single-label branch): obj >= conf ; cls*obj ; argmax ; > cls_thr."""
+    trainer/eval_yolov5.py:266-286.  Single-label branch (:280-286): obj >= conf ; cls*obj ; argmax ; > cls_thr.
+    Multi-label branch (:276-279, hyp['mutil_label']): every (row, class) with cls*obj >= cls_thr is a candidate of its own,
+    in row-major order (np.nonzero)."""
     x = np.asarray(x_img, dtype=F32)
     x = x[x[:, 4] >= F32(conf_thr)].copy()
     if len(x) == 0:
         return np.zeros((0, 6), F32)
     x[:, 5:] *= x[:, 4:5]
     box = xywh2xyxy(x[:, :4])
+    if multi_label:
+        ri, ci = (x[:, 5:] >= F32(cls_thr)).nonzero()
+        return np.concatenate((box[ri], x[ri, ci + 5][:, None], ci[:, None].astype(F32)), axis=1).astype(F32)
     conf = x[:, 5:].max(axis=1)
     cls = x[:, 5:].argmax(axis=1).astype(F32)
     out = np.concatenate((box, conf[:, None], cls[:, None]), axis=1).astype(F32)
@@ -139,11 +144,11 @@ def nms_image(cand, iou_thr, class_aware, max_keep, merge_filter, inclusive=True
     return x[keep], [int(k) for k in keep]
 
 
-def postprocess_v5(decoded, conf_thr, cls_thr, iou_thr, class_aware=True, max_keep=300, merge_filter=True):
+def postprocess_v5(decoded, conf_thr, cls_thr, iou_thr, class_aware=True, max_keep=300, merge_filter=True, multi_label=False):
     """YOLOV5Evaluator.numba_nms (trainer/eval_yolov5.py:261-317): list per image of (n,6) or None."""
     outs = []
     for i in range(decoded.shape[0]):
-        cand = candidates_v5(decoded[i], conf_thr, cls_thr)
+        cand = candidates_v5(decoded[i], conf_thr, cls_thr, multi_label)
         rows, _ = nms_image(cand, iou_thr, class_aware, max_keep, merge_filter)
         outs.append(rows if rows is not None else None)
     return outs

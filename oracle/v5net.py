@@ -12,9 +12,12 @@ import torch.nn.functional as F
 
 
 class V5NetOracle:
-    def __init__(self, state_dict, train=False, momentum=0.03, eps=1e-3):
+    def __init__(self, state_dict, train=False, momentum=0.03, eps=1e-3, grad=None):
+        """train: BatchNorm on batch statistics (and running-statistics update); grad: parameters require gradients
+        (default: == train; grad=True with train=False is model.eval() under autograd — BatchNorm on its running statistics)"""
         self.sd = {k: v.detach().to("cpu", torch.float32).clone() for k, v in state_dict.items() if v.dtype.is_floating_point}
         self.train = train
+        self.grad = train if grad is None else grad
         self.momentum, self.eps = momentum, eps
         self.params = {}
 
@@ -27,9 +30,9 @@ class V5NetOracle:
         return self.params[key]
 
     def cba(self, x, name, k, s, pad):
-        w = self.p(name + ".conv.weight", self.train)
+        w = self.p(name + ".conv.weight", self.grad)
         y = F.conv2d(x, w, None, s, pad)
-        g, b = self.p(name + ".bn.weight", self.train), self.p(name + ".bn.bias", self.train)
+        g, b = self.p(name + ".bn.weight", self.grad), self.p(name + ".bn.bias", self.grad)
         rm, rv = self.sd[name + ".bn.running_mean"], self.sd[name + ".bn.running_var"]
         y = F.batch_norm(y, rm, rv, g, b, self.train, self.momentum, self.eps)
         return F.silu(y)
@@ -75,7 +78,7 @@ class V5NetOracle:
         large = self.c3(x, "head_stage4_bscp", False)
         outs = []
         for n, t in (("detect.detect_small", small), ("detect.detect_mid", mid), ("detect.detect_large", large)):
-            outs.append(F.conv2d(t, self.p(n + ".weight", self.train), self.p(n + ".bias", self.train)))
+            outs.append(F.conv2d(t, self.p(n + ".weight", self.grad), self.p(n + ".bias", self.grad)))
         return tuple(outs)
 
     def sgd_step(self, lr=0.01):

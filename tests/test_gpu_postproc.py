@@ -39,6 +39,31 @@ def test_nms_golden(dev, key):
             np.testing.assert_array_equal(o, g[f"{key}_out{i}"])
 
 
+def test_nms_multi_label_golden(dev):
+    """hyp['mutil_label'] (trainer/eval_yolov5.py:276-279): every (prediction, class) with cls*obj >= cls_thr enters NMS as a
+    candidate of its own — rows and pick order of the reference evaluator, bit for bit, both through numba_nms(decoded) and
+    with a candidate table that has to grow (more candidates than predictions)"""
+    from yoloseries_amd.trainer import YOLOV5Evaluator
+    g = np.load(os.path.join(G, "g12_round3.npz"))
+    dec = g["ml_dec"]
+    ev = YOLOV5Evaluator(None, torch.from_numpy(COCO_ANCHORS), _hyp(dev, nc=dec.shape[2] - 5, img=320, mutil_label=True))
+    outs = ev.numba_nms(torch.from_numpy(dec).to(dev))
+    assert [(-1 if o is None else len(o)) for o in outs] == list(g["ml_n"])
+    for i, o in enumerate(outs):
+        if o is not None:
+            np.testing.assert_array_equal(o, g[f"ml_out{i}"])
+    assert max(ev.last_ncand) > dec.shape[1]              # the table grew past one row per prediction
+    # and against the oracle on fresh inputs with many classes per box
+    r = np.random.RandomState(77)
+    d2 = r.uniform(0, 1, (2, 300, 5 + 8)).astype(np.float32)
+    d2[..., :2] = r.uniform(20, 300, (2, 300, 2)); d2[..., 2:4] = r.uniform(10, 60, (2, 300, 2))
+    ev2 = YOLOV5Evaluator(None, torch.from_numpy(COCO_ANCHORS), _hyp(dev, nc=8, img=320, mutil_label=True, conf_threshold=0.2, cls_threshold=0.1))
+    got = ev2.numba_nms(torch.from_numpy(d2).to(dev))
+    exp = opp.postprocess_v5(d2, 0.2, 0.1, 0.2, multi_label=True)
+    for a, b in zip(got, exp):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_numba_nms_function(dev):
     from yoloseries_amd import utils as U
     g = np.load(os.path.join(G, "g5_nms.npz"))

@@ -261,3 +261,15 @@ def test_letterbox_resize_paths():
     small = rs.randint(0, 256, size=(100, 200, 3), dtype=np.uint8)
     out3, info3 = letter_resize_img(small, 640, only_ds=True)
     assert info3['scale'] == 1.0 and out3.shape == (640, 640, 3)
+
+
+def test_g12_multi_label_candidates():
+    """hyp['mutil_label'] (trainer/eval_yolov5.py:276-279): one candidate per (prediction, class) — the oracle's rows and pick
+    order equal the reference evaluator's, bit for bit"""
+    g = load("g12_round3.npz")
+    outs = postproc.postprocess_v5(g["ml_dec"], 0.3, 0.3, 0.2, class_aware=True, max_keep=300, merge_filter=True, multi_label=True)
+    assert [(-1 if o is None else len(o)) for o in outs] == list(g["ml_n"])
+    assert max(g["ml_n"]) > 40
+    for i, o in enumerate(outs):
+        if o is not None:
+            np.testing.assert_array_equal(o, g[f"ml_out{i}"])

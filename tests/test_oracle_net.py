@@ -117,3 +117,28 @@ def test_oracle_v5mlx_vs_reference_model(name):
     for pn, tol in (("focus", 1e-5), ("backbone_stage2_conv", 1e-4), ("backbone_stage4_conv", 1e-4), ("head_stage4_bscp.cba3", 5e-4)):
         _near(net.sd[pn + ".bn.running_mean"].numpy(), g[f"{name}_rm_{pn}"], f"v5{name} {pn} running_mean", tol)
         _near(net.sd[pn + ".bn.running_var"].numpy(), g[f"{name}_rv_{pn}"], f"v5{name} {pn} running_var", tol)
+
+
+def test_oracle_v5s_eval_mode_gradients_vs_reference():
+    """model.eval() under autograd (BatchNorm on its running statistics, no batch coupling): the net oracle's outputs and the
+    gradient of EVERY parameter against the reference's (g12_round3.npz: signature + 256 sampled elements per parameter)"""
+    g = np.load(os.path.join(G, "g12_round3.npz"))
+    seed = int(g["v5s_frozen_seed"][0])
+    m = _model_cls("s")(3, 80)
+    fill_state(m, seed)
+    net = V5NetOracle(m.state_dict(), train=False, grad=True)
+    x = torch.from_numpy(np.random.RandomState(1201).rand(2, 3, 256, 256).astype(np.float32))
+    outs = net(x)
+    r = np.random.RandomState(seed + 1)
+    gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)) for o in outs]
+    for i, o in enumerate(outs):
+        _near(o.detach().reshape(-1).numpy()[g[f"v5s_frozen_out_idx{i}"]], g[f"v5s_frozen_out_val{i}"], f"eval-mode out{i}")
+    names = [str(n) for n in g["v5s_frozen_pnames"]]
+    assert names == [n for n, _ in m.named_parameters()]
+    grads = torch.autograd.grad(outs, [net.params[n] for n in names], gos)
+    for pi, (n, gr) in enumerate(zip(names, grads)):
+        gf = gr.double().reshape(-1).numpy()
+        s_sum, s_abs, s_norm, s_size, s_max = g["v5s_frozen_psig"][pi]
+        assert gf.size == int(s_size)
+        assert abs(np.sqrt((gf ** 2).sum()) - s_norm) <= 1e-4 * s_norm + 1e-9, n
+        assert np.abs(gf[g["v5s_frozen_pidx"][pi]] - g["v5s_frozen_pval"][pi]).max() <= 1e-4 * s_max + 1e-9, n

@@ -83,6 +83,9 @@ def main():
     if sys.argv[1:] == ["--only", "g11"]:
         gen_g11(ref_utils, ref_models)
         return
+    if sys.argv[1:] == ["--only", "g12"]:
+        gen_g12(ref_models, ref_trainer)
+        return
     from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_head_outputs, synth_targets
 
     os.makedirs(OUT, exist_ok=True)
@@ -461,6 +464,7 @@ def main():
 
     gen_g10(ref_utils)
     gen_g11(ref_utils, ref_models)
+    gen_g12(ref_models, ref_trainer)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden written:", sorted(os.listdir(OUT)), f"{total / 1e6:.2f} MB")
 
@@ -610,6 +614,87 @@ def gen_g11(ref_utils, ref_models):
     g["soft_exp_giou"] = ref_utils.gpu_exponential_soft_nms(torch.from_numpy(eb), torch.from_numpy(es.copy()), "giou", 0.3, 0.5, 0.001).numpy()
     np.savez_compressed(os.path.join(OUT, "g11_round2.npz"), **g)
     print("g11 written", os.path.getsize(os.path.join(OUT, "g11_round2.npz")) / 1e6, "MB")
+
+
+def gen_g12(ref_models, ref_trainer):
+    """G12 (round 3): (a) a WELL-CONDITIONED full-graph gradient check — YOLOv5s and YOLOXs with BatchNorm in evaluation mode
+    (model.eval(): running statistics, no batch coupling) under autograd, state filled from a RandomState: output samples and,
+    for every parameter, the gradient's signature plus 256 sampled elements.  Isolates the concat / upsample / residual / stacked
+    GEMM gradient wiring from the batch-statistics chaos of train mode, so the bar can be tight.
+    (b) YOLOV5Evaluator.numba_nms with hyp['mutil_label'] = True (trainer/eval_yolov5.py:276-279)."""
+    import torch
+    g = {}
+
+    def frozen_bwd(key, make, seed, x, outs_of):
+        m = make()
+        fill_state_rs(m, seed)
+        m.eval()
+        xt = torch.from_numpy(x.copy())
+        outs = outs_of(m(xt))
+        r = np.random.RandomState(seed + 1)
+        gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)) for o in outs]
+        grads = torch.autograd.grad(outs, list(m.parameters()), gos)
+        g[f"{key}_seed"] = np.array([seed])
+        for i, o in enumerate(outs):
+            flat = o.detach().numpy().reshape(-1)
+            idx = np.random.RandomState(seed + 10 + i).randint(0, flat.size, 4096)
+            g[f"{key}_out_shape{i}"] = np.array(o.shape)
+            g[f"{key}_out_idx{i}"], g[f"{key}_out_val{i}"] = idx.astype(np.int64), flat[idx]
+        names, sig, sidx, sval = [], [], [], []
+        for pi, ((n, p), gr) in enumerate(zip(m.named_parameters(), grads)):
+            gf = gr.detach().double().numpy().reshape(-1)
+            names.append(n)
+            sig.append([gf.sum(), np.abs(gf).sum(), np.sqrt((gf ** 2).sum()), float(gf.size), np.abs(gf).max()])
+            si = np.random.RandomState(seed + 100 + pi).randint(0, gf.size, 256)
+            sidx.append(si)
+            sval.append(gf[si])
+        g[f"{key}_pnames"] = np.array(names)
+        g[f"{key}_psig"] = np.array(sig)
+        g[f"{key}_pidx"] = np.array(sidx, np.int64)
+        g[f"{key}_pval"] = np.array(sval)
+        # calibration: the reference ITSELF under torch bf16 autocast, same state and inputs — per parameter the largest sampled
+        # element error relative to the largest gradient element, and the relative error of the norm
+        m2 = make()
+        fill_state_rs(m2, seed)
+        m2.eval()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            outs2 = [o.float() for o in outs_of(m2(torch.from_numpy(x.copy())))]
+        grads2 = torch.autograd.grad(outs2, list(m2.parameters()), gos)
+        cal = []
+        for pi, gr in enumerate(grads2):
+            gl = gr.detach().double().numpy().reshape(-1)
+            cal.append([np.abs(gl[sidx[pi]] - sval[pi]).max() / (sig[pi][4] + 1e-30), abs(np.sqrt((gl ** 2).sum()) - sig[pi][2]) / (sig[pi][2] + 1e-30)])
+        g[f"{key}_pcal"] = np.array(cal)
+    xs = np.random.RandomState(1201).rand(2, 3, 256, 256).astype(np.float32)
+    frozen_bwd("v5s_frozen", lambda: ref_models.YOLOV5Small(3, 80), 1210, xs, lambda o: list(o))
+    xx = np.random.RandomState(1202).rand(2, 3, 256, 256).astype(np.float32)
+    frozen_bwd("yolox_frozen", lambda: ref_models.YOLOXSmall(1, 3, 80, 0.01), 1220, xx, lambda o: list(o.values()))
+
+    # ---- multi-label candidates: every class whose cls*obj reaches the threshold makes a row of its own
+    from yoloseries_amd.utils.synth import COCO_ANCHORS
+    nc = 6
+    r = np.random.RandomState(1230)
+    B, N = 3, 400
+    dec = np.zeros((B, N, 5 + nc), np.float32)
+    for b in range(B):
+        c = r.uniform(30, 290, (12, 2)); wh = r.uniform(20, 80, (12, 2))
+        for i in range(N):
+            k = r.randint(12)
+            cls = r.uniform(0.0, 0.25, nc)
+            hot = r.choice(nc, size=r.randint(1, 4), replace=False)
+            cls[hot] = r.uniform(0.45, 1.0, len(hot))
+            dec[b, i] = np.concatenate([c[k] + r.uniform(-6, 6, 2), wh[k] * r.uniform(0.85, 1.2, 2), [r.uniform(0.05, 1.0)], cls])
+    dec[2, :, 4] = 0.01                          # an image without candidates
+    h = make_hyp(num_class=nc, img=320, mutil_label=True)
+    e = ref_trainer.YOLOV5Evaluator(None, torch.from_numpy(COCO_ANCHORS.copy()), h, compute_metric=False)
+    res = e.numba_nms(torch.from_numpy(dec.copy()))
+    g["ml_dec"] = dec
+    g["ml_n"] = np.array([-1 if q is None else len(q) for q in res])
+    for i, q in enumerate(res):
+        if q is not None:
+            g[f"ml_out{i}"] = np.asarray(q, np.float32)
+    np.savez_compressed(os.path.join(OUT, "g12_round3.npz"), **g)
+    print("g12 written", os.path.getsize(os.path.join(OUT, "g12_round3.npz")) / 1e6, "MB", g["ml_n"])
 
 
 def gen_g10(ref_utils):

@@ -139,6 +139,7 @@ _SIGS = {
     "yh_conv_kernel_name": (_i32, [C.POINTER(ConvDesc), C.c_char_p, _i32]),
     "yh_bn_finalize": (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
     "yh_bn_fold": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp]),
+    "yh_bn_frozen": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp]),
     "yh_bn_fold_batch": (_i32, [_vp, _i32, _vp]),
     "yh_bn_silu_apply": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
     "yh_bn_silu_apply_acc": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _i32, _vp]),

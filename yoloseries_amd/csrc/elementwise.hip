@@ -116,6 +116,20 @@ __global__ void bn_fold_kernel(const float* gamma, const float* beta, const floa
     shift[c] = beta[c] - rm[c] * s;
 }
 
+// BatchNorm in evaluation mode inside a differentiable forward (model.eval() with gradients enabled, as torch runs
+// nn.BatchNorm2d then): the constants of the BN+SiLU passes come from the running statistics; ws = scale | shift | mean | invstd
+__global__ void bn_frozen_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* ws)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+    const float s = gamma[c] * invstd;
+    ws[c] = s;
+    ws[C + c] = beta[c] - rm[c] * s;
+    ws[2 * C + c] = rm[c];
+    ws[3 * C + c] = invstd;
+}
+
 // every BatchNorm of a network in ONE launch: block b folds item b (a table in device memory)
 __global__ void bn_fold_batch_kernel(const yh_bn_fold_item* items)
 {
@@ -821,6 +835,14 @@ extern "C" int yh_bn_fold(const float* gamma, const float* beta, const float* rm
     YH_CHECK_ARG(gamma && beta && rm && rv && scale && shift && C > 0, "yh_bn_fold: bad args");
     hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps, C, scale, shift);
     YH_CHECK_LAUNCH("yh_bn_fold");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_frozen(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* ws, yh_stream stream)
+{
+    YH_CHECK_ARG(gamma && beta && rm && rv && ws && C > 0, "yh_bn_frozen: bad args");
+    hipLaunchKernelGGL(bn_frozen_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta, rm, rv, eps, C, ws);
+    YH_CHECK_LAUNCH("yh_bn_frozen");
     return YH_OK;
 }
 

@@ -255,6 +255,62 @@ __global__ __launch_bounds__(1024) void decode_gather_kernel(const float* __rest
     if (t == 0) ncand[b] = base_s;
 }
 
+// Multi-label candidate filter (hyp['mutil_label'], eval_yolov5.py:276-279): every (prediction, class) with cls*obj >= cls_thr
+// among the predictions with obj >= conf_thr is a candidate of its own; rows in (prediction, class) order like np.nonzero.
+// A thread counts its prediction's classes, a wave / block prefix sum places them.
+__global__ __launch_bounds__(1024) void filter_decoded_multi_kernel(const float* __restrict__ dec, int N, int nc, float conf_thr,
+                                                                    float cls_thr, float* __restrict__ cand, int32_t* __restrict__ ncand, int cap)
+{
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int E = 5 + nc;
+    if (t == 0) base_s = 0;
+    __syncthreads();
+    float* out = cand + (size_t)b * cap * 6;
+    for (int p0 = 0; p0 < N; p0 += 1024) {
+        const int pi = p0 + t;
+        const float* row = dec + ((size_t)b * N + (pi < N ? pi : 0)) * E;
+        int cnt = 0;
+        float obj = 0.f;
+        if (pi < N) {
+            obj = row[4];
+            if (obj >= conf_thr)
+                for (int c = 0; c < nc; ++c) cnt += (row[5 + c] * obj >= cls_thr) ? 1 : 0;
+        }
+        int incl = cnt;                                   // inclusive prefix sum over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wave_cnt[wv] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { int c = wave_cnt[w]; if (w < wv) before += c; total += c; }
+        int pos = base_s + before + incl - cnt;
+        if (cnt > 0) {
+            const float x0 = row[0] - row[2] / 2.f, y0 = row[1] - row[3] / 2.f, x1 = row[0] + row[2] / 2.f, y1 = row[1] + row[3] / 2.f;
+            for (int c = 0; c < nc; ++c) {
+                const float sc = row[5 + c] * obj;
+                if (sc >= cls_thr) {
+                    if (pos < cap) {
+                        float* o = out + (size_t)pos * 6;
+                        o[0] = x0; o[1] = y0; o[2] = x1; o[3] = y1; o[4] = sc; o[5] = (float)c;
+                    }
+                    ++pos;
+                }
+            }
+        }
+        __syncthreads();
+        if (t == 0) base_s += total;
+        __syncthreads();
+    }
+    if (t == 0) ncand[b] = base_s;
+}
+
 // Candidate filter on an already decoded (B, N, 5+nc) fp32 tensor (the argument of
 // YOLOV5Evaluator.numba_nms, eval_yolov5.py:261-286), order preserving.
 __global__ __launch_bounds__(1024) void filter_decoded_kernel(const float* __restrict__ dec, int N, int nc, float conf_thr,
@@ -585,7 +641,11 @@ extern "C" int yh_filter_decoded(const float* dec, int B, int N, int num_class, 
                                  float* cand, int32_t* ncand, int cap, yh_stream stream)
 {
     YH_CHECK_ARG(dec && cand && ncand && B > 0 && N > 0 && num_class >= 1 && cap > 0 && cap % 4 == 0, "yh_filter_decoded: bad args");
-    hipLaunchKernelGGL(filter_decoded_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, dec, N, num_class, conf_thr, cls_thr, yolox, cand, ncand, cap);
+    YH_CHECK_ARG(yolox >= 0 && yolox <= 2, "yh_filter_decoded: mode must be 0 (YOLOv5), 1 (YOLOX) or 2 (YOLOv5 multi-label)");
+    if (yolox == 2)
+        hipLaunchKernelGGL(filter_decoded_multi_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, dec, N, num_class, conf_thr, cls_thr, cand, ncand, cap);
+    else
+        hipLaunchKernelGGL(filter_decoded_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, dec, N, num_class, conf_thr, cls_thr, yolox, cand, ncand, cap);
     YH_CHECK_LAUNCH("yh_filter_decoded");
     return YH_OK;
 }

@@ -809,7 +809,7 @@ class Program:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         prof = self.profile
         if prof is None and USE_EXEC and not BN_ACC:
-            key = 'train' if cmds is self.cmd_train else 'eval'
+            key = 'train' if cmds is self.cmd_train else ('frozen' if cmds is getattr(self, "cmd_frozen", None) else 'eval')
             cc = self._compiled.get(key)
             if cc is None or cc.source is not cmds:
                 cc = self._compiled[key] = self._compile(cmds)
@@ -830,7 +830,27 @@ class Program:
                 e1.record()
                 prof.setdefault(meta + (name,), []).append((e0, e1))
 
-    def forward(self, train):
+    def _frozen_cmds(self):
+        """the training program with every BatchNorm in evaluation mode (model.eval() under autograd): the finalize launches —
+        batch statistics -> constants, running-statistics update — give way to yh_bn_frozen (constants from the running
+        statistics); the conv kernels still emit their partial sums, nobody reads them"""
+        L, out = self.L, []
+        for cmd in self.cmd_train:
+            fn, args = cmd[0], cmd[1]
+            if fn is L.yh_bn_finalize:
+                _stats, _nblk, _ld, n, _M, gamma, beta, rm, rv, _nbt, eps, _mom, ws = args
+                out.append((L.yh_bn_frozen, (gamma, beta, rm, rv, eps, n, ws), cmd[2], ('yh_bn_frozen', 0, 0.0)))
+            elif fn is L.yh_bn_finalize_parts:
+                parts, nparts, _M = args
+                for i in range(nparts):
+                    q = parts[i]
+                    out.append((L.yh_bn_frozen, (q.gamma, q.beta, q.running_mean, q.running_var, float(q.eps), int(q.C), q.ws), cmd[2],
+                                ('yh_bn_frozen', 0, 0.0)))
+            else:
+                out.append(cmd)
+        return out
+
+    def forward(self, train, frozen=False):
         self.generation += 1
         # fresh head buffers every call: the returned views must not be overwritten by the next forward
         for o in self.outputs:
@@ -839,7 +859,14 @@ class Program:
                 self.op_state[o.name]['desc'].out0 = o.y.t.data_ptr()
         if train and self.cmd_train is None:
             self._build_train()
-        self._run(self.cmd_train if train else self.cmd_eval)
+        if train and frozen:
+            if BN_ACC:
+                raise YoloHipError("evaluation-mode BatchNorm under autograd is not available with YH_BN_ACC=1")
+            if getattr(self, "cmd_frozen", None) is None:
+                self.cmd_frozen = self._frozen_cmds()
+            self._run(self.cmd_frozen)
+        else:
+            self._run(self.cmd_train if train else self.cmd_eval)
         return self.generation
 
     # -- backward --------------------------------------------------------------------------
@@ -1115,6 +1142,7 @@ class Program:
                         self.bnr_fused[(po.name, ppi)] = (slab, rows)
                     cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C, self._conv_bytes(d))))
         self.cmd_bwd = cmds
+        self.cmd_bwd_frozen = None
         self.bwd_buckets = plan_grad_buckets(marks, pk.gsize, int(os.environ.get("YH_DP_BUCKETS", "4")))
         self.bwd_ready = True
         _tune_cache_save()
@@ -1192,13 +1220,32 @@ class Program:
         with torch.cuda.stream(side):
             return bucket_hook(part)
 
-    def _compile_backward(self, two, buckets):
+    def _frozen_bwd_cmds(self):
+        """backward of the evaluation-mode-BatchNorm forward: the same launches, with the batch-mean coefficients every
+        yh_bn_bwd_finalize leaves for the apply pass zeroed (gz = gamma * invstd * dz).  Command indices are preserved
+        for the gradient buckets: the fill rides in the finalize's slot as a pair."""
+        L, out = self.L, []
+        for cmd in self.cmd_bwd:
+            fn = cmd[0]
+            if fn is L.yh_bn_bwd_finalize:
+                coef_ptr = cmd[1][7]
+                out.append(('pair', [cmd, (L.yh_fill_u32, (coef_ptr, 0, 2 * cmd[1][2]), cmd[2], ('yh_fill_u32', 0, 0.0))], cmd[2], ('sync', 0, 0.0)))
+            elif fn is L.yh_bn_bwd_finalize_parts:
+                parts, nparts, _M = cmd[1]
+                fills = [(L.yh_fill_u32, (parts[i].coef, 0, 2 * int(parts[i].C)), cmd[2], ('yh_fill_u32', 0, 0.0)) for i in range(nparts)]
+                out.append(('pair', [cmd] + fills, cmd[2], ('sync', 0, 0.0)))
+            else:
+                out.append(cmd)
+        return out
+
+    def _compile_backward(self, two, buckets, cmd_bwd=None):
         """the backward command list as a yh_cmd array: kernels on stream 0 (main) / 1 (side: weight gradients), the event
         records and stream waits of the gz ring in between; returns (array, positions at which a gradient bucket is complete,
         per-call patches for the head gradients)"""
         L = self.L
-        cc = CompiledCmds(L, 2 * len(self.cmd_bwd) + 8)
-        cc.source = self.cmd_bwd
+        cmd_bwd = self.cmd_bwd if cmd_bwd is None else cmd_bwd
+        cc = CompiledCmds(L, 2 * len(cmd_bwd) + 8 + 4 * sum(1 for c in cmd_bwd if c[0] == 'pair'))
+        cc.source = cmd_bwd
         breaks, patches = [], []
         pending = [False] * NGZ
         if two:
@@ -1206,11 +1253,15 @@ class Program:
                 ev.record(self._side)
             ev_gz, ev_wg = self._ev_gz.cuda_event, [e.cuda_event for e in self._ev_wg]
         nb = 0
-        for ci, cmd in enumerate(self.cmd_bwd):
+        for ci, cmd in enumerate(cmd_bwd):
             while nb < len(buckets) and buckets[nb][0] == ci:
                 breaks.append(cc.n)
                 nb += 1
             fn = cmd[0]
+            if fn == 'pair':
+                for sub in cmd[1]:
+                    cc.call(sub[0], sub[1], 0, sub[2])
+                continue
             if fn == 'gz_begin':
                 if two and pending[cmd[1]]:
                     cc.event(YH_CMD_STREAM_WAIT, ev_wg[cmd[1]], 0)
@@ -1251,13 +1302,18 @@ class Program:
             nb += 1
         return cc, breaks, patches
 
-    def backward(self, head_grads, bucket_hook=None):
+    def backward(self, head_grads, bucket_hook=None, frozen=False):
         """head_grads: list of [B,h,w,ld] bf16 gradient buffers matching self.outputs (plain ops).
         bucket_hook(slice of the packed fp32 gradient arena) -> finisher or None: called as soon as a bucket of
         gradients is complete (data-parallel all-reduce overlapped with the remaining backward); finishers run
         before the gradients are scattered to parameter order."""
         if not self.bwd_ready:
             self._build_backward()
+        cmd_bwd = self.cmd_bwd
+        if frozen:
+            if self.cmd_bwd_frozen is None:
+                self.cmd_bwd_frozen = self._frozen_bwd_cmds()
+            cmd_bwd = self.cmd_bwd_frozen
         buckets = self.bwd_buckets if bucket_hook is not None else []
         nb, finishers = 0, []
         pk, L = self.pack, self.L
@@ -1287,10 +1343,10 @@ class Program:
             pending = [False] * NGZ
         if prof is None and USE_EXEC and not BN_ACC:
             # replay the compiled command array (yh_exec): one call per bucket segment instead of one ctypes call per launch
-            key = ('bwd', two, bucket_hook is not None)
+            key = ('bwd', two, bucket_hook is not None, frozen)
             comp = self._compiled.get(key)
-            if comp is None or comp[0].source is not self.cmd_bwd:
-                comp = self._compiled[key] = self._compile_backward(two, buckets)
+            if comp is None or comp[0].source is not cmd_bwd:
+                comp = self._compiled[key] = self._compile_backward(two, buckets, cmd_bwd)
             cc, breaks, patches = comp
             for kind, obj, opname, slot_idx in patches:          # head gradients arrive per call
                 ptr = heads[opname].data_ptr()
@@ -1315,11 +1371,17 @@ class Program:
                 if f is not None:
                     f()
             return pk.grads_to_params()
-        for ci, cmd in enumerate(self.cmd_bwd):
+        for ci, cmd in enumerate(cmd_bwd):
             while nb < len(buckets) and buckets[nb][0] == ci:
                 finishers.append(self._bucket_ready(bucket_hook, buckets[nb], main if two else None, side if two else None))
                 nb += 1
             fn = cmd[0]
+            if fn == 'pair':
+                for sub in cmd[1]:
+                    rc = sub[0](*sub[1], st)
+                    if rc:
+                        check(rc, f"{sub[0].__name__} bwd [{sub[2]}]")
+                continue
             if fn == 'gz_begin':
                 if two and pending[cmd[1]]:
                     main.wait_event(self._ev_wg[cmd[1]])
@@ -1389,7 +1451,8 @@ class _NetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, host, prog, x, *params):
-        gen = prog.forward(True)
+        ctx.frozen = not host.training                # model.eval() under autograd: BatchNorm on its running statistics
+        gen = prog.forward(True, frozen=ctx.frozen)
         ctx.prog, ctx.gen, ctx.host = prog, gen, host
         outs = host._yh_outputs(prog)
         ctx.out_meta = [(o.shape, o.stride()) for o in outs]
@@ -1425,7 +1488,7 @@ class _NetFn(torch.autograd.Function):
         owner = getattr(bucket_hook, "__self__", None)
         if owner is not None and not getattr(owner, "buckets_active", True):
             bucket_hook = None                                      # no_sync / accumulation boundary: no per-bucket segmentation
-        flat_g, pgrads = prog.backward(head_grads, bucket_hook)
+        flat_g, pgrads = prog.backward(head_grads, bucket_hook, frozen=ctx.frozen)
         ctx.host._yh_last_flat_grad = flat_g
         # whole-gradient hook of the data-parallel exchange: all-reduces flat_g when no bucket hook ran, keeps the
         # books of un-exchanged accumulation steps, and at an accumulation boundary swaps in the averaged total
@@ -1505,7 +1568,9 @@ class HipModuleMixin:
     def _yh_forward(self, prog, x):
         pk = prog.pack
         pk.repack()
-        if self.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in pk.params)):
+        # a differentiable forward runs the training program (raw conv outputs kept for the backward); in evaluation mode its
+        # BatchNorms use the running statistics, exactly as nn.BatchNorm2d.eval() does under autograd
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in pk.params)):
             return _NetFn.apply(self, prog, x, *pk.params)
         prog.forward(self.training)
         return tuple(self._yh_outputs(prog))

@@ -94,10 +94,6 @@ class YOLOV5Evaluator:
         check(lib().yh_decode_full(C.byref(d), ptrs, out.data_ptr(), _lib.stream_ptr()), "yh_decode_full")
         return out
 
-    def _check_cfg(self):
-        if self.hyp.get('mutil_label', False):
-            raise NotImplementedError("mutil_label=True is not implemented on the HIP path (false in every shipped config)")
-
     def _run_nms(self, cand, ncand, B, cap):
         dev = cand.device
         L = lib()
@@ -117,7 +113,8 @@ class YOLOV5Evaluator:
 
     def _nms_from_heads(self, stage_preds):
         """fused decode + filter + NMS straight from the head tensors (no decoded tensor is materialised)"""
-        self._check_cfg()
+        if self.hyp.get('mutil_label', False):          # one candidate per (prediction, class): through the decoded tensor (:276-279)
+            return self.numba_nms(self.decode(stage_preds))
         d, canon, ptrs = self._desc(stage_preds)
         dev = stage_preds[0].device
         B = d.B
@@ -135,7 +132,6 @@ class YOLOV5Evaluator:
 
     def numba_nms(self, preds_out):
         """:param preds_out: decoded (bs, N, 5+nc) tensor -> list of np.ndarray (n,6) or None (:261-317)"""
-        self._check_cfg()
         p = preds_out.detach().to(torch.float32).contiguous()
         if not p.is_cuda:
             dev = self.device if str(self.device).startswith("cuda") else "cuda:0"
@@ -143,10 +139,16 @@ class YOLOV5Evaluator:
         B, n, E = p.shape
         assert E == 5 + self.num_class
         cap = ((n + 3) // 4) * 4
-        cand = torch.empty(B, cap, 6, dtype=torch.float32, device=p.device)
-        ncand = torch.zeros(B, dtype=torch.int32, device=p.device)
-        check(lib().yh_filter_decoded(p.data_ptr(), B, n, self.num_class, float(self.conf_threshold), float(self.cls_threshold), 0,
-                                      cand.data_ptr(), ncand.data_ptr(), cap, _lib.stream_ptr()), "yh_filter_decoded")
+        mode = 2 if self.hyp.get('mutil_label', False) else 0
+        while True:
+            cand = torch.empty(B, cap, 6, dtype=torch.float32, device=p.device)
+            ncand = torch.zeros(B, dtype=torch.int32, device=p.device)
+            check(lib().yh_filter_decoded(p.data_ptr(), B, n, self.num_class, float(self.conf_threshold), float(self.cls_threshold), mode,
+                                          cand.data_ptr(), ncand.data_ptr(), cap, _lib.stream_ptr()), "yh_filter_decoded")
+            most = int(ncand.max().item()) if mode == 2 else 0       # multi-label: up to num_class candidates per prediction
+            if most <= cap:
+                break
+            cap = ((most + 3) // 4) * 4
         return self._run_nms(cand, ncand, B, cap)
 
     def test_time_augmentation(self, inputs):
