@@ -381,6 +381,45 @@ def test_conv_concat_upsample_algos(dev, algo):
     assert (out1[..., :32] == 0).all()
 
 
+@pytest.mark.parametrize("C0,C1,Cout,k", [(80, 80, 160, 1), (48, 80, 96, 1), (80, 48, 64, 3), (40, 24, 32, 1)])
+def test_conv_two_segments_ragged_first_segment(dev, C0, C1, Cout, k):
+    """a concat input whose FIRST segment is not a multiple of the 32-channel k-step (YOLOv5x stage 1 `cba3`: 80 + 80, YOLOv5m:
+    48 + ...): conv_v2_kernel walks the channel blocks per segment (ragged block masked, next segment starts its own block)
+    instead of falling back to the 64-bit-pointer kernel — folded BN + SiLU (inference) and raw output + statistics (training),
+    with NaN-filled neighbour channels around both slices"""
+    from yoloseries_amd import hipk
+    B, H, W = 2, 20, 12
+    p = k // 2
+    a_buf = _nhwc(B, H, W, C0 + 16, dev, 71); a_buf[..., C0:] = float("nan")
+    b_buf = _nhwc(B, H, W, C1 + 24, dev, 72); b_buf[..., :8] = float("nan"); b_buf[..., 8 + C1:] = float("nan")
+    g = torch.Generator().manual_seed(73)
+    w = (torch.randn(Cout, C0 + C1, k, k, generator=g) / (k * k * (C0 + C1)) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    segs = [hipk.Slice(a_buf, 0, C0), hipk.Slice(b_buf, 8, C1)]
+    xin = torch.cat([_nchw(a_buf[..., :C0]), _nchw(b_buf[..., 8:8 + C1])], 1)
+    ref = F.conv2d(xin, w, padding=p).permute(0, 2, 3, 1)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=g).to(dev)
+    out = torch.zeros(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    d = hipk.conv_desc(segs, hipk.YH_CONV_FWD, B, H, W, H, W, k, 1, p, wp, Cout, hipk.full(out), scale=scale, shift=shift, act=hipk.YH_ACT_SILU)
+    d.algo = 1
+    assert "conv_v2_kernel" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out, F.silu(ref * scale + shift), 8e-3, 2e-2)
+    out2 = torch.zeros(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    d2 = hipk.conv_desc(segs, hipk.YH_CONV_FWD, B, H, W, H, W, k, 1, p, wp, Cout, hipk.full(out2))
+    d2.algo = 1
+    stats = torch.zeros(hipk.conv_stat_blocks(d2), 2, wp.shape[0], device=dev)
+    d2.stats = stats.data_ptr()
+    assert "conv_v2_kernel" in _kname(d2), _kname(d2)
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    _close(out2, ref, 8e-3, 2e-2)
+    o = out2.float().reshape(-1, Cout).double()
+    assert ((stats[:, 0, :Cout].double().sum(0) - o.sum(0)).abs() <= 1e-2 + 4 * 2.0 ** -9 * (o ** 2).sum(0).sqrt()).all()
+
+
 @pytest.mark.parametrize("Cout", [32, 48, 64, 80])
 def test_conv_stem_kernel(dev, Cout):
     """the strip kernel of the stem (3x3 on the 16-channel space-to-depth image, 1..3 output tiles of 32 channels: v5s 32, v5m 48,

@@ -76,6 +76,8 @@ for name, H, Cin, Cout, k, s in shapes:
     res = []
     for algo in (1, 2, 3, 4, 5, 6, 7):
         d.algo = algo
+        d.tile_k = int(os.environ.get("BA_TILE_K", 0)) if algo == 7 else 0
+        d.tile_n = int(os.environ.get("BA_TILE_N", 0)) if algo == 7 else 0
         kn = kname(d)
         if (algo in (2, 3, 4) and "conv_v3" not in kn) or (algo == 5 and "conv_halo_kernel" not in kn) or (algo == 6 and "conv_halo160" not in kn) or \
                 (algo == 7 and "conv_dg2" not in kn):

@@ -30,8 +30,8 @@ __device__ __forceinline__ void dg_st_nt16(uint16_t* p, uint4 v) {
     __builtin_nontemporal_store(w, reinterpret_cast<u32x4_nt*>(p));
 }
 
-constexpr int DG_RPX = 128;         // region pixels per block
-constexpr int DG_PMAX = 168;        // most patch pixels (TH+1)*(TW+1)
+constexpr int DG_RPX1 = 128;        // region pixels per block and pixel tile (PT tiles of 32 pixels per wave: 128 * PT pixels per block)
+constexpr int dg_pmax(int pt) { return pt == 1 ? 168 : 304; }     // most patch pixels (TH+1)*(TW+1)
 
 struct Dg2K {
     const uint16_t* gz; int ldg, Nk;
@@ -44,19 +44,23 @@ struct Dg2K {
     unsigned gzbytes, wbytes;
 };
 
-template <int CT, int KC>
+template <int CT, int KC, int PT>
 constexpr int dg_smem_bytes() {
     // patch [PMAX][KC+8] | weights [9][32*CT][KC+8] | scale,shift [2][32*CT] floats;  the output staging (one row parity at a
-    // time: [2*128][32*CT+8]) aliases the patch (+ the weights when it is larger than the patch)
-    return (DG_PMAX + 9 * 32 * CT) * (KC + 8) * 2 + 2 * 32 * CT * 4;
+    // time: [2*128*PT][32*CT+8]) aliases the patch (+ the weights when it is larger than the patch)
+    const int main_b = (dg_pmax(PT) + 9 * 32 * CT) * (KC + 8) * 2;
+    const int stg_b = 2 * DG_RPX1 * PT * (32 * CT + 8) * 2;
+    return (main_b > stg_b ? main_b : stg_b) + 2 * 32 * CT * 4;
 }
 
-// block = 4*CT waves: wave (ct, q) multiplies the q-th 32 pixels of the region with the ct-th 32 output channels, all four
-// parity classes (4 x 16 accumulator registers); CB = 32*CT channels per block; KC gz channels per step
-template <int CT, int KC, int EPI>
+// block = 4*CT waves: wave (ct, q) multiplies PT tiles of 32 region pixels (q*PT .. q*PT+PT-1) with the ct-th 32 output channels,
+// all four parity classes (4 x PT x 16 accumulator registers); CB = 32*CT channels per block; KC gz channels per step
+template <int CT, int KC, int EPI, int PT>
 __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
 {
     constexpr int NT = 256 * CT;
+    constexpr int DG_RPX = DG_RPX1 * PT;
+    constexpr int DG_PMAX = dg_pmax(PT);
     constexpr int PITCH = KC + 8;                 // LDS row pitch in elements (80 / 144 bytes: conflict-free ds_read_b128)
     constexpr int CHR = KC / 8;                   // 16-byte chunks per patch pixel / weight row
     constexpr int CB = 32 * CT;                   // output channels of the block
@@ -65,17 +69,17 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
     constexpr int NWI = (9 * CB + PPP - 1) / PPP;                // weight chunks per thread
     constexpr int SP = CB + 8;                    // staging row pitch (elements)
     constexpr int CPR = CB / 8;                   // 16-byte chunks per staging row
-    constexpr int NOI = 2 * DG_RPX * CPR / NT;    // read-out items per thread and row parity (== 4)
+    constexpr int NOI = 2 * DG_RPX * CPR / NT;    // read-out items per thread and row parity (== 4 * PT)
     constexpr unsigned OOB = 0x80000000u;
     constexpr int PATCH_BYTES = DG_PMAX * PITCH * 2;
     constexpr int STG_BYTES = 2 * DG_RPX * SP * 2;
     constexpr bool STG_IN_PATCH = STG_BYTES <= PATCH_BYTES;        // then the weights survive the epilogue
-    static_assert(NT % CPR == 0 && NOI == 4, "read-out mapping");
+    static_assert(NT % CPR == 0 && NOI == 4 * PT, "read-out mapping");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* sP = reinterpret_cast<uint16_t*>(smem);
     uint16_t* sW = sP + DG_PMAX * PITCH;
-    float* sStat = reinterpret_cast<float*>(smem + (DG_PMAX + 9 * CB) * PITCH * 2);
+    float* sStat = reinterpret_cast<float*>(smem + dg_smem_bytes<CT, KC, PT>() - 2 * CB * 4);
     uint16_t* sStg = reinterpret_cast<uint16_t*>(smem);
 
     const int t = threadIdx.x;
@@ -107,12 +111,17 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
         ppij[j] = pp < p.npatch ? (pi << 8) | (pp - pi * TWp) : -1;
     }
     // MFMA fragments: region pixel of this lane (B operand column) and its patch position
-    const int rpx = wq * 32 + (lane & 31);
-    const bool rvalid = rpx < p.TH * p.TW;
-    const int ri = rvalid ? rpx / p.TW : 0;
-    const int rj = rvalid ? rpx - ri * p.TW : 0;
     const int koff = (lane >> 5) * 8;
-    const uint16_t* const xbase = sP + (ri * TWp + rj) * PITCH + koff;
+    int rpx[PT];
+    const uint16_t* xbase[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        rpx[pt] = (wq * PT + pt) * 32 + (lane & 31);
+        const bool rvalid = rpx[pt] < p.TH * p.TW;
+        const int ri = rvalid ? rpx[pt] / p.TW : 0;
+        const int rj = rvalid ? rpx[pt] - ri * p.TW : 0;
+        xbase[pt] = sP + (ri * TWp + rj) * PITCH + koff;
+    }
     const uint16_t* const wbase = sW + (wct * 32 + (lane & 31)) * PITCH + koff;
 
     if (EPI == 3) {
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
         }
     };
 
-    f32x16_t acc[4];
+    f32x16_t acc[4][PT];
     int tile = blockIdx.x;
     if (tile >= p.ntiles) return;
     load_regs(tile, 0, true);
@@ -173,7 +182,9 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+            for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][pt][r] = 0.f;
         for (int kc = 0; kc < p.nchunk; ++kc) {
             const bool with_w = !w_resident || first;
             __syncthreads();                           // the previous step's fragment reads / read-out are done
@@ -188,10 +199,12 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
 #pragma unroll
             for (int sh = 0; sh < 4; ++sh) {
                 const int dy = sh >> 1, dx = sh & 1;
-                bf16x8_t xf[KC / 16];
+                bf16x8_t xf[PT][KC / 16];
 #pragma unroll
-                for (int ks = 0; ks < KC / 16; ++ks)
-                    xf[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xbase + (dy * TWp + dx) * PITCH + ks * 16));
+                for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                    for (int ks = 0; ks < KC / 16; ++ks)
+                        xf[pt][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xbase[pt] + (dy * TWp + dx) * PITCH + ks * 16));
 #pragma unroll
                 for (int a = 0; a < (dy ? 1 : 2); ++a) {
                     const int kh = dy ? 0 : 1 + a;
@@ -203,7 +216,9 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
 #pragma unroll
                         for (int ks = 0; ks < KC / 16; ++ks) {
                             const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wbase + tap * CB * PITCH + ks * 16));
-                            acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[ks], acc[cls], 0, 0, 0);
+#pragma unroll
+                            for (int pt = 0; pt < PT; ++pt)
+                                acc[cls][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[pt][ks], acc[cls][pt], 0, 0, 0);
                         }
                     }
                 }
@@ -219,7 +234,8 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
         for (int ph = 0; ph < 2; ++ph) {
             // pixel index of this thread's read-out items (and, EPI 3, the producer's z chunks: requested before the barriers)
             int oidx[NOI];
-            uint4 zpre[EPI == 3 ? NOI : 1];
+            constexpr bool ZPRE = EPI == 3 && PT == 1;     // PT 2: the z chunks are requested in the read-out loop (register budget)
+            uint4 zpre[ZPRE ? NOI : 1];
 #pragma unroll
             for (int it = 0; it < NOI; ++it) {
                 const int row = t / CPR + it * (NT / CPR);
@@ -228,24 +244,26 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
                 const int gi = i0 + i, gj = j0 + j;
                 const bool ok = r < p.TH * p.TW && gi < p.Hg && gj < p.Wg && n < p.C;
                 oidx[it] = ok ? (b * p.Ho + 2 * gi + ph) * p.Wo + 2 * gj + pw : -1;
-                if (EPI == 3) {
+                if (ZPRE) {
                     zpre[it] = make_uint4(0, 0, 0, 0);
                     if (ok) zpre[it] = dg_ld_nt16(p.z + (size_t)oidx[it] * p.ldz + n);
                 }
             }
             __syncthreads();                           // fragment reads of the last channel block (ph 0) / read-out of ph 0 (ph 1) done
 #pragma unroll
-            for (int pw = 0; pw < 2; ++pw) {
-                uint16_t* dst = sStg + (rpx * 2 + pw) * SP + wct * 32 + 4 * (lane >> 5);
-                const f32x16_t& a = acc[ph * 2 + pw];
+            for (int pw = 0; pw < 2; ++pw)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint2 v;
-                    v.x = pack2(a[4 * q + 0], a[4 * q + 1]);
-                    v.y = pack2(a[4 * q + 2], a[4 * q + 3]);
-                    *reinterpret_cast<uint2*>(dst + 8 * q) = v;
+                for (int pt = 0; pt < PT; ++pt) {
+                    uint16_t* dst = sStg + (rpx[pt] * 2 + pw) * SP + wct * 32 + 4 * (lane >> 5);
+                    const f32x16_t& a = acc[ph * 2 + pw][pt];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint2 v;
+                        v.x = pack2(a[4 * q + 0], a[4 * q + 1]);
+                        v.y = pack2(a[4 * q + 2], a[4 * q + 3]);
+                        *reinterpret_cast<uint2*>(dst + 8 * q) = v;
+                    }
                 }
-            }
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < NOI; ++it) {
@@ -267,7 +285,8 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
                 if (EPI == 3) {
                     float g[8], z[8];
                     unpack8(v, g);
-                    unpack8(zpre[it], z);
+                    const uint4 zv = ZPRE ? zpre[it] : dg_ld_nt16(p.z + (size_t)oidx[it] * p.ldz + n);
+                    unpack8(zv, z);
                     const float4 s0 = *reinterpret_cast<const float4*>(sStat + cch * 8);
                     const float4 s1 = *reinterpret_cast<const float4*>(sStat + cch * 8 + 4);
                     const float4 h0 = *reinterpret_cast<const float4*>(sStat + CB + cch * 8);
@@ -302,21 +321,22 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_dg2_kernel(const Dg2K p)
 }
 
 // region geometry for a gz map of Hg x Wg: TH x TW <= 128 pixels with a patch of <= DG_PMAX pixels, most useful MFMA rows first
-bool dg2_geom(int Hg, int Wg, int* TH, int* TW, int* tx, int* ty)
+bool dg2_geom(int Hg, int Wg, int pt, int* TH, int* TW, int* tx, int* ty)
 {
     double best = -1.0;
+    const int rpx = DG_RPX1 * pt;
     for (int tw = 4; tw <= 64; ++tw)
-        for (int th = 1; th * tw <= DG_RPX; ++th) {
-            if ((th + 1) * (tw + 1) > DG_PMAX) continue;
+        for (int th = 1; th * tw <= rpx; ++th) {
+            if ((th + 1) * (tw + 1) > dg_pmax(pt)) continue;
             const int nx = (Wg + tw - 1) / tw, ny = (Hg + th - 1) / th;
-            double eff = (double)Hg * Wg / ((double)nx * ny * DG_RPX);
+            double eff = (double)Hg * Wg / ((double)nx * ny * rpx);
             eff += 1e-4 * tw;                                  // ties: longer rows (whole lines per store)
             if (eff > best) { best = eff; *TH = th; *TW = tw; *tx = nx; *ty = ny; }
         }
     return best > 0.0;
 }
 
-struct Dg2Plan { int ct, kc, gx, gy; Dg2K k; };
+struct Dg2Plan { int ct, kc, pt, gx, gy; Dg2K k; };
 
 bool dg2_plan(const yh_conv_desc* d, Dg2Plan* pl)
 {
@@ -331,9 +351,13 @@ bool dg2_plan(const yh_conv_desc* d, Dg2Plan* pl)
     if (gzb >= (1ul << 31) || wb >= (1ul << 31)) return false;
     if ((unsigned long)d->B * d->Ho * d->Wo >= (1ul << 31)) return false;
     Dg2K& k = pl->k;
-    if (!dg2_geom(d->Hi, d->Wi, &k.TH, &k.TW, &k.tx, &k.ty)) return false;
     pl->ct = d->N <= 32 ? 1 : 2;
     pl->kc = (Nk % 64 == 0 && d->tile_k != 32) ? 64 : 32;
+    // PT = 2 (two pixel tiles per wave, 256-pixel regions: twice the MFMAs per weight fragment and per barrier) is implemented and
+    // correct, and measured at HALF the speed of PT = 1 on the YOLOv5s / YOLOv5l layers: 128 accumulator registers plus the register-
+    // staged operands of the next step need > 256 VGPRs (spills with 8 waves, one 4-wave block per CU with 4) — not instantiated
+    pl->pt = 1;
+    if (!dg2_geom(d->Hi, d->Wi, pl->pt, &k.TH, &k.TW, &k.tx, &k.ty)) return false;
     const int cb = 32 * pl->ct;
     pl->gy = (d->N + cb - 1) / cb;
     if (pl->gy * cb > d->Npad) return false;
@@ -370,23 +394,23 @@ int yh_dg2_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name
     const int epi = d->bnr_part ? 3 : 0;
     if (d->bnr_part)
         YH_CHECK_ARG(d->bnr_z && yh_aligned16(d->bnr_z) && d->bnr_ldz % 8 == 0 && d->bnr_ws && d->bnr_C >= d->N, "yh_conv_igemm: bad fused-reduction operands");
-    if (name_out) { snprintf(name_out, name_len, "conv_dg2_kernel<%d, %d, %d>", pl.ct, pl.kc, epi); return YH_OK; }
+    if (name_out) { snprintf(name_out, name_len, "conv_dg2_kernel<%d, %d, %d, %d>", pl.ct, pl.kc, epi, pl.pt); return YH_OK; }
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(pl.gx, pl.gy), blk(256 * pl.ct);
-#define YH_LAUNCH_DG2(CT_, KC_)                                                                                        \
+#define YH_LAUNCH_DG2(CT_, KC_, PT_)                                                                                   \
     do {                                                                                                               \
-        const int sm = dg_smem_bytes<CT_, KC_>();                                                                      \
+        const int sm = dg_smem_bytes<CT_, KC_, PT_>();                                                                 \
         static bool attr_set = false;                                                                                  \
         if (!attr_set) {                                                                                               \
-            (void)hipFuncSetAttribute((const void*)conv_dg2_kernel<CT_, KC_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            (void)hipFuncSetAttribute((const void*)conv_dg2_kernel<CT_, KC_, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            (void)hipFuncSetAttribute((const void*)conv_dg2_kernel<CT_, KC_, 0, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            (void)hipFuncSetAttribute((const void*)conv_dg2_kernel<CT_, KC_, 3, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
             attr_set = true;                                                                                           \
         }                                                                                                              \
-        if (epi == 3) conv_dg2_kernel<CT_, KC_, 3><<<grid, blk, sm, st>>>(pl.k);                                       \
-        else          conv_dg2_kernel<CT_, KC_, 0><<<grid, blk, sm, st>>>(pl.k);                                       \
+        if (epi == 3) conv_dg2_kernel<CT_, KC_, 3, PT_><<<grid, blk, sm, st>>>(pl.k);                                  \
+        else          conv_dg2_kernel<CT_, KC_, 0, PT_><<<grid, blk, sm, st>>>(pl.k);                                  \
     } while (0)
-    if (pl.ct == 1) { if (pl.kc == 64) YH_LAUNCH_DG2(1, 64); else YH_LAUNCH_DG2(1, 32); }
-    else            { if (pl.kc == 64) YH_LAUNCH_DG2(2, 64); else YH_LAUNCH_DG2(2, 32); }
+    if (pl.ct == 1)      { if (pl.kc == 64) YH_LAUNCH_DG2(1, 64, 1); else YH_LAUNCH_DG2(1, 32, 1); }
+    else                 { if (pl.kc == 64) YH_LAUNCH_DG2(2, 64, 1); else YH_LAUNCH_DG2(2, 32, 1); }
 #undef YH_LAUNCH_DG2
     YH_CHECK_LAUNCH("yh_conv_igemm(dg2)");
     return YH_OK;

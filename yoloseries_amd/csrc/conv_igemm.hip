@@ -443,9 +443,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
     const int n0 = blockIdx.y * BN;
     const int HoWo = d.Ho * d.Wo;
     const int sdmask = (1 << p.sdshift) - 1;
-    const int ncb = (p.Ctot + BKT - 1) / BKT;       // a ragged last channel block is masked to zero on the activation side
-    const int HcWc = p.Hc * p.Wc;
+    // channel blocks are walked per segment: a segment's ragged last block (channel count not a multiple of the k-step) is masked
+    // to zero on the activation side, and the next segment starts a block of its own at its first channel (80 + 80: 3 + 3 blocks)
     const int C0 = d.seg[0].C;
+    const int ncb0 = d.nseg > 1 ? (C0 + BKT - 1) / BKT : 0;
+    const int ncb = d.nseg > 1 ? ncb0 + (p.Ctot - C0 + BKT - 1) / BKT : (p.Ctot + BKT - 1) / BKT;
+    const int HcWc = p.Hc * p.Wc;
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg[0].ptr, 0, p.segbytes[0], 0x00020000);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(d.nseg > 1 ? d.seg[1].ptr : d.seg[0].ptr), 0,
@@ -576,11 +579,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void conv_v2_kernel(const ConvK
         };
         auto load_tile = [&]() {
             if (ld_cb == 0) tap_setup(ld_tap);
-            const int c = ld_cb * BKT;
-            const bool s1 = d.nseg > 1 && c >= C0;           // wave-uniform
+            const bool s1 = d.nseg > 1 && ld_cb >= ncb0;     // wave-uniform
+            const int c = s1 ? C0 + (ld_cb - ncb0) * BKT : ld_cb * BKT;      // channel of the concatenated input the block starts at
             // channels of this thread's chunk that lie past the segment (last block of a channel count that is not a
             // multiple of the k-step) read as zero; the weight columns they meet are finite, so they add nothing
-            const bool cok = c + kc * 8 < (s1 ? p.Ctot : C0);
+            const bool cok = c + kc * 8 < (s1 || d.nseg == 1 ? p.Ctot : C0);
 #if YH_CONV_ABLATE
             if (YH_CONV_ABLATE & 1) {
 #pragma unroll
@@ -2240,7 +2243,6 @@ static bool conv_buf_ok(const yh_conv_desc* d, bool rebased)
 {
     if (d->nseg < 1 || d->nseg > 2) return false;
     if (conv_dbg_mask() & 16) return false;
-    if (d->nseg > 1 && d->seg[0].C % 32) return false;                 // a first concat segment must end on a 32-channel block
     if ((long)d->B * d->Hi * d->Wi >= (1L << 31) || (long)d->B * d->Ho * d->Wo >= (1L << 31)) return false;
     int Ctot = 0;
     for (int s2 = 0; s2 < d->nseg; ++s2) {
