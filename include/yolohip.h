@@ -155,6 +155,15 @@ typedef struct yh_wgrad_desc {
      * of L2.  dw is read-modify-written by that kernel: launches that share dw columns must be stream-ordered. */
     float*   partial;
     uint64_t partial_bytes;
+    /* Fused BatchNorm+SiLU backward for a layer WITHOUT a data gradient (the stem: its input is the image): with bn_z != NULL
+     * `gy` is not gz but ga, the gradient w.r.t. the layer's ACTIVATION, and the kernel forms gz = gamma*invstd*(dz - c1 - xhat*c2),
+     * dz = ga*silu'(z*scale+shift), in its operand loader — the arithmetic of yh_bn_silu_bwd_apply, rounded to bf16 exactly as that
+     * pass stores it — so gz is never written or re-read (YOLOv5s stem at batch 64: 420 MB each way) and the pass disappears from
+     * the end of the backward's critical path.  bn_z = raw conv output [M][bn_ldz], bn_ws = scale|shift|mean|invstd (stride N),
+     * bn_gamma [N], bn_coef = mean(dz)|mean(dz*xhat) (yh_bn_bwd_finalize).  Layers with N <= 64 * ... tilings listed in
+     * conv_wgrad.hip (wide tilings of up to 256 im2col columns); others return YH_EINVAL.                                      */
+    const yh_bf16* bn_z; int32_t bn_ldz; int32_t reserved0;
+    const float* bn_ws; const float* bn_gamma; const float* bn_coef;
 } yh_wgrad_desc;
 int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
 size_t yh_conv_wgrad_ws_bytes(const yh_wgrad_desc* d);

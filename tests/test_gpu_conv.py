@@ -166,6 +166,62 @@ def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits, tile_k):
     assert lib().yh_conv_wgrad(C.byref(d), None) != 0      # a workspace that is too small is refused
 
 
+@pytest.mark.parametrize("tile_k", [0, 64])
+@pytest.mark.parametrize("Cout", [32, 48, 64, 80])
+def test_conv_wgrad_fused_bn_backward(dev, Cout, tile_k):
+    """weight gradient of a layer without a data gradient (the stem: 3x3 on the 16-channel space-to-depth image, 32 / 48 / 64 / 80
+    output channels for YOLOv5 s / m / l / x) with the BatchNorm+SiLU backward apply fused into its operand loader
+    (yh_wgrad_desc.bn_*): BIT-identical to yh_bn_silu_bwd_apply followed by the plain weight gradient (both through the
+    deterministic partial-tile workspace), and close to an fp32 torch evaluation of the same chain"""
+    import ctypes as C
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import lib
+    B, H, W, Cin, k = 3, 24, 40, 16, 3
+    M = B * H * W
+    g = torch.Generator().manual_seed(90 + Cout)
+    x = _nhwc(B, H, W, Cin, dev, 91)
+    ga = _nhwc(B, H, W, Cout, dev, 92)
+    z = _nhwc(B, H, W, Cout, dev, 93)
+    z[0, :2] = 0.0                                   # pixels where z (and below ga) are exactly zero: gz there is the constant D, not 0
+    ga[0, 0] = 0.0
+    mean, invstd = torch.randn(Cout, generator=g) * 0.3, torch.rand(Cout, generator=g) + 0.5
+    gamma = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    beta = torch.randn(Cout, generator=g) * 0.2
+    scale = gamma.cpu() * invstd
+    ws = torch.cat([scale, beta - mean * scale, mean, invstd]).to(dev)
+    coef = torch.cat([torch.randn(Cout, generator=g) * 0.05, torch.randn(Cout, generator=g) * 0.05]).to(dev)
+    # unfused: the apply pass writes gz, the weight gradient reads it
+    gz = torch.zeros(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    hipk.bn_silu_bwd_apply(hipk.full(ga), hipk.full(z), ws, gamma, coef, M, hipk.full(gz))
+
+    def run(gy_t, fused):
+        dw = torch.zeros(Cout, k * k * Cin, device=dev)
+        d = hipk.wgrad_desc(hipk.full(gy_t), Cout, hipk.full(x), 0, Cin, B, H, W, H, W, k, 1, 1, dw, 7)
+        d.tile_k = tile_k
+        need = lib().yh_conv_wgrad_ws_bytes(C.byref(d))
+        wsb = torch.zeros(need // 4 + 16, device=dev)
+        d.partial, d.partial_bytes = wsb.data_ptr(), need
+        if fused:
+            d.bn_z, d.bn_ldz = z.data_ptr(), Cout
+            d.bn_ws, d.bn_gamma, d.bn_coef = ws.data_ptr(), gamma.data_ptr(), coef.data_ptr()
+        hipk.wgrad_launch(d)
+        torch.cuda.synchronize()
+        return dw
+    ref_dw = run(gz, False)
+    got = run(ga, True)
+    assert torch.equal(got, ref_dw), (got - ref_dw).abs().max().item()
+    # fp32 evaluation of the chain
+    a = z.float() * ws[:Cout] + ws[Cout:2 * Cout]
+    sg = torch.sigmoid(a)
+    dz = ga.float() * (sg * (1 + a * (1 - sg)))
+    xhat = (z.float() - ws[2 * Cout:3 * Cout]) * ws[3 * Cout:]
+    gzf = gamma * ws[3 * Cout:] * (dz - coef[:Cout] - xhat * coef[Cout:])
+    w = torch.zeros(Cout, Cin, k, k, device=dev, requires_grad=True)
+    (rw,) = torch.autograd.grad(F.conv2d(_nchw(x), w, padding=1), w, gzf.permute(0, 3, 1, 2))
+    rw = rw.permute(0, 2, 3, 1).reshape(Cout, -1)
+    _close(got, rw, 1e-2, 1e-2 * rw.abs().max().item())
+
+
 @pytest.mark.parametrize("C0,C1,Cout", [(32, 64, 64), (512, 448, 128)])
 def test_conv_wgrad_segment_upsampled(dev, C0, C1, Cout):
     """wgrad of one segment of a concat input, read through the 2x upsample (wide tiling; general tiling)."""

@@ -1,2 +1,2 @@
-python3 -m pytest tests/test_gpu_conv.py -x -q 2>&1 | tail -4
-python3 -m pytest tests/test_gpu_model.py -x -q 2>&1 | tail -2
+export YH_TUNE_CACHE=$PWD/gpurun_out/tune_local.json
+python3 -m pytest tests -x -q -m gpu > gpurun_out/r3_full2.log 2>&1; tail -3 gpurun_out/r3_full2.log

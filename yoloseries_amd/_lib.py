@@ -48,6 +48,8 @@ class WgradDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("dw", C.c_void_p), ("splits", C.c_int32), ("tile_k", C.c_int32),
         ("partial", C.c_void_p), ("partial_bytes", C.c_uint64),
+        ("bn_z", C.c_void_p), ("bn_ldz", C.c_int32), ("reserved0", C.c_int32),
+        ("bn_ws", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_coef", C.c_void_p),
     ]
 
 

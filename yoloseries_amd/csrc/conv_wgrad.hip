@@ -27,7 +27,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 struct WgK {
     yh_wgrad_desc d;
     int M, Ktot, Kseg, rows_per_split, ctiles, pointwise;
-    unsigned gybytes, xbytes;
+    unsigned gybytes, xbytes, zbytes;
     // split-M partial tiles leave the kernel either as fp32 atomics into dw (part == nullptr) or as plain stores into the
     // workspace part[split][pn][pk], summed afterwards in split order by wgrad_reduce_kernel (deterministic; the L2 atomic
     // unit — one 4-byte add per channel and clock — is what bounds the atomic form)
@@ -46,7 +46,9 @@ constexpr int wg_pitch(int cols) { return (cols % 64 == 32) ? cols : cols + 32; 
 // WN x WC waves, each wave computes (TNW*32) x (TCW*32); TK pixels per k-step
 // PF2: two tiles in flight per thread (see the register sets below): +7..12 % on the stem and the general (K > 384) tilings;
 // off where the second set would spill and on the 1x1 tilings, which already stream at 5.4 TB/s (measured 2 % slower with it)
-template <int WN, int WC, int TNW, int TCW, int TK, int MINW, bool PF2 = false>
+// FBN: the A operand is formed in the loader from (ga, z) — the BatchNorm+SiLU backward apply of a layer without a data gradient
+// (yh_wgrad_desc.bn_*): one chunk column per thread, its 8 channels' constants in registers
+template <int WN, int WC, int TNW, int TCW, int TK, int MINW, bool PF2 = false, bool FBN = false>
 __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const WgK p)
 {
     constexpr int NT = WN * WC * 64;              // threads per block
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
 
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)d.gy, 0, p.gybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg.ptr, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)(FBN ? d.bn_z : d.gy), 0, FBN ? p.zbytes : p.gybytes, 0x00020000);
 
     // per-thread constants
     unsigned voffA[ACH];
@@ -105,6 +108,30 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
     for (int j = 0; j < ACH; ++j) {
         const int ch = (sub + TPR * j) * 8;
         voffA[j] = (ch < TN && n0 + ch < d.N) ? (unsigned)((row * d.ldg + n0 + ch) * 2) : OOB;
+    }
+    // FBN: gz = A*dz + (Bc*z + D), dz = ga*silu'(z*sc + sh) (bn_silu_bwd_apply_kernel, elementwise.hip): the five per-channel
+    // constants of the block's TN channels live in LDS behind the tile buffers: sCst[5][TN] = sc | sh | A | Bc | D
+    float* const sCst = reinterpret_cast<float*>(sB + 2 * TK * PB);
+    unsigned voffZ[ACH];
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) voffZ[j] = OOB;
+    if (FBN) {
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) {
+            const int ch = (sub + TPR * j) * 8;
+            voffZ[j] = (ch < TN && n0 + ch < d.N) ? (unsigned)((row * d.bn_ldz + n0 + ch) * 2) : OOB;
+        }
+        for (int c = t; c < TN; c += NT) {
+            const int cc = n0 + c < d.N ? n0 + c : 0;
+            const float mu = d.bn_ws[2 * d.N + cc], is = d.bn_ws[3 * d.N + cc];
+            const float gi = d.bn_gamma[cc] * is;
+            const float c1 = d.bn_coef[cc], c2 = d.bn_coef[d.N + cc];
+            sCst[c] = d.bn_ws[cc]; sCst[TN + c] = d.bn_ws[d.N + cc];
+            sCst[2 * TN + c] = gi;
+            sCst[3 * TN + c] = -gi * is * c2;
+            sCst[4 * TN + c] = gi * (mu * is * c2 - c1);
+        }
+        __syncthreads();
     }
     int bkh[BCH], bkw[BCH];
     unsigned bcoff[BCH];              // byte offset of the chunk's channel inside a pixel (OOB when the column is padding)
@@ -141,12 +168,20 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
     // two register sets: the tile of k-step kt+2 is requested while tile kt is multiplied and tile kt+1 (requested one step
     // earlier) moves to LDS — two tiles in flight per thread; the layers this kernel serves are HBM bound
     u32x4_t ra0[ACH], rb0[BCH], ra1[ACH], rb1[BCH];
-    auto load_tile = [&](int kt, u32x4_t (&ra)[ACH], u32x4_t (&rb)[BCH]) {
+    u32x4_t rz0[ACH], rz1[ACH];
+    bool live0 = false, live1 = false;           // FBN: this thread's row of the tile lies inside the split
+    auto load_tile = [&](int kt, u32x4_t (&ra)[ACH], u32x4_t (&rb)[BCH], u32x4_t (&rz)[ACH], bool& live) {
         const int mb = mbeg + kt * TK;             // scalar
         const bool mv = mb + row < mend;
         const unsigned sg = (unsigned)mb * (unsigned)(d.ldg * 2);
 #pragma unroll
-        for (int j = 0; j < ACH; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsg, mv ? voffA[j] : OOB, sg, 0);
+        for (int j = 0; j < ACH; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsg, mv ? voffA[j] : OOB, sg, FBN ? 2 : 0);
+        if (FBN) {
+            const unsigned sz = (unsigned)mb * (unsigned)(d.bn_ldz * 2);
+#pragma unroll
+            for (int j = 0; j < ACH; ++j) rz[j] = __builtin_amdgcn_raw_buffer_load_b128(rsz, mv ? voffZ[j] : OOB, sz, 2);
+            live = mv;
+        }
         if (p.pointwise) {
             const unsigned sx = (unsigned)mb * (unsigned)(d.seg.ld * 2);
 #pragma unroll
@@ -170,7 +205,34 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
     };
     uint16_t* const stA = sA + row * PA + sub * 8;
     uint16_t* const stB = sB + row * PB + sub * 8;
-    auto store_tile = [&](int buf, const u32x4_t (&ra)[ACH], const u32x4_t (&rb)[BCH]) {
+    auto store_tile = [&](int buf, const u32x4_t (&ra)[ACH], const u32x4_t (&rb)[BCH], const u32x4_t (&rz)[ACH], const bool live) {
+        if (FBN) {
+#pragma unroll
+            for (int j = 0; j < ACH; ++j) {
+                const int ch = (sub + TPR * j) * 8;
+                if (ch >= TN) continue;
+                float g[8], z[8], o[8], cst[5][8];
+                unpack8(make_uint4(ra[j].x, ra[j].y, ra[j].z, ra[j].w), g);
+                unpack8(make_uint4(rz[j].x, rz[j].y, rz[j].z, rz[j].w), z);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const float4 lo = *reinterpret_cast<const float4*>(sCst + q * TN + ch);
+                    const float4 hi = *reinterpret_cast<const float4*>(sCst + q * TN + ch + 4);
+                    cst[q][0] = lo.x; cst[q][1] = lo.y; cst[q][2] = lo.z; cst[q][3] = lo.w;
+                    cst[q][4] = hi.x; cst[q][5] = hi.y; cst[q][6] = hi.z; cst[q][7] = hi.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = z[e] * cst[0][e] + cst[1][e];
+                    const float sg = sigmoid_fast(a);
+                    const float dz = g[e] * (sg * (1.f + a * (1.f - sg)));
+                    o[e] = cst[2][e] * dz + (cst[3][e] * z[e] + cst[4][e]);
+                }
+                // rows past the split / padded channels were loaded as zeros: dz = 0, but Bc*0 + D is not — they stay zero
+                const uint4 v = (live && voffZ[j] != OOB) ? pack8(o) : make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<u32x4_t*>(stA + buf * TK * PA + TPR * j * 8) = u32x4_t{v.x, v.y, v.z, v.w};
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < ACH; ++j)
             if ((sub + TPR * j) * 8 < TN) *reinterpret_cast<u32x4_t*>(stA + buf * TK * PA + TPR * j * 8) = ra[j];
@@ -217,20 +279,20 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
     };
 
     // tile j travels through register set j & 1 into LDS buffer j & 1
-    load_tile(0, ra0, rb0);
-    store_tile(0, ra0, rb0);
+    load_tile(0, ra0, rb0, rz0, live0);
+    store_tile(0, ra0, rb0, rz0, live0);
     if (PF2) {
-        if (nkt > 1) load_tile(1, ra1, rb1);
+        if (nkt > 1) load_tile(1, ra1, rb1, rz1, live1);
         __syncthreads();
         for (int kt = 0; kt < nkt; kt += 2) {
-            if (kt + 2 < nkt) load_tile(kt + 2, ra0, rb0);
+            if (kt + 2 < nkt) load_tile(kt + 2, ra0, rb0, rz0, live0);
             multiply(0);
-            if (kt + 1 < nkt) store_tile(1, ra1, rb1);
+            if (kt + 1 < nkt) store_tile(1, ra1, rb1, rz1, live1);
             __syncthreads();
             if (kt + 1 >= nkt) break;
-            if (kt + 3 < nkt) load_tile(kt + 3, ra1, rb1);
+            if (kt + 3 < nkt) load_tile(kt + 3, ra1, rb1, rz1, live1);
             multiply(1);
-            if (kt + 2 < nkt) store_tile(0, ra0, rb0);
+            if (kt + 2 < nkt) store_tile(0, ra0, rb0, rz0, live0);
             __syncthreads();
         }
     } else {
@@ -238,9 +300,9 @@ __global__ __launch_bounds__(WN * WC * 64, MINW) void conv_wgrad_kernel(const Wg
         for (int kt = 0; kt < nkt; ++kt) {
             const int buf = kt & 1;
             const bool more = (kt + 1) < nkt;
-            if (more) load_tile(kt + 1, ra0, rb0);
+            if (more) load_tile(kt + 1, ra0, rb0, rz0, live0);
             multiply(buf);
-            if (more) store_tile(buf ^ 1, ra0, rb0);
+            if (more) store_tile(buf ^ 1, ra0, rb0, rz0, live0);
             __syncthreads();
         }
     }
@@ -336,7 +398,8 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 
 template <int WN, int WC, int TNW, int TCW, int TK>
 constexpr size_t wg_smem() {
-    return (size_t)2 * TK * (wg_pitch(WN * TNW * 32) + wg_pitch(WC * TCW * 32)) * 2;
+    // tiles [2][TK][PA + PB] + (fused BatchNorm backward) the per-channel constants [5][TN]
+    return (size_t)2 * TK * (wg_pitch(WN * TNW * 32) + wg_pitch(WC * TCW * 32)) * 2 + 5 * WN * TNW * 32 * 4;
 }
 
 // instantiation used for a layer (N out channels, Kseg im2col columns of the segment)
@@ -475,20 +538,38 @@ static int conv_wgrad_launch(const yh_wgrad_desc* d, yh_stream stream)
         dim3 grid((NT_) * k.ctiles, (splits + 7) / 8 * 8);                                                      \
         conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_, PF2_><<<grid, dim3(WN_ * WC_ * 64), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
     } while (0)
+    // the same with the BatchNorm-backward apply fused into the A-operand loader (bn_z): the wide tilings a stem layer gets
+#define YH_WGF(WN_, WC_, TNW_, TCW_, TK_, MINW_, NT_, PF2_)                                                     \
+    do {                                                                                                        \
+        dim3 grid((NT_) * k.ctiles, (splits + 7) / 8 * 8);                                                      \
+        if (fbn) conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_, PF2_, true><<<grid, dim3(WN_ * WC_ * 64), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
+        else     conv_wgrad_kernel<WN_, WC_, TNW_, TCW_, TK_, MINW_, PF2_><<<grid, dim3(WN_ * WC_ * 64), wg_smem<WN_, WC_, TNW_, TCW_, TK_>(), st>>>(k); \
+    } while (0)
+    const bool fbn = d->bn_z != nullptr;
+    if (fbn) {
+        YH_CHECK_ARG(wide && (cfg == 0 || cfg == 3), "yh_conv_wgrad: the fused BatchNorm backward (bn_z) needs a wide tiling with <= 256 im2col columns "
+                     "(N <= 32: <= 256 columns; N > 32: 129..256 columns)");
+        YH_CHECK_ARG(yh_aligned16(d->bn_z) && d->bn_ldz % 8 == 0 && d->bn_ldz >= d->N && d->bn_ws && d->bn_gamma && d->bn_coef && d->N % 8 == 0,
+                     "yh_conv_wgrad: bad fused-BatchNorm operands");
+        const unsigned long zb = ((unsigned long)(M - 1) * d->bn_ldz + d->N) * 2;
+        YH_CHECK_ARG(zb < (1ul << 31), "yh_conv_wgrad: bn_z of 2 GiB or more is not supported");
+        k.zbytes = (unsigned)zb;
+    } else k.zbytes = 0;
     k.ctiles = wide ? 1 : (k.Kseg + 127) / 128;
     switch (cfg) {
     case 0:
-        if (k.Kseg <= 160) { if (tk64) YH_WG(1, 5, 1, 1, 64, 3, (d->N + 31) / 32, true); else YH_WG(1, 5, 1, 1, 32, 3, (d->N + 31) / 32, true); }  // stem: 5 waves x one 32-column tile (144 of 160 used)
-        else               { if (tk64) YH_WG(1, 4, 1, 2, 64, 2, (d->N + 31) / 32, true); else YH_WG(1, 4, 1, 2, 32, 3, (d->N + 31) / 32, true); }
+        if (k.Kseg <= 160) { if (tk64) YH_WGF(1, 5, 1, 1, 64, 3, (d->N + 31) / 32, true); else YH_WGF(1, 5, 1, 1, 32, 3, (d->N + 31) / 32, true); }  // stem: 5 waves x one 32-column tile (144 of 160 used)
+        else               { if (tk64) YH_WGF(1, 4, 1, 2, 64, 2, (d->N + 31) / 32, true); else YH_WGF(1, 4, 1, 2, 32, 3, (d->N + 31) / 32, true); }
         break;
     case 1: if (tk64) YH_WG(1, 4, 1, 3, 64, 2, (d->N + 31) / 32, false); else YH_WG(1, 4, 1, 3, 32, 3, (d->N + 31) / 32, false); break;
     case 2: if (tk64) YH_WG(1, 4, 2, 1, 64, 2, (d->N + 63) / 64, false); else YH_WG(1, 4, 2, 1, 32, 4, (d->N + 63) / 64, false); break;
-    case 3: if (tk64) YH_WG(1, 4, 2, 2, 64, 2, (d->N + 63) / 64, false); else YH_WG(1, 4, 2, 2, 32, 3, (d->N + 63) / 64, false); break;
+    case 3: if (tk64) YH_WGF(1, 4, 2, 2, 64, 2, (d->N + 63) / 64, false); else YH_WGF(1, 4, 2, 2, 32, 3, (d->N + 63) / 64, false); break;
     case 4: YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64, false); break;
     case 5: YH_WG(2, 2, 1, 2, 64, 3, (d->N + 63) / 64, true); break;
     default: YH_WG(4, 2, 1, 2, 64, 4, (d->N + 127) / 128, true); break; // 8 waves of 32 x 64 (measured 5% over 4 waves of 64 x 64)
     }
 #undef YH_WG
+#undef YH_WGF
     YH_CHECK_LAUNCH("yh_conv_wgrad");
     if (k.part) {
         const long items = (long)d->N * (k.Kseg / 4);

@@ -127,6 +127,11 @@ MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct
 # order by a second kernel (yh_wgrad_desc.partial) instead of fp32 atomics: BIT-REPRODUCIBLE gradients.  Measured on the YOLOv5s
 # step: the weight-gradient kernels themselves get 4 % faster (3.67 -> 3.52 ms), the step 1.6 % slower (the 2.5 GB of partial
 # tiles are written and read back next to an HBM-bound main chain) — so the atomic form stays the default.
+# YH_FUSE_STEM_BWD=1: the BatchNorm backward apply of a layer without a data gradient (the stem) runs inside its weight gradient's
+# operand loader (yh_wgrad_desc.bn_*; bit-identical, tests/test_gpu_conv.py).  Measured on the YOLOv5s step: the fused kernel takes
+# 0.55 ms against 0.22 (apply pass, HBM-bound) + 0.25 (weight gradient) — the sigmoid of 210 M elements is hidden behind HBM time in
+# the streaming pass but not between the barriers of a 15-wave-per-CU GEMM — and the step gets 1 % slower: opt-in.
+FUSE_STEM_BWD = os.environ.get("YH_FUSE_STEM_BWD", "0") == "1"
 WG_WS_BYTES = (256 << 20) if os.environ.get("YH_WGRAD_PARTIAL", "0") == "1" else 0
 NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weight gradients may lag behind by
 
@@ -145,7 +150,7 @@ _WGRAD_TK64 = {
 # entries of a shipped / cached table are not applied.  Stride-2 data gradients carry their own version (conv_dg2_kernel, algo 7,
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
 KEY_CONV, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "wgrad5", "wgrad6"
-TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS))
+TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
 # YH_ABL_SKIP=<entry point>[,...|wgrad]: TIMING EXPERIMENTS ONLY (results are wrong) — the named launches are left out of the
 # compiled programs, which gives the wall time a step would have if that family were free (profiles/r03_step_ablation.txt)
@@ -991,6 +996,13 @@ class Program:
                 gy_sl = None
             else:
                 c0 = 0
+                # a layer without a data gradient (the stem: its input is the image) hands gz to nobody but its own weight
+                # gradient: that kernel forms gz from (ga, z) in its operand loader (yh_wgrad_desc.bn_*), the apply pass — the
+                # last 0.2 ms of the backward's critical path on YOLOv5s — and the gz round trip through HBM disappear
+                Kseg0 = op.k * op.k * op.segs[0].C
+                fused_stem = (FUSE_STEM_BWD and not BN_ACC and len(op.parts) == 1 and len(op.segs) == 1 and op.res is None and
+                              not op.segs[0].buf.needs_grad and op.N % 8 == 0 and
+                              ((op.N <= 32 and Kseg0 <= 256) or (op.N > 32 and 128 < Kseg0 <= 256)))
                 merged = (MERGE_PARTS and not BN_ACC and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and
                           not (op.res is not None and op.res.buf.needs_grad))
                 bwd_parts = (BnPart * len(op.parts))() if merged else None
@@ -1049,6 +1061,8 @@ class Program:
                         pa = bwd_parts[pi]
                         pa.ws, pa.C, pa.ga, pa.ldga = ws.data_ptr(), n, ga.ptr(), ga.ld
                         pa.gamma, pa.coef = bn.weight.data_ptr(), coef.data_ptr()
+                    elif fused_stem:
+                        st['fused_bwd'] = (ga, ws, bn, coef)
                     else:
                         cmds.append((L.yh_bn_silu_bwd_apply, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), bn.weight.data_ptr(),
                                                               coef.data_ptr(), n, M, gys.data_ptr() + 2 * c0, op.N,
@@ -1069,6 +1083,11 @@ class Program:
                 wd = WgradDesc()
                 wd.gy = gys.data_ptr() if op.kind == 'cba' else 0
                 wd.ldg, wd.N = gy_ld, gyN
+                if op.kind == 'cba' and fused_stem:
+                    ga_, ws_, bn_, coef_ = st['fused_bwd']
+                    wd.gy, wd.ldg = ga_.ptr(), ga_.ld
+                    wd.bn_z, wd.bn_ldz = op.y.t.data_ptr(), op.y.C
+                    wd.bn_ws, wd.bn_gamma, wd.bn_coef = ws_.data_ptr(), bn_.weight.data_ptr(), coef_.data_ptr()
                 wd.seg = hipk.make_seg(sg.sl())
                 wd.coff_k, wd.Ctot = coff_k, op.Ctot
                 wd.B, wd.Ho, wd.Wo, wd.Hi, wd.Wi = B, op.Ho, op.Wo, op.Hi, op.Wi
@@ -1081,7 +1100,7 @@ class Program:
                 wd.splits = self._tune_wgrad_splits(wd, M, ntile, op)
                 self._keep.append(wd)
                 cmds.append(('wgrad', op, wd, (self._wgrad_name(L, wd), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C),
-                                               2.0 * M * gy_ld + 2.0 * B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.C)))
+                                               2.0 * M * gy_ld * (2 if wd.bn_z else 1) + 2.0 * B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.C)))
                 coff_k += sg.C
             cmds.append(('wg_end', (n_cba - 1) % NGZ if op.kind == 'cba' else None, None, ('sync', 0, 0.0)))
             # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
@@ -1159,7 +1178,7 @@ class Program:
             return max(1, min((M + 255) // 256, (total + nt - 1) // nt))
         if os.environ.get("YH_WGRAD_TUNE", "1") == "0":
             return splits_for(512)
-        key = f"{KEY_WGRAD_WS if wd.partial else KEY_WGRAD}:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
+        key = f"{KEY_WGRAD_WS if wd.partial else KEY_WGRAD}{'f' if wd.bn_z else ''}:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
                                                           wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad))
         cache = _tune_cache()
         if key in cache:
@@ -1173,7 +1192,7 @@ class Program:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         name = self.L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
         tks = (0, 64) if name in _WGRAD_TK64 else (0,)
-        if 128 <= Kseg <= 384 and wd.N > 32:
+        if 128 <= Kseg <= 384 and wd.N > 32 and not wd.bn_z:
             tks = tks + (128,)              # the general 128-column tiling on a layer that defaults to a wide one
         best, best_ms = None, None
         for tk in tks:

@@ -87,7 +87,8 @@ class YOLOXEvaluator(YOLOV5Evaluator):
         return [torch.from_numpy(x) if x is not None else None for x in outs]
 
     def _nms_from_heads(self, stage_preds, img_h=None):
-        self._check_cfg()
+        if self.hyp.get('mutil_label', False):
+            raise NotImplementedError("mutil_label=True (trainer/eval_yolox.py:218-221) is not implemented for YOLOX on the HIP path (false in every shipped config; the YOLOv5 evaluator has it)")
         sp = self._stage_list(stage_preds)
         d, canon, ptrs = self._desc(sp)
         self._set_strides(d, img_h if img_h is not None else self.inp_h)
@@ -104,7 +105,8 @@ class YOLOXEvaluator(YOLOV5Evaluator):
     def numba_nms(self, preds_out):
         """decoded (bs, N, 5+nc) -> list of np.ndarray (n,6) or None (eval_yolox.py:201-259): pre-filter on
         obj*max(cls) >= conf, class confidence >= cls threshold (inclusive, unlike the v5 evaluator)"""
-        self._check_cfg()
+        if self.hyp.get('mutil_label', False):
+            raise NotImplementedError("mutil_label=True (trainer/eval_yolox.py:218-221) is not implemented for YOLOX on the HIP path (false in every shipped config; the YOLOv5 evaluator has it)")
         p = preds_out.detach().to(torch.float32).contiguous()
         if not p.is_cuda:
             p = p.to(self.device if str(self.device).startswith("cuda") else "cuda:0")
