@@ -307,10 +307,13 @@ def worker(args):
         out = step()
     sync_all()
     t0 = time.perf_counter()
+    w0 = time.time()
     for _ in range(args.steps):
         out = step()
     sync_all()
     dt = time.perf_counter() - t0
+    if os.environ.get("YH_BENCH_STAMP"):          # wall-clock window of the timed region (concurrency experiments)
+        print(f"# timed region {w0:.4f} .. {time.time():.4f}", file=sys.stderr)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -45,4 +45,7 @@ if [ -z "$QUICK" ]; then
   pmc_passes _infer_xlarge_128_1280 infer:xlarge:128:1280 1 --workload infer --model xlarge --img 1280 --batch 128
   YH_BENCH_LAYERS=200 python3 bench.py --workload infer --model xlarge --img 1280 --batch 128 --steps 6 --warmup 3 --no-cpu-baseline > profiles/${TAG}_bench_infer_v5x_1280_b128.json 2> profiles/${TAG}_layers_infer_v5x_1280_b128.txt
 fi
-ls -la $OUT profiles
+# gpurun merges only gpurun_out/ back: everything for profiles/ travels in $OUT/profiles (copy it over profiles/ afterwards)
+mkdir -p $OUT/profiles
+cp profiles/pmc_traffic*.json profiles/pmc_mfma*.json profiles/${TAG}_* $OUT/profiles/ 2>/dev/null || true
+ls -la $OUT $OUT/profiles

@@ -415,9 +415,9 @@ int wg_config(int N, int Kseg, int tile_k)
     return N <= 64 ? 5 : 6;
 }
 const char* const wg_names[7] = {
-    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3, true>", "conv_wgrad_kernel<1, 4, 1, 3, 32, 3, false>", "conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false>",
-    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false>", "conv_wgrad_kernel<1, 4, 2, 3, 32, 2, false>", "conv_wgrad_kernel<2, 2, 1, 2, 64, 3, true>",
-    "conv_wgrad_kernel<4, 2, 1, 2, 64, 4, true>"};
+    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3, true, false>", "conv_wgrad_kernel<1, 4, 1, 3, 32, 3, false, false>", "conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false, false>",
+    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false, false>", "conv_wgrad_kernel<1, 4, 2, 3, 32, 2, false, false>", "conv_wgrad_kernel<2, 2, 1, 2, 64, 3, true, false>",
+    "conv_wgrad_kernel<4, 2, 1, 2, 64, 4, true, false>"};
 
 }  // namespace
 
@@ -425,7 +425,7 @@ const char* const wg_names[7] = {
 extern "C" const char* yh_conv_wgrad_kernel_name2(int N, int Kseg, int tile_k)
 {
     const int c = wg_config(N, Kseg, tile_k);
-    return (c == 0 && Kseg <= 160) ? "conv_wgrad_kernel<1, 5, 1, 1, 32, 3, true>" : wg_names[c];
+    return (c == 0 && Kseg <= 160) ? "conv_wgrad_kernel<1, 5, 1, 1, 32, 3, true, false>" : wg_names[c];
 }
 extern "C" const char* yh_conv_wgrad_kernel_name(int N, int Kseg) { return yh_conv_wgrad_kernel_name2(N, Kseg, 0); }
 

@@ -138,11 +138,11 @@ NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weig
 
 # wide weight-gradient tilings that also exist with 64-pixel k-steps (yh_wgrad_desc.tile_k = 64): 32-pixel name -> 64-pixel name
 _WGRAD_TK64 = {
-    "conv_wgrad_kernel<1, 5, 1, 1, 32, 3, true>": "conv_wgrad_kernel<1, 5, 1, 1, 64, 3, true>",
-    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3, true>": "conv_wgrad_kernel<1, 4, 1, 2, 64, 2, true>",
-    "conv_wgrad_kernel<1, 4, 1, 3, 32, 3, false>": "conv_wgrad_kernel<1, 4, 1, 3, 64, 2, false>",
-    "conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false>": "conv_wgrad_kernel<1, 4, 2, 1, 64, 2, false>",
-    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false>": "conv_wgrad_kernel<1, 4, 2, 2, 64, 2, false>",
+    "conv_wgrad_kernel<1, 5, 1, 1, 32, 3, true, false>": "conv_wgrad_kernel<1, 5, 1, 1, 64, 3, true, false>",
+    "conv_wgrad_kernel<1, 4, 1, 2, 32, 3, true, false>": "conv_wgrad_kernel<1, 4, 1, 2, 64, 2, true, false>",
+    "conv_wgrad_kernel<1, 4, 1, 3, 32, 3, false, false>": "conv_wgrad_kernel<1, 4, 1, 3, 64, 2, false, false>",
+    "conv_wgrad_kernel<1, 4, 2, 1, 32, 4, false, false>": "conv_wgrad_kernel<1, 4, 2, 1, 64, 2, false, false>",
+    "conv_wgrad_kernel<1, 4, 2, 2, 32, 3, false, false>": "conv_wgrad_kernel<1, 4, 2, 2, 64, 2, false, false>",
 }
 
 
@@ -1224,6 +1224,8 @@ class Program:
         name = L.yh_conv_wgrad_kernel_name2(wd.N, wd.KH * wd.KW * wd.seg.C, wd.tile_k).decode()
         if wd.tile_k == 64:
             name = _WGRAD_TK64.get(name, name)
+        if wd.bn_z:                        # last template argument: BatchNorm backward fused into the operand loader
+            name = name[:-len(", false>")] + ", true>"
         return name
 
     def _bucket_ready(self, bucket_hook, bucket, main, side):
