@@ -148,7 +148,9 @@ typedef struct yh_wgrad_desc {
     float*   dw;                      /* [N][KH*KW*Ctot] fp32, accumulated          */
     int32_t  splits;                  /* split of the M (pixel) reduction, >=1      */
     int32_t  tile_k;                  /* launch tuning: 64 = 64-pixel k-steps on the wide 64-row tilings (0 / 32: default);
-                                         128 = the general 128-column tiling also where KH*KW*C <= 384 (needs >= 128 columns) */
+                                         128 = the general 128-column tiling also where KH*KW*C <= 384 (needs >= 128 columns);
+                                         on the general tiling: 32 = 32-pixel k-steps (two blocks per CU), 35 = four waves of
+                                         64 x 64 on 32-pixel k-steps */
     /* optional workspace of >= yh_conv_wgrad_ws_bytes() bytes (16-byte aligned, caller-owned, may be shared by launches on ONE
      * stream): the split-M partial tiles are written there with plain stores and summed into dw by a second kernel in split
      * order — bit-reproducible, and faster than the fp32 atomics of the default form (NULL), which are bound by the atomic rate

@@ -425,6 +425,8 @@ const char* const wg_names[7] = {
 extern "C" const char* yh_conv_wgrad_kernel_name2(int N, int Kseg, int tile_k)
 {
     const int c = wg_config(N, Kseg, tile_k);
+    if (c == 6 && tile_k == 32) return "conv_wgrad_kernel<4, 2, 1, 2, 32, 2, true, false>";
+    if (c == 6 && tile_k == 35) return "conv_wgrad_kernel<2, 2, 2, 2, 32, 2, false, false>";
     return (c == 0 && Kseg <= 160) ? "conv_wgrad_kernel<1, 5, 1, 1, 32, 3, true, false>" : wg_names[c];
 }
 extern "C" const char* yh_conv_wgrad_kernel_name(int N, int Kseg) { return yh_conv_wgrad_kernel_name2(N, Kseg, 0); }
@@ -447,7 +449,7 @@ static void wg_split_plan(const yh_wgrad_desc* d, long M, int* tk_out, int* rps_
     const bool wide = wg_wide(Kseg, d->tile_k);
     const int cfg = wg_config(d->N, Kseg, d->tile_k);
     const bool tk64 = wide && d->tile_k == 64 && cfg <= 3;
-    const int TK = (wide && !tk64) ? 32 : 64;
+    const int TK = ((wide && !tk64) || (cfg == 6 && (d->tile_k == 32 || d->tile_k == 35))) ? 32 : 64;
     int splits = d->splits < 1 ? 1 : d->splits;
     int rps = (int)((M + splits - 1) / splits);
     rps = ((rps + TK - 1) / TK) * TK;
@@ -566,7 +568,16 @@ static int conv_wgrad_launch(const yh_wgrad_desc* d, yh_stream stream)
     case 3: if (tk64) YH_WGF(1, 4, 2, 2, 64, 2, (d->N + 63) / 64, false); else YH_WGF(1, 4, 2, 2, 32, 3, (d->N + 63) / 64, false); break;
     case 4: YH_WG(1, 4, 2, 3, 32, 2, (d->N + 63) / 64, false); break;
     case 5: YH_WG(2, 2, 1, 2, 64, 3, (d->N + 63) / 64, true); break;
-    default: YH_WG(4, 2, 1, 2, 64, 4, (d->N + 127) / 128, true); break; // 8 waves of 32 x 64 (measured 5% over 4 waves of 64 x 64)
+    default:
+        // 8 waves of 32 x 64, 64-pixel k-steps: 82 KB of LDS, ONE block per CU whose every k-step ends in a block-wide barrier.
+        // tile_k == 32: the same waves on 32-pixel k-steps (41 KB: two blocks per CU, one block's barrier is covered by the other's
+        // MFMAs: +10 % on the 3x3 layers of YOLOv5s at 40 x 40); tile_k == 35: FOUR waves of 64 x 64 on 32-pixel k-steps (two
+        // transposing reads per MFMA instead of three: +15 % at 20 x 20).  Measured and dropped: three blocks per CU (equal), the
+        // 4-wave tile with two register sets in flight (spills: half the speed).  The engine times the three per layer.
+        if (d->tile_k == 32)      YH_WG(4, 2, 1, 2, 32, 2, (d->N + 127) / 128, true);
+        else if (d->tile_k == 35) YH_WG(2, 2, 2, 2, 32, 2, (d->N + 127) / 128, false);
+        else                      YH_WG(4, 2, 1, 2, 64, 4, (d->N + 127) / 128, true);
+        break;
     }
 #undef YH_WG
 #undef YH_WGF

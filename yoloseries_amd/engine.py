@@ -149,7 +149,7 @@ _WGRAD_TK64 = {
 # version prefixes of the tuning-table keys: bumped when the candidates or the meaning of a tuned value change, so that stale
 # entries of a shipped / cached table are not applied.  Stride-2 data gradients carry their own version (conv_dg2_kernel, algo 7,
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
-KEY_CONV, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "wgrad5", "wgrad6"
+KEY_CONV, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "wgrad7", "wgrad8"
 TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
 # YH_ABL_SKIP=<entry point>[,...|wgrad]: TIMING EXPERIMENTS ONLY (results are wrong) — the named launches are left out of the
@@ -1192,6 +1192,8 @@ class Program:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         name = self.L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
         tks = (0, 64) if name in _WGRAD_TK64 else (0,)
+        if name.startswith("conv_wgrad_kernel<4, 2, 1, 2, 64"):
+            tks = tks + (32, 35)            # the general tiling with 32-pixel k-steps (two blocks per CU): 8 waves of 32 x 64 / 4 of 64 x 64
         if 128 <= Kseg <= 384 and wd.N > 32 and not wd.bn_z:
             tks = tks + (128,)              # the general 128-column tiling on a layer that defaults to a wide one
         best, best_ms = None, None
