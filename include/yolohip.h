@@ -102,7 +102,9 @@ typedef struct yh_conv_desc {
                            * (conv_v3_kernel) with a 256x128 / 128x128 / 128x64 tile, 5 the 3x3 halo kernel (conv_halo_kernel), 6 its
                            * 160-channel-wide variant (conv_halo160_kernel: N % 160 == 0, no statistics), when the shape is eligible;
                            * 7 the stride-2 data-gradient kernel (conv_dg2_kernel: DGRAD of a 3x3 / s2 / p1 layer with even output
-                           * dims and gz channels in a multiple of 32: the four parity classes from one LDS patch of gz) */
+                           * dims and gz channels in a multiple of 32: the four parity classes from one LDS patch of gz);
+                           * 8 the 3x3 / stride-1 patch kernel for small channel counts (conv_p3_kernel: <= 128 channels in a multiple
+                           * of 32 in, <= 128 out, forward with statistics or data gradient with the fused reduction) */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
      * contributions already in out0 are added first and the sums are taken over the rounded total):

@@ -274,6 +274,8 @@ def _expect_family(d, algo):
         pytest.skip("shape not eligible for the halo kernel")
     if algo == 7:
         assert "conv_dg2_kernel" in kn, kn
+    if algo == 8:
+        assert "conv_p3_kernel" in kn, kn
 
 
 @pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])
@@ -346,7 +348,49 @@ def test_conv_dgrad_stride2_kernel(dev, B, H, W, Cin, Cout):
         _dgrad_check(dev, B, H, W, Cin, Cout, 3, 2, 1, 7, tile_k=32)
 
 
-def _dgrad_check(dev, B, H, W, Cin, Cout, k, s, p, algo, tile_k=0):
+P3_CASES = [
+    # B, H, W, Cin, Cout: ConvBnAct(Cin, Cout, 3, 1, 1) on an H x W map
+    (2, 48, 40, 32, 32),        # YOLOv5s stage-1 bottleneck class: one channel tile, weights resident in LDS, two pixel tiles per wave
+    (1, 33, 17, 64, 64),        # odd sizes: ragged regions, 64-channel step, two channel tiles
+    (2, 24, 24, 32, 64),
+    (1, 40, 40, 64, 32),
+    (2, 20, 20, 96, 96),        # 32-channel steps (96 % 64 != 0), three channel blocks, two blocks along the output channels
+    (1, 16, 16, 128, 128),
+    (1, 24, 40, 40 + 24, 40),   # output channel count that is not a multiple of 32 (masked chunk columns)
+]
+
+
+@pytest.mark.parametrize("tile_n", [0, 32])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", P3_CASES)
+def test_conv_patch3_kernel(dev, B, H, W, Cin, Cout, tile_n):
+    """conv_p3_kernel (algo 8): 3x3 / stride-1 layers with few channels from ONE LDS patch of the input — forward with the
+    BatchNorm partial sums, data gradient plain / accumulating / with the fused BatchNorm-backward reduction — against torch;
+    tile_n 32 = one pixel tile per wave (128-pixel regions) instead of two"""
+    from yoloseries_amd import hipk
+    x = _nhwc(B, H, W, Cin, dev, 81)
+    g = torch.Generator().manual_seed(82)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    out = torch.full((B, H, W, Cout), 3.0, dtype=torch.bfloat16, device=dev)
+    d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.full(out))
+    d.algo, d.tile_n = 8, tile_n
+    assert "conv_p3_kernel" in _kname(d), _kname(d)
+    stats = torch.full((hipk.conv_stat_blocks(d), 2, wp.shape[0]), float("nan"), device=dev)
+    d.stats = stats.data_ptr()
+    assert "conv_p3_kernel" in _kname(d) and hipk.conv_stat_blocks(d) == stats.shape[0]
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    ref = F.conv2d(_nchw(x), w, padding=1).permute(0, 2, 3, 1)
+    _close(out, ref, 8e-3, 2e-2)
+    o = out.float().reshape(-1, Cout).double()
+    assert not torch.isnan(stats[:, :, :Cout]).any()
+    assert ((stats[:, 0, :Cout].double().sum(0) - o.sum(0)).abs() <= 1e-3 + 1e-5 * o.abs().sum(0)).all()      # sums of the STORED values
+    assert ((stats[:, 1, :Cout].double().sum(0) - (o ** 2).sum(0)).abs() <= 1e-3 + 1e-5 * (o ** 2).sum(0)).all()
+    if Cout % 32 == 0:                 # the data gradient reads gz with Cout channels: whole 32-channel blocks needed
+        _dgrad_check(dev, B, H, W, Cin, Cout, 3, 1, 1, 8, tile_n=tile_n)
+
+
+def _dgrad_check(dev, B, H, W, Cin, Cout, k, s, p, algo, tile_k=0, tile_n=0):
     from yoloseries_amd import hipk
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     gy = _nhwc(B, Ho, Wo, Cout, dev, 27)
@@ -360,7 +404,7 @@ def _dgrad_check(dev, B, H, W, Cin, Cout, k, s, p, algo, tile_k=0):
     gx = _nhwc(B, H, W, Cin, dev, 29)
     gx0 = gx.clone()
     d = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, Ho, Wo, k, s, p, wd, Cin, hipk.full(gx), accumulate=1)
-    d.algo, d.tile_k = algo, tile_k
+    d.algo, d.tile_k, d.tile_n = algo, tile_k, tile_n
     _expect_family(d, algo)
     hipk.conv_launch(d)
     torch.cuda.synchronize()
@@ -372,7 +416,7 @@ def _dgrad_check(dev, B, H, W, Cin, Cout, k, s, p, algo, tile_k=0):
     ws = torch.cat([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)]).to(dev)
     gx2 = torch.zeros(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
     d2 = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, Ho, Wo, k, s, p, wd, Cin, hipk.full(gx2))
-    d2.algo, d2.tile_k = algo, tile_k
+    d2.algo, d2.tile_k, d2.tile_n = algo, tile_k, tile_n
     rows = lib().yh_conv_bnr_rows(C.byref(d2))
     assert rows > 0
     slab = torch.zeros(rows, 2, Cin, device=dev)

@@ -1,5 +1,4 @@
-rm -f gpurun_out/r3_sweep8.log
-tools/sweep_env.sh gpurun_out/r3_sweep8.log "" "YH_X=1" "YH_X=2"
-tools/sweep_env.sh gpurun_out/r3_sweep8.log "--model large" "YH_X=1"
-tools/sweep_env.sh gpurun_out/r3_sweep8.log "--workload yolox" "YH_X=1"
-git stash -q 2>/dev/null
+rm -f gpurun_out/r3_sweep10.log
+A="YH_TUNE_CACHE=$PWD/gpurun_out/tc_a.json YH_SKIP_ALGOS=8"
+Bv="YH_TUNE_CACHE=$PWD/gpurun_out/tc_b.json"
+tools/sweep_env.sh gpurun_out/r3_sweep10.log "" "$A YH_BWD_STREAMS=0" "$Bv YH_BWD_STREAMS=0" "$A YH_BWD_STREAMS=0" "$Bv YH_BWD_STREAMS=0" "$A" "$Bv" "$A" "$Bv"

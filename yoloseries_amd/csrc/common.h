@@ -85,4 +85,8 @@ void yh_set_error(const char* fmt, ...);
 int yh_dg2_rows(const yh_conv_desc* d);                 // grid rows (== slab rows of the fused reduction); 0 = not eligible
 int yh_dg2_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
 
+// conv_p3.hip: the 3x3 / stride-1 patch kernel for small channel counts behind yh_conv_igemm (algo 8)
+int yh_p3_rows(const yh_conv_desc* d);                  // grid rows (== statistics / fused-reduction slab rows); 0 = not eligible
+int yh_p3_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
+
 static inline bool yh_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -149,8 +149,12 @@ _WGRAD_TK64 = {
 # version prefixes of the tuning-table keys: bumped when the candidates or the meaning of a tuned value change, so that stale
 # entries of a shipped / cached table are not applied.  Stride-2 data gradients carry their own version (conv_dg2_kernel, algo 7,
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
-KEY_CONV, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "wgrad7", "wgrad8"
-TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
+KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "wgrad7", "wgrad8"
+TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
+
+# YH_SKIP_ALGOS=<n>[,<n>]: leave these kernel families (yh_conv_desc.algo) out of the per-layer timing — A/B runs of a new family on
+# one box (use a YH_TUNE_CACHE of its own and YH_TUNE_DEFAULTS=0 for the layers concerned)
+SKIP_ALGOS = frozenset(x for x in os.environ.get("YH_SKIP_ALGOS", "").split(",") if x)
 
 # YH_ABL_SKIP=<entry point>[,...|wgrad]: TIMING EXPERIMENTS ONLY (results are wrong) — the named launches are left out of the
 # compiled programs, which gives the wall time a step would have if that family were free (profiles/r03_step_ablation.txt)
@@ -547,7 +551,8 @@ class Program:
         only the number of BatchNorm partial-sum rows follows the grid."""
         if os.environ.get("YH_CONV_TUNE", "1") == "0":
             return
-        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else KEY_CONV}:{kind}:" + ",".join(str(int(v)) for v in (
+        small3 = d.KH == 3 and d.stride == 1 and d.nseg == 1 and d.seg[0].C <= 128 and d.N <= 128 and kind != 'eval'
+        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else KEY_CONV)}:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
             int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), d.acc_rows))
@@ -573,11 +578,13 @@ class Program:
                 cands.append((1, tk, cap))
         d.tile_k = d.grid_cap = 0
         if os.environ.get("YH_CONV_V3", "1") != "0":
-            for algo in (2, 3, 4, 5, 6, 7):
+            for algo in (2, 3, 4, 5, 6, 7, 8):
+                if str(algo) in SKIP_ALGOS:
+                    continue
                 d.algo = algo
                 kn = self._kernel_name(d)
                 if ("conv_v3" in kn and algo < 5) or ("conv_halo_kernel" in kn and algo == 5) or ("conv_halo160" in kn and algo == 6) or \
-                        ("conv_dg2" in kn and algo == 7):
+                        ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8):
                     cands.append((algo, 0, 0))
                     if algo < 5 and kn.endswith(", true>") and all(d.seg[i].C % 32 == 0 for i in range(d.nseg)):
                         cands.append((algo, 32, 0))    # ragged last channel block: 32-channel steps instead of 64 + tail
