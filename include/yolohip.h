@@ -152,7 +152,9 @@ typedef struct yh_wgrad_desc {
     int32_t  tile_k;                  /* launch tuning: 64 = 64-pixel k-steps on the wide 64-row tilings (0 / 32: default);
                                          128 = the general 128-column tiling also where KH*KW*C <= 384 (needs >= 128 columns);
                                          on the general tiling: 32 = 32-pixel k-steps (two blocks per CU), 35 = four waves of
-                                         64 x 64 on 32-pixel k-steps */
+                                         64 x 64 on 32-pixel k-steps; 40 = the patch form (conv_wgp_kernel: 3x3 layers with 16 / 32 /
+                                         64 input channels and <= 64 outputs: the input patch of a pixel region staged once in LDS,
+                                         persistent blocks, `splits` caps their number) where yh_conv_wgrad_patch_ok() */
     /* optional workspace of >= yh_conv_wgrad_ws_bytes() bytes (16-byte aligned, caller-owned, may be shared by launches on ONE
      * stream): the split-M partial tiles are written there with plain stores and summed into dw by a second kernel in split
      * order — bit-reproducible, and faster than the fp32 atomics of the default form (NULL), which are bound by the atomic rate
@@ -171,6 +173,8 @@ typedef struct yh_wgrad_desc {
 } yh_wgrad_desc;
 int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
 size_t yh_conv_wgrad_ws_bytes(const yh_wgrad_desc* d);
+int yh_conv_wgrad_patch_ok(const yh_wgrad_desc* d);
+int yh_conv_wgrad_patch_name(const yh_wgrad_desc* d, char* buf, int buflen);   /* instantiation of the patch form, profiler spelling */
 const char* yh_conv_wgrad_kernel_name(int N, int Kseg);   /* instantiation used for a layer (tile_k 0), profiler spelling */
 const char* yh_conv_wgrad_kernel_name2(int N, int Kseg, int tile_k);
 /* number of (out-channel x im2col-column) tiles the kernel uses for a layer; callers size `splits` so that

@@ -166,6 +166,47 @@ def test_conv_wgrad(dev, B, H, W, Cin, Cout, k, s, p, splits, tile_k):
     assert lib().yh_conv_wgrad(C.byref(d), None) != 0      # a workspace that is too small is refused
 
 
+WGP_CASES = [
+    # B, H, W, Cin, Cout, stride, coff_k, Ctot
+    (2, 40, 48, 16, 32, 1, 0, 16),       # stem class (space-to-depth image, 16 channels: two taps per 32-column tile, half a tile past tap 8)
+    (1, 24, 32, 16, 64, 1, 0, 16),       # YOLOv5l stem
+    (2, 48, 40, 32, 32, 1, 0, 32),       # stage-1 bottleneck class; W not a multiple of 16, H a multiple of 16
+    (1, 33, 21, 32, 32, 1, 0, 32),       # odd sizes: ragged regions on both axes
+    (2, 32, 64, 32, 64, 2, 0, 32),       # stage-1 conv class (stride 2, 18 accumulator tiles)
+    (1, 20, 20, 64, 32, 1, 0, 64),
+    (1, 16, 32, 32, 48, 1, 32, 96),      # a segment of a concat input: columns [32, 64) of every tap; ragged n-tile
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,s,coff,Ctot", WGP_CASES)
+def test_conv_wgrad_patch_form(dev, B, H, W, Cin, Cout, s, coff, Ctot):
+    """conv_wgp_kernel (tile_k 40): weight gradient of the 3x3 small-channel layers from the input patch of a pixel region staged
+    once in LDS (nine taps = nine address offsets of transposing reads, persistent blocks) against torch; also with few blocks"""
+    import ctypes as C
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import lib
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    ldg = ((Cout + 7) // 8) * 8
+    gyb = torch.zeros(B, Ho, Wo, ldg, dtype=torch.bfloat16, device=dev)
+    gyb[..., :Cout] = _nhwc(B, Ho, Wo, Cout, dev, 95)
+    x = _nhwc(B, H, W, Cin, dev, 96)
+    w = torch.zeros(Cout, Cin, 3, 3, device=dev, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(_nchw(x), w, stride=s, padding=1), w, _nchw(gyb[..., :Cout]))
+    ref = ref.permute(0, 2, 3, 1)                                  # [N][kh][kw][C]
+    for blocks in (512, 3):
+        dw = torch.full((Cout, 9 * Ctot), 0.5, device=dev)
+        d = hipk.wgrad_desc(hipk.full(gyb), Cout, hipk.full(x), coff, Ctot, B, Ho, Wo, H, W, 3, s, 1, dw, blocks)
+        d.tile_k = 40
+        assert lib().yh_conv_wgrad_patch_ok(C.byref(d)) == 1
+        hipk.wgrad_launch(d)
+        torch.cuda.synchronize()
+        got = dw.reshape(Cout, 9, Ctot)
+        _close(got[:, :, coff:coff + Cin] - 0.5, ref.reshape(Cout, 9, Cin), 2e-3, 2e-3 * ref.abs().max().item())
+        rest = torch.ones(Ctot, dtype=torch.bool, device=dev)
+        rest[coff:coff + Cin] = False
+        assert (got[:, :, rest] == 0.5).all()                       # the other segments' columns are untouched
+
+
 @pytest.mark.parametrize("tile_k", [0, 64])
 @pytest.mark.parametrize("Cout", [32, 48, 64, 80])
 def test_conv_wgrad_fused_bn_backward(dev, Cout, tile_k):

@@ -44,6 +44,8 @@ for name, H, Cin, Cout, k, s in shapes:
     res = []
     for tot in (128, 256, 512, 768, 1024, 1536, 3072):
         splits = max(1, min((M + 255) // 256, (tot + ntile - 1) // ntile))
+        if os.environ.get("WG_TK") == "40":
+            splits = tot                     # patch form: `splits` caps the persistent blocks
         d = hipk.wgrad_desc(hipk.full(gy), Cout, hipk.full(x), 0, Cin, B, Ho, Ho, H, H, k, s, p, dw, splits)
         d.tile_k = int(os.environ.get("WG_TK", "0"))
         for _ in range(2):

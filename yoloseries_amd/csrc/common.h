@@ -89,4 +89,8 @@ int yh_dg2_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name
 int yh_p3_rows(const yh_conv_desc* d);                  // grid rows (== statistics / fused-reduction slab rows); 0 = not eligible
 int yh_p3_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
 
+// conv_wgp.hip: the patch form of the weight gradient behind yh_conv_wgrad (tile_k 40)
+int yh_wgp_ok(const yh_wgrad_desc* d);
+int yh_wgp_run(const yh_wgrad_desc* d, yh_stream stream);
+
 static inline bool yh_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
