@@ -175,7 +175,33 @@ WGP_CASES = [
     (2, 32, 64, 32, 64, 2, 0, 32),       # stage-1 conv class (stride 2, 18 accumulator tiles)
     (1, 20, 20, 64, 32, 1, 0, 64),
     (1, 16, 32, 32, 48, 1, 32, 96),      # a segment of a concat input: columns [32, 64) of every tap; ragged n-tile
+    (2, 24, 40, 64, 64, 1, 0, 64),       # 64 -> 64 (36 accumulator tiles: eight waves)
 ]
+WGP_1X1 = [(2, 24, 40, 64, 64, 0, 64), (1, 33, 17, 32, 32, 0, 32), (2, 16, 16, 64, 40, 64, 128), (1, 20, 36, 16, 64, 0, 16)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,coff,Ctot", WGP_1X1)
+def test_conv_wgrad_patch_form_1x1(dev, B, H, W, Cin, Cout, coff, Ctot):
+    """the patch form on 1x1 layers (the "patch" is the region itself; persistent blocks, one set of atomics per block)"""
+    import ctypes as C
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import lib
+    ldg = ((Cout + 7) // 8) * 8
+    gyb = torch.zeros(B, H, W, ldg, dtype=torch.bfloat16, device=dev)
+    gyb[..., :Cout] = _nhwc(B, H, W, Cout, dev, 97)
+    x = _nhwc(B, H, W, Cin, dev, 98)
+    ref = gyb[..., :Cout].float().reshape(-1, Cout).t() @ x.float().reshape(-1, Cin)
+    dw = torch.full((Cout, Ctot), 0.25, device=dev)
+    d = hipk.wgrad_desc(hipk.full(gyb), Cout, hipk.full(x), coff, Ctot, B, H, W, H, W, 1, 1, 0, dw, 1024)
+    d.tile_k = 40
+    assert lib().yh_conv_wgrad_patch_ok(C.byref(d)) == 1
+    hipk.wgrad_launch(d)
+    torch.cuda.synchronize()
+    _close(dw[:, coff:coff + Cin] - 0.25, ref, 2e-3, 2e-3 * ref.abs().max().item())
+    rest = torch.ones(Ctot, dtype=torch.bool, device=dev)
+    rest[coff:coff + Cin] = False
+    assert (dw[:, rest] == 0.25).all()
+
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,s,coff,Ctot", WGP_CASES)

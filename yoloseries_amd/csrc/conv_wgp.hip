@@ -37,16 +37,19 @@ struct WgpK {
     int B, Ho, Wo, Hi, Wi, stride;
     int TH, tx, ty, ntiles, PW, npatch;
     int ntile_n, ntile_c, ntiles_acc, tpw;      // accumulator tiles: n-tiles x channel-tiles (over the taps), tiles per wave
+    int ntaps, kw_, pad;                        // 9 taps (3x3, pad 1) or 1 (1x1, pad 0: the "patch" is the region itself)
     unsigned gybytes, xbytes;
 };
 
 // PG / PX: LDS pitches (elements) of the gy tile and of the patch: 64 or 192 bytes mod 256 (conflict-free transposing reads)
 constexpr int wgp_pitch(int cols) { const int r = (cols + 31) / 32 * 32; return (r % 64 == 32) ? r : r + 32; }
 
-template <int TPW, int NGI, int NXI>     // accumulator tiles per wave, 16-byte chunks per thread of the gy tile / of the patch
-__global__ __launch_bounds__(256, (TPW <= 2 ? WGP_MINB : 2)) void conv_wgp_kernel(const WgpK p, const int PG, const int PX)
+// NW waves per block (chosen so that the accumulator tiles divide evenly over them), TPW accumulator tiles per wave, NGI / NXI
+// 16-byte chunks per thread of the gy tile / of the patch
+template <int NW, int TPW, int NGI, int NXI>
+__global__ __launch_bounds__(64 * NW, (NW >= 8 ? 1 : (TPW <= 2 ? WGP_MINB : 2))) void conv_wgp_kernel(const WgpK p, const int PG, const int PX)
 {
-    constexpr int NT = 256;
+    constexpr int NT = 64 * NW;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* sG = reinterpret_cast<uint16_t*>(smem);             // [TH*16][PG]
@@ -70,12 +73,12 @@ __global__ __launch_bounds__(256, (TPW <= 2 ? WGP_MINB : 2)) void conv_wgp_kerne
     const int prow = 8 * (g16 >> 1) + q;                        // pixel of the k-group this lane addresses (second read: + 4)
     const int chalf = 16 * (g16 & 1) + 4 * pp;                  // column inside the 32-wide tile
 
-    // this wave's accumulator tiles, dealt round-robin: tile id = k * 4 + wave  ->  (n-tile, channel-tile over the taps)
+    // this wave's accumulator tiles, dealt round-robin: tile id = k * NW + wave  ->  (n-tile, channel-tile over the taps)
     int a_off[TPW], b_off[TPW];                                 // LDS element offsets of the lane's A / B row 0 for pixel 0 of a group
     bool live[TPW];
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
-        const int tile = k * 4 + wave;
+        const int tile = k * NW + wave;
         live[k] = tile < p.ntiles_acc;                          // wave-uniform
         const int nt = live[k] ? tile / p.ntile_c : 0;
         const int tc = live[k] ? tile - nt * p.ntile_c : 0;
@@ -84,8 +87,8 @@ __global__ __launch_bounds__(256, (TPW <= 2 ? WGP_MINB : 2)) void conv_wgp_kerne
         const int col = tc * 32 + chalf;
         const int tap = col / p.C, c = col - tap * p.C;
         // a 16-column half past the last tap (C = 16: 9 taps fill 4.5 tiles) reads tap 8 again: its columns are dropped in the epilogue
-        const int tp = tap < 9 ? tap : 8;
-        const int kh = tp / 3, kw = tp - kh * 3;
+        const int tp = tap < p.ntaps ? tap : p.ntaps - 1;
+        const int kh = tp / p.kw_, kw = tp - kh * p.kw_;
         b_off[k] = (kh * p.PW + kw + prow * s) * PX + c;
     }
 
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, (TPW <= 2 ? WGP_MINB : 2)) void conv_wgp_kerne
             const bool ok = id < ng_items && gi < p.Ho && gj < p.Wo;
             rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsg, ok ? (unsigned)(((b * p.Ho + gi) * p.Wo + gj) * (p.ldg * 2) + chn * 16) : OOB, 0, 0);
         }
-        const int pi0 = i0 * s - 1, pj0 = j0 * s - 1;
+        const int pi0 = i0 * s - p.pad, pj0 = j0 * s - p.pad;
 #pragma unroll
         for (int j = 0; j < NXI; ++j) {
             const int id = t + j * NT;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, (TPW <= 2 ? WGP_MINB : 2)) void conv_wgp_kerne
 #pragma unroll
             for (int k = 0; k < TPW; ++k) {
                 if (!live[k]) continue;
-                const int nt = (k * 4 + wave) / p.ntile_c;
+                const int nt = (k * NW + wave) / p.ntile_c;
                 if (nt != last_nt) {                   // consecutive tiles of a wave mostly share their n-tile
                     const v4s lo = wgp_tr(ga + a_off[k]);
                     const v4s hi = wgp_tr(ga + a_off[k] + 4 * PG);
@@ -174,11 +177,11 @@ __global__ __launch_bounds__(256, (TPW <= 2 ? WGP_MINB : 2)) void conv_wgp_kerne
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
         if (!live[k]) continue;
-        const int tile_id = k * 4 + wave;
+        const int tile_id = k * NW + wave;
         const int nt = tile_id / p.ntile_c, tc = tile_id - nt * p.ntile_c;
         const int col = tc * 32 + (lane & 31);
         const int tap = col / p.C, c = col - tap * p.C;
-        if (tap >= 9) continue;
+        if (tap >= p.ntaps) continue;
         float* base = p.dw + (size_t)tap * p.Ctot + p.coff_k + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -188,11 +191,13 @@ __global__ __launch_bounds__(256, (TPW <= 2 ? WGP_MINB : 2)) void conv_wgp_kerne
     }
 }
 
-struct WgpPlan { WgpK k; int tpw, ngi, nxi, PG, PX, gx, smem; };
+struct WgpPlan { WgpK k; int nw, tpw, ngi, nxi, PG, PX, gx, smem; };
 
 bool wgp_plan(const yh_wgrad_desc* d, WgpPlan* pl)
 {
-    if (d->KH != 3 || d->KW != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2) || d->seg.ups) return false;
+    const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2);
+    const bool k1 = d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 1;
+    if (!(k3 || k1) || d->seg.ups) return false;
     if (d->bn_z || d->partial) return false;
     const int C = d->seg.C, N = d->N;
     if (!(C == 16 || C == 32 || C == 64) || N < 8 || N > 64) return false;      // staging registers: <= 8 gy chunks per pixel
@@ -206,28 +211,35 @@ bool wgp_plan(const yh_wgrad_desc* d, WgpPlan* pl)
     const int s = d->stride;
     k.TH = s == 1 ? 16 : 8;                             // 256 / 128 region pixels; patch 18 x 18 / 17 x 33 + 1
     if (k.TH > d->Ho) k.TH = d->Ho;
-    k.PW = WGP_TW * s + 2;
-    k.npatch = (k.TH * s + 2) * k.PW;
+    k.ntaps = k3 ? 9 : 1; k.kw_ = k3 ? 3 : 1; k.pad = d->pad;
+    k.PW = WGP_TW * s + 2 * d->pad;
+    k.npatch = (k.TH * s + 2 * d->pad) * k.PW;
     k.tx = (d->Wo + WGP_TW - 1) / WGP_TW; k.ty = (d->Ho + k.TH - 1) / k.TH;
     k.ntiles = d->B * k.tx * k.ty;
     k.ntile_n = (N + 31) / 32;
-    k.ntile_c = (9 * C + 31) / 32;
+    k.ntile_c = (k.ntaps * C + 31) / 32;
     k.ntiles_acc = k.ntile_n * k.ntile_c;
-    k.tpw = (k.ntiles_acc + 3) / 4;
+    // waves per block: five where the accumulator tiles divide evenly over them (the stems: 5 tiles = 5 x 1, 10 = 5 x 2: 172 ->
+    // 151 us on YOLOv5s), else four (measured: 3 waves x 3 tiles for the 9-tile layers equal, 6 x 3 for the 18-tile layer 20 % slower)
+    const int na = k.ntiles_acc;
+    const int nw = (na == 5 || na == 10) ? 5 : (na > 20 ? 8 : 4);      // > 20 tiles (64 -> 64, 3x3): eight waves x 5
+    pl->nw = nw;
+    k.tpw = (na + nw - 1) / nw;
     if (k.tpw > 5) return false;                        // <= 5 x 16 accumulator registers per lane
     pl->tpw = k.tpw;
-    pl->ngi = (k.TH * WGP_TW * ((N + 7) / 8) + 255) / 256;       // 16-byte chunks per thread: gy tile, patch
-    pl->nxi = (k.npatch * (C / 8) + 255) / 256;
+    const int nt = 64 * nw;
+    pl->ngi = (k.TH * WGP_TW * ((N + 7) / 8) + nt - 1) / nt;     // 16-byte chunks per thread: gy tile, patch
+    pl->nxi = (k.npatch * (C / 8) + nt - 1) / nt;
     k.gy = d->gy; k.ldg = d->ldg; k.N = N;
     k.x = d->seg.ptr; k.ldx = d->seg.ld; k.C = C;
-    k.dw = d->dw; k.Ktot = 9 * d->Ctot; k.Ctot = d->Ctot; k.coff_k = d->coff_k;
+    k.dw = d->dw; k.Ktot = k.ntaps * d->Ctot; k.Ctot = d->Ctot; k.coff_k = d->coff_k;
     k.B = d->B; k.Ho = d->Ho; k.Wo = d->Wo; k.Hi = d->Hi; k.Wi = d->Wi; k.stride = s;
     k.gybytes = (unsigned)gyb; k.xbytes = (unsigned)xb;
     pl->PG = wgp_pitch(k.ntile_n * 32);
     pl->PX = wgp_pitch(C < 32 ? 32 : C);
     pl->smem = (k.TH * WGP_TW * pl->PG + k.npatch * pl->PX) * 2;
     int occ = (150 * 1024) / pl->smem;
-    const int occ_max = k.tpw <= 2 ? WGP_MINB : 2;      // __launch_bounds__
+    const int occ_max = nw >= 8 ? 1 : (k.tpw <= 2 ? WGP_MINB : 2);      // __launch_bounds__
     if (occ > occ_max) occ = occ_max;
     if (occ < 1) return false;
     int gx = 256 * occ;
@@ -241,11 +253,12 @@ bool wgp_plan(const yh_wgrad_desc* d, WgpPlan* pl)
 int yh_wgp_ok(const yh_wgrad_desc* d) { WgpPlan pl; return wgp_plan(d, &pl) ? 1 : 0; }
 
 // instantiation table shared by the launcher and the name query: (accumulator tiles per wave, gy chunks, patch chunks per thread)
-static const int kWgpInst[5][3] = {{2, 8, 3}, {3, 8, 3}, {3, 4, 6}, {5, 4, 10}, {5, 8, 11}};
+// (waves, accumulator tiles per wave, gy chunks, patch chunks per thread)
+static const int kWgpInst[7][4] = {{5, 1, 4, 3}, {5, 2, 7, 3}, {4, 1, 8, 8}, {4, 3, 4, 6}, {4, 5, 4, 10}, {4, 5, 8, 11}, {8, 5, 4, 6}};
 static int wgp_pick(const WgpPlan& pl)
 {
-    for (int i = 0; i < 5; ++i)
-        if (pl.tpw <= kWgpInst[i][0] && pl.ngi <= kWgpInst[i][1] && pl.nxi <= kWgpInst[i][2]) return i;
+    for (int i = 0; i < 7; ++i)
+        if (pl.nw == kWgpInst[i][0] && pl.tpw <= kWgpInst[i][1] && pl.ngi <= kWgpInst[i][2] && pl.nxi <= kWgpInst[i][3]) return i;
     return -1;
 }
 
@@ -257,7 +270,7 @@ extern "C" int yh_conv_wgrad_patch_name(const yh_wgrad_desc* d, char* buf, int b
     buf[0] = 0;
     if (!d || !wgp_plan(d, &pl)) return YH_OK;
     const int i = wgp_pick(pl);
-    if (i >= 0) snprintf(buf, buflen, "conv_wgp_kernel<%d, %d, %d>", kWgpInst[i][0], kWgpInst[i][1], kWgpInst[i][2]);
+    if (i >= 0) snprintf(buf, buflen, "conv_wgp_kernel<%d, %d, %d, %d>", kWgpInst[i][0], kWgpInst[i][1], kWgpInst[i][2], kWgpInst[i][3]);
     return YH_OK;
 }
 
@@ -268,17 +281,19 @@ int yh_wgp_run(const yh_wgrad_desc* d, yh_stream stream)
     hipStream_t st = (hipStream_t)stream;
     const int inst = wgp_pick(pl);
     YH_CHECK_ARG(inst >= 0, "yh_conv_wgrad: no patch-form instantiation for this layer");
-#define YH_TRY_WGP(I_, TPW_, NGI_, NXI_)                                                                          \
+#define YH_TRY_WGP(I_, NW_, TPW_, NGI_, NXI_)                                                                     \
     if (inst == I_) {                                                                                             \
         static bool attr_set = false;                                                                             \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgp_kernel<TPW_, NGI_, NXI_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; } \
-        conv_wgp_kernel<TPW_, NGI_, NXI_><<<dim3(pl.gx), dim3(256), pl.smem, st>>>(pl.k, pl.PG, pl.PX);            \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgp_kernel<NW_, TPW_, NGI_, NXI_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; } \
+        conv_wgp_kernel<NW_, TPW_, NGI_, NXI_><<<dim3(pl.gx), dim3(64 * NW_), pl.smem, st>>>(pl.k, pl.PG, pl.PX);  \
     }
-    YH_TRY_WGP(0, 2, 8, 3)        // stem, <= 32 outputs (C = 16: 5 tiles)
-    YH_TRY_WGP(1, 3, 8, 3)        // stem, 64 outputs
-    YH_TRY_WGP(2, 3, 4, 6)        // 32 -> 32, stride 1 (9 tiles)
-    YH_TRY_WGP(3, 5, 4, 10)       // 32 -> 64, stride 2 (18 tiles)
-    YH_TRY_WGP(4, 5, 8, 11)       // the rest (32 -> 64 stride 1, 64 -> 32)
+    YH_TRY_WGP(0, 5, 1, 4, 3)        // stem, <= 32 outputs (C = 16: 5 tiles, one per wave)
+    YH_TRY_WGP(1, 5, 2, 7, 3)        // stem, 64 outputs (10 tiles)
+    YH_TRY_WGP(2, 4, 1, 8, 8)        // 1x1 layers: <= 64 channels on both sides (<= 4 tiles)
+    YH_TRY_WGP(3, 4, 3, 4, 6)        // 32 -> 32, 3x3 stride 1 (9 tiles)
+    YH_TRY_WGP(4, 4, 5, 4, 10)       // 32 -> 64, 3x3 stride 2 (18 tiles)
+    YH_TRY_WGP(5, 4, 5, 8, 11)       // the rest on four waves (32 -> 64 stride 1, 64 -> 32)
+    YH_TRY_WGP(6, 8, 5, 4, 6)        // 64 -> 64, 3x3 stride 1 (36 tiles: eight waves)
 #undef YH_TRY_WGP
     YH_CHECK_LAUNCH("yh_conv_wgrad(patch)");
     return YH_OK;
