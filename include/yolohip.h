@@ -273,6 +273,16 @@ int yh_maxpool5_fwd(const yh_bf16* x, int ldx, int B, int H, int W, int C,
                     yh_bf16* out, int ldo, int8_t* idx, yh_stream stream);
 int yh_maxpool5_bwd(const yh_bf16* gout, int ldgo, const int8_t* idx, int B, int H, int W, int C,
                     yh_bf16* gin, int ldgi, int accumulate, yh_stream stream);
+/* FastSPP's chain x2 = mp(x), x3 = mp(x2), x4 = mp(x3) (utils/layer_tools.py:282-288) in one launch per direction for maps of
+ * <= 480 pixels (yh_sppf_pool3_ok; 20 x 20 at 640^2 input): the map of one image x 64 channels lives in LDS, the pools run
+ * separably.  Bit-identical to three yh_maxpool5_fwd / yh_maxpool5_bwd launches (arg-max rule, summation order, rounding points).
+ * Backward: g1..g3 = gradients of x2..x4 as they stand before the pools' backward (ld ldg), gx (+)= the chain's gradient w.r.t. x;
+ * the intermediate sums g(x3)', g(x2)' are not written back. */
+int yh_sppf_pool3_ok(int H, int W, int C);
+int yh_sppf_pool3_fwd(const yh_bf16* x, int ldx, int B, int H, int W, int C, yh_bf16* o1, yh_bf16* o2, yh_bf16* o3, int ldo,
+                      int8_t* i1, int8_t* i2, int8_t* i3, yh_stream stream);
+int yh_sppf_pool3_bwd(const yh_bf16* g1, const yh_bf16* g2, const yh_bf16* g3, int ldg, const int8_t* i1, const int8_t* i2, const int8_t* i3,
+                      int B, int H, int W, int C, yh_bf16* gx, int ldx, int accumulate, yh_stream stream);
 /* gradient of nearest-2x upsample: glo (op)= sum of the 2x2 block of ghi        */
 int yh_upsample2_bwd(const yh_bf16* ghi, int ldh, int B, int Hlo, int Wlo, int C,
                      yh_bf16* glo, int ldl, int accumulate, yh_stream stream);

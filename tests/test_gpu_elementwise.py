@@ -201,6 +201,44 @@ def test_maxpool5_fwd_bwd(dev, B, H, W, C):
     assert torch.equal(out2.float()[ok], ref2[ok])
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 20, 20, 256), (2, 12, 17, 72), (1, 5, 3, 8), (2, 20, 24, 128)])
+def test_sppf_fused_pools_bit_identical(dev, B, H, W, C):
+    """FastSPP's three chained 5x5 pools in one launch per direction (csrc/sppf.hip) against three yh_maxpool5_fwd / _bwd launches:
+    outputs, arg-max bytes and the input gradient BIT-identical — with ties (coarse values), NaNs and a ragged channel count"""
+    import ctypes as C_
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import check, lib, stream_ptr
+    assert lib().yh_sppf_pool3_ok(H, W, C) == 1 and lib().yh_sppf_pool3_ok(40, 40, C) == 0
+    cat = torch.zeros(B, H, W, 4 * C, dtype=torch.bfloat16, device=dev)
+    x = (_rand_bf16((B, H, W, C), dev, 16).float() * 2).round().div(2).to(torch.bfloat16)
+    x[0, H // 2, W // 2, :3] = float("nan")
+    cat[..., :C] = x
+    ref = cat.clone()
+    idx_r = [torch.zeros(B, H, W, C, dtype=torch.int8, device=dev) for _ in range(3)]
+    for k in range(3):
+        hipk.maxpool5_fwd(hipk.Slice(ref, k * C, C), B, H, W, hipk.Slice(ref, (k + 1) * C, C), idx_r[k])
+    idx_f = [torch.full((B, H, W, C), 99, dtype=torch.int8, device=dev) for _ in range(3)]
+    sl = [hipk.Slice(cat, k * C, C) for k in range(4)]
+    check(lib().yh_sppf_pool3_fwd(sl[0].ptr(), sl[0].ld, B, H, W, C, sl[1].ptr(), sl[2].ptr(), sl[3].ptr(), sl[1].ld,
+                                  idx_f[0].data_ptr(), idx_f[1].data_ptr(), idx_f[2].data_ptr(), stream_ptr()), "yh_sppf_pool3_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(cat.view(torch.int16), ref.view(torch.int16))
+    for a, b_ in zip(idx_f, idx_r):
+        assert torch.equal(a, b_)
+    # backward: gradient of the concat buffer as cba2's data gradient leaves it, then the pools' backward
+    g = _rand_bf16((B, H, W, 4 * C), dev, 17)
+    gr = g.clone()
+    for k in (2, 1, 0):
+        hipk.maxpool5_bwd(hipk.Slice(gr, (k + 1) * C, C), idx_r[k], B, H, W, hipk.Slice(gr, k * C, C), 1)
+    gf = g.clone()
+    gs = [hipk.Slice(gf, k * C, C) for k in range(4)]
+    check(lib().yh_sppf_pool3_bwd(gs[1].ptr(), gs[2].ptr(), gs[3].ptr(), gs[1].ld, idx_f[0].data_ptr(), idx_f[1].data_ptr(), idx_f[2].data_ptr(),
+                                  B, H, W, C, gs[0].ptr(), gs[0].ld, 1, stream_ptr()), "yh_sppf_pool3_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(gf[..., :C].view(torch.int16), gr[..., :C].view(torch.int16))
+    assert torch.equal(gf[..., C:].view(torch.int16), g[..., C:].view(torch.int16))          # the intermediate gradients are left as they were
+
+
 def test_upsample2_bwd_and_s2d(dev):
     from yoloseries_amd import hipk
     B, Hl, Wl, C = 2, 10, 12, 32

@@ -1,4 +1,2 @@
-python3 -m pytest tests -x -q -m gpu > gpurun_out/r3_full3.log 2>&1; tail -3 gpurun_out/r3_full3.log
-python3 bench.py --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-140
-python3 bench.py --no-cpu-baseline --no-roofline --model large 2>/dev/null | cut -c1-140
-python3 bench.py --no-cpu-baseline --no-roofline --workload yolox 2>/dev/null | cut -c1-140
+python3 -m pytest tests/test_gpu_elementwise.py -x -q -k "sppf" 2>&1 | tail -2
+YH_BENCH_LAYERS=500 python3 bench.py --no-cpu-baseline --steps 10 2>&1 >/dev/null | grep -i "pool"

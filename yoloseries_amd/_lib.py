@@ -160,6 +160,9 @@ _SIGS = {
     "yh_colsum": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp]),
     "yh_maxpool5_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "yh_maxpool5_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "yh_sppf_pool3_ok": (_i32, [_i32, _i32, _i32]),
+    "yh_sppf_pool3_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "yh_sppf_pool3_bwd": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "yh_upsample2_bwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "yh_input_s2d": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "yh_fill_u32": (_i32, [_vp, C.c_uint32, _i64, _vp]),

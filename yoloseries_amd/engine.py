@@ -132,6 +132,7 @@ MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct
 # 0.55 ms against 0.22 (apply pass, HBM-bound) + 0.25 (weight gradient) — the sigmoid of 210 M elements is hidden behind HBM time in
 # the streaming pass but not between the barriers of a 15-wave-per-CU GEMM — and the step gets 1 % slower: opt-in.
 FUSE_STEM_BWD = os.environ.get("YH_FUSE_STEM_BWD", "0") == "1"
+SPPF_FUSE = os.environ.get("YH_SPPF_FUSE", "1") != "0"      # FastSPP's three pools in one launch per direction (csrc/sppf.hip)
 WG_WS_BYTES = (256 << 20) if os.environ.get("YH_WGRAD_PARTIAL", "0") == "1" else 0
 NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weight gradients may lag behind by
 
@@ -281,6 +282,20 @@ class PoolOp:
     def __init__(self, name, src, dst):
         self.name, self.src, self.dst = name, src, dst
         self.idx = None
+
+
+def sppf_chain(ops, i, L):
+    """ops[i], ops[i+1], ops[i+2] = FastSPP's three max-pools chained through slices of one concat buffer (utils/layer_tools.py:282-288)
+    on a map the fused kernels take (csrc/sppf.hip)?  YH_SPPF_FUSE=0: never."""
+    if not SPPF_FUSE or i + 2 >= len(ops) or not all(isinstance(o, PoolOp) for o in ops[i:i + 3]):
+        return False
+    a, b_, c = ops[i:i + 3]
+    same = lambda r1, r2: r1.buf is r2.buf and r1.coff == r2.coff and r1.C == r2.C and not r1.ups and not r2.ups   # noqa: E731
+    if not (same(a.dst, b_.src) and same(b_.dst, c.src)):
+        return False
+    if not (a.src.buf is a.dst.buf and a.src.C == a.dst.C == b_.dst.C == c.dst.C and not a.src.ups):
+        return False
+    return bool(L.yh_sppf_pool3_ok(a.src.buf.H, a.src.buf.W, a.src.C))
 
 
 class Builder:
@@ -629,7 +644,19 @@ class Program:
         self.cmd_train, self.cmd_eval = None, []
         self.op_state = {}
         fold_items = []                 # every BatchNorm of the net is folded to (scale, shift) by ONE launch ahead of the convs
-        for op in self.ops:
+        skip = set()
+        for oi, op in enumerate(self.ops):
+            if oi in skip:
+                continue
+            if isinstance(op, PoolOp) and sppf_chain(self.ops, oi, L):
+                p1, p2, p3 = self.ops[oi:oi + 3]
+                s = p1.src.sl()
+                d1, d2, d3 = p1.dst.sl(), p2.dst.sl(), p3.dst.sl()
+                Hs, Ws = p1.src.buf.H, p1.src.buf.W
+                self.cmd_eval.append((L.yh_sppf_pool3_fwd, (s.ptr(), s.ld, B, Hs, Ws, s.C, d1.ptr(), d2.ptr(), d3.ptr(), d1.ld, None, None, None),
+                                      p1.name, ('yh_sppf_pool3_fwd', 0, 8.0 * B * Hs * Ws * s.C)))
+                skip.update((oi + 1, oi + 2))
+                continue
             if isinstance(op, PoolOp):
                 s, dd = op.src.sl(), op.dst.sl()
                 args = (s.ptr(), s.ld, B, op.src.buf.H, op.src.buf.W, s.C, dd.ptr(), dd.ld, None)
@@ -685,7 +712,22 @@ class Program:
                 b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=self.dev)
         self.cmd_train = []
         self._acc_fwd_elems = 0
-        for op in self.ops:
+        skip = set()
+        for oi, op in enumerate(self.ops):
+            if oi in skip:
+                continue
+            if isinstance(op, PoolOp) and sppf_chain(self.ops, oi, L):
+                p1, p2, p3 = self.ops[oi:oi + 3]
+                Hs, Ws = p1.src.buf.H, p1.src.buf.W
+                for q in (p1, p2, p3):
+                    q.idx = torch.zeros(B, Hs, Ws, q.src.C, dtype=torch.int8, device=self.dev)
+                s = p1.src.sl()
+                d1, d2, d3 = p1.dst.sl(), p2.dst.sl(), p3.dst.sl()
+                self.cmd_train.append((L.yh_sppf_pool3_fwd, (s.ptr(), s.ld, B, Hs, Ws, s.C, d1.ptr(), d2.ptr(), d3.ptr(), d1.ld,
+                                                             p1.idx.data_ptr(), p2.idx.data_ptr(), p3.idx.data_ptr()),
+                                       p1.name, ('yh_sppf_pool3_fwd', 0, 11.0 * B * Hs * Ws * s.C)))
+                skip.update((oi + 1, oi + 2))
+                continue
             if isinstance(op, PoolOp):
                 op.idx = torch.zeros(B, op.src.buf.H, op.src.buf.W, op.src.C, dtype=torch.int8, device=self.dev)
                 s, dd = op.src.sl(), op.dst.sl()
@@ -977,7 +1019,27 @@ class Program:
         self.acc_bwd = torch.zeros(max(tot, 2), dtype=torch.int64, device=self.dev) if BN_ACC else None
 
         marks = []
-        for op in reversed(self.ops):
+        skip_bwd = set()
+        nops = len(self.ops)
+        for ri, op in enumerate(reversed(self.ops)):
+            oi = nops - 1 - ri
+            if oi in skip_bwd:
+                continue
+            if isinstance(op, PoolOp) and oi >= 2 and sppf_chain(self.ops, oi - 2, L):
+                # the chain's backward in one launch; needs every pool's input gradient to exist already (cba2's data gradient wrote
+                # all four slices of the concat buffer earlier in this program) — else the three single launches below
+                p1, p2, p3 = self.ops[oi - 2:oi + 1]
+                flags = lambda r: r.buf.ginit[r.coff:r.coff + r.C]        # noqa: E731
+                if flags(p3.dst).all() and flags(p3.src).all() and flags(p2.src).all():
+                    acc1 = claim(p1.src)
+                    claim(p2.src); claim(p3.src)
+                    g1, g2, g3, gx_ = p1.dst.sl(True), p2.dst.sl(True), p3.dst.sl(True), p1.src.sl(True)
+                    Hs, Ws = p1.src.buf.H, p1.src.buf.W
+                    cmds.append((L.yh_sppf_pool3_bwd, (g1.ptr(), g2.ptr(), g3.ptr(), g1.ld, p1.idx.data_ptr(), p2.idx.data_ptr(), p3.idx.data_ptr(),
+                                                       B, Hs, Ws, g1.C, gx_.ptr(), gx_.ld, acc1), p1.name,
+                                 ('yh_sppf_pool3_bwd', 0, (13.0 if acc1 else 11.0) * B * Hs * Ws * g1.C)))
+                    skip_bwd.update((oi - 1, oi - 2))
+                    continue
             if isinstance(op, PoolOp):
                 require(op.dst, op.name)
                 acc = claim(op.src)
