@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
         const int cch = t % CPR;
         const int n = c0 + cch * 8;
         int oidx[NOI];
+        uint4 zpre[EPI == 3 ? NOI : 1];                // EPI 3: the producer's z chunks are requested before the barriers of the staging
 #pragma unroll
         for (int it = 0; it < NOI; ++it) {
             const int r = t / CPR + it * (NT / CPR);
@@ -214,6 +215,10 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
             const int gi = i0 + i, gj = j0 + j;
             const bool ok = r < p.TH * p.TW && gi < p.H && gj < p.W && n < p.N;
             oidx[it] = ok ? (b * p.H + gi) * p.W + gj : -1;
+            if (EPI == 3) {
+                zpre[it] = make_uint4(0, 0, 0, 0);
+                if (ok) zpre[it] = p3_ld_nt16(p.z + (size_t)oidx[it] * p.ldz + n);
+            }
         }
         __syncthreads();                               // fragment reads of the last channel block are done
 #pragma unroll
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
             if (EPI == 3) {
                 float g[8], z[8];
                 unpack8(v, g);
-                unpack8(p3_ld_nt16(p.z + (size_t)oidx[it] * p.ldz + n), z);
+                unpack8(zpre[it], z);
                 const float4 s0 = *reinterpret_cast<const float4*>(sStat + cch * 8);
                 const float4 s1 = *reinterpret_cast<const float4*>(sStat + cch * 8 + 4);
                 const float4 h0 = *reinterpret_cast<const float4*>(sStat + CB + cch * 8);
