@@ -104,7 +104,10 @@ typedef struct yh_conv_desc {
                            * 7 the stride-2 data-gradient kernel (conv_dg2_kernel: DGRAD of a 3x3 / s2 / p1 layer with even output
                            * dims and gz channels in a multiple of 32: the four parity classes from one LDS patch of gz);
                            * 8 the 3x3 / stride-1 patch kernel for small channel counts (conv_p3_kernel: <= 128 channels in a multiple
-                           * of 32 in, <= 128 out, forward with statistics or data gradient with the fused reduction) */
+                           * of 32 in, <= 128 out, forward with statistics or data gradient with the fused reduction);
+                           * 9 the 80-channel halo kernel (conv_h80_kernel: 3x3 / s1 / p1 with exactly 80 input channels and N % 80 == 0,
+                           * no statistics: 256-pixel x 80-channel tiles on 16x16x32 MFMAs, reduction over the flattened (tap, channel)
+                           * index — no padding of N or K) */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
      * contributions already in out0 are added first and the sums are taken over the rounded total):

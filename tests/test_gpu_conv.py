@@ -343,6 +343,8 @@ def _expect_family(d, algo):
         assert "conv_dg2_kernel" in kn, kn
     if algo == 8:
         assert "conv_p3_kernel" in kn, kn
+    if algo == 9:
+        assert "conv_h80_kernel" in kn, kn
 
 
 @pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])
@@ -455,6 +457,85 @@ def test_conv_patch3_kernel(dev, B, H, W, Cin, Cout, tile_n):
     assert ((stats[:, 1, :Cout].double().sum(0) - (o ** 2).sum(0)).abs() <= 1e-3 + 1e-5 * (o ** 2).sum(0)).all()
     if Cout % 32 == 0:                 # the data gradient reads gz with Cout channels: whole 32-channel blocks needed
         _dgrad_check(dev, B, H, W, Cin, Cout, 3, 1, 1, 8, tile_n=tile_n)
+
+
+H80_CASES = [
+    # B, H, W, Cout: ConvBnAct(80, Cout, 3, 1, 1) on an H x W map (YOLOv5x stage-1 bottlenecks: 80 -> 80 at 320 x 320)
+    (2, 32, 32, 80),            # whole 16 x 16 tiles
+    (1, 40, 24, 80),            # tiles cut by the right / lower edge
+    (3, 19, 23, 80),            # odd sizes: ragged tiles, 16-pixel groups that wrap tile rows; several images per block
+    (1, 48, 48, 160),           # two blocks along the output channels
+    (2, 7, 5, 80),              # map smaller than a tile
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cout", H80_CASES)
+def test_conv_halo80_kernel(dev, B, H, W, Cout):
+    """conv_h80_kernel (algo 9): 3x3 / stride-1 layers with 80 input channels on 256-pixel x 80-channel tiles, reduction over the
+    flattened (tap, channel) index — plain store, folded BatchNorm + SiLU + residual into a channel slice (the C3 concat buffer) with
+    a split destination, accumulate, and the data gradient (flipped taps) — against torch"""
+    from yoloseries_amd import hipk
+    Cin = 80
+    x = _nhwc(B, H, W, Cin, dev, 91)
+    g = torch.Generator().manual_seed(92)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    ref = F.conv2d(_nchw(x), w, None, stride=1, padding=1).permute(0, 2, 3, 1)
+    # the input as a channel slice of a wider buffer (ld > C); NaN around it must never be read into a result
+    xbuf = torch.full((B, H, W, Cin + 16), float("nan"), dtype=torch.bfloat16, device=dev)
+    xbuf[..., 8:8 + Cin] = x
+    xin = hipk.Slice(xbuf, 8, Cin)
+    out = torch.full((B, H, W, Cout), 7.0, dtype=torch.bfloat16, device=dev)
+    d = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.full(out))
+    d.algo = 9
+    assert "conv_h80_kernel<80, 5, 0>" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out, ref, 8e-3, 2e-2)
+    # folded BatchNorm + SiLU + residual on the first 80 channels written into a slice of a wider buffer, split destination
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=g).to(dev)
+    res = _nhwc(B, H, W, 80, dev, 93)
+    cat = torch.full((B, H, W, 160), 5.0, dtype=torch.bfloat16, device=dev)
+    a = F.silu(ref * scale + shift)
+    if Cout > 80:
+        obuf = torch.full((B, H, W, Cout - 80 + 16), 3.0, dtype=torch.bfloat16, device=dev)
+        d2 = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.Slice(cat, 0, 80), nsplit=80,
+                            out1=hipk.Slice(obuf, 8, Cout - 80), scale=scale, shift=shift, act=hipk.YH_ACT_SILU, res=hipk.full(res))
+    else:
+        d2 = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.Slice(cat, 0, 80),
+                            scale=scale, shift=shift, act=hipk.YH_ACT_SILU, res=hipk.full(res))
+    d2.algo = 9
+    assert "conv_h80_kernel<80, 5, 2>" in _kname(d2), _kname(d2)
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    _close(cat[..., :80], a[..., :80].to(torch.bfloat16).float() + res.float(), 1e-2, 3e-2)
+    assert (cat[..., 80:] == 5.0).all()
+    if Cout > 80:
+        _close(obuf[..., 8:8 + Cout - 80], a[..., 80:], 8e-3, 2e-2)
+        assert (obuf[..., :8] == 3.0).all() and (obuf[..., 8 + Cout - 80:] == 3.0).all()
+    # accumulate on top of an existing tensor
+    acc0 = _nhwc(B, H, W, Cout, dev, 94)
+    acc = acc0.clone()
+    d3 = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 3, 1, 1, wp, Cout, hipk.full(acc), accumulate=1)
+    d3.algo = 9
+    hipk.conv_launch(d3)
+    torch.cuda.synchronize()
+    _close(acc, ref.to(torch.bfloat16).float() + acc0.float(), 1e-2, 3e-2)
+    # data gradient of an 80 -> Cout' layer: gz has 80 channels, the flipped weight image
+    if Cout == 80:
+        gy = _nhwc(B, H, W, 80, dev, 95)
+        w2 = (torch.randn(80, 80, 3, 3, generator=g) / (80 * 9) ** 0.5).to(torch.bfloat16).float().to(dev)
+        wd = hipk.pack_weight_dgrad(w2)
+        xz = torch.zeros(B, 80, H, W, device=dev, requires_grad=True)
+        (gref,) = torch.autograd.grad(F.conv2d(xz, w2, stride=1, padding=1), xz, _nchw(gy))
+        gx = torch.zeros(B, H, W, 80, dtype=torch.bfloat16, device=dev)
+        d4 = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, H, W, 3, 1, 1, wd, 80, hipk.full(gx))
+        d4.algo = 9
+        assert "conv_h80_kernel" in _kname(d4), _kname(d4)
+        hipk.conv_launch(d4)
+        torch.cuda.synchronize()
+        _close(gx, gref.permute(0, 2, 3, 1), 1e-2, 4e-2)
 
 
 def _dgrad_check(dev, B, H, W, Cin, Cout, k, s, p, algo, tile_k=0, tile_n=0):

@@ -89,6 +89,10 @@ int yh_dg2_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name
 int yh_p3_rows(const yh_conv_desc* d);                  // grid rows (== statistics / fused-reduction slab rows); 0 = not eligible
 int yh_p3_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
 
+// conv_h80.hip: the 80-channel 3x3 halo kernel (YOLOv5x stage 1, inference epilogues) behind yh_conv_igemm (algo 9)
+int yh_h80_rows(const yh_conv_desc* d);                 // grid rows; 0 = not eligible
+int yh_h80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
+
 // conv_wgp.hip: the patch form of the weight gradient behind yh_conv_wgrad (tile_k 40)
 int yh_wgp_ok(const yh_wgrad_desc* d);
 int yh_wgp_run(const yh_wgrad_desc* d, yh_stream stream);

@@ -1,0 +1,453 @@
+// 3x3 / stride-1 / pad-1 convolution for the 80-channel layers of YOLOv5x (stage-1 bottlenecks at 320 x 320 for a 1280 x 1280
+// input: models/normal/yolov5x.py, utils/layer_tools.py:97-114), inference epilogues.  The 128-wide halo kernel computes 128
+// output channels for 80 and spends nine barriers on the 16-channel tail of the input (310 TFLOP/s); this kernel has no padding on
+// either side:
+//
+//   * N: the block's tile is 256 pixels x 80 channels on v_mfma_f32_16x16x32_bf16 (8 waves of 32 pixels x 80 channels = 2 x 5
+//     tiles of 16 x 16; operands swapped, D = W X^T: a lane holds one pixel and four consecutive channels per accumulator);
+//   * K: the reduction runs over the FLATTENED (tap, channel) index, 9 * 80 = 720 = 22.5 MFMA steps of 32 — an MFMA step may start
+//     in one tap and end in the next.  Lane (l & 15, kq = l >> 4) supplies the 8 reduction indices of chunk q = 4 ks + kq; the patch
+//     address of a chunk — (tap shift) * pitch + channel chunk — depends on kq only, so every lane keeps its 23 chunk offsets in
+//     registers and an A fragment read is patch row + offset.  The weights are read in their memory order ([n][tap][c] IS [n][q]).
+//
+// The (TH+2) x (TW+2) x 80 input patch of a 16 x 16 pixel tile is staged ONCE per tile by LDS-DMA (rows of 11 chunks of 16 bytes:
+// an odd pitch, conflict-free fragment reads without a swizzle) and double buffered across the tiles of a persistent block; the
+// weights stream through a 3-stage ring of 12-chunk slices (80 rows x 192 bytes, chunk-swizzled on the source side of the DMA);
+// eight k-steps (barriers) per tile, 30 MFMAs per wave and step.  Output through LDS, stored as whole 160-byte rows.
+// Chosen per layer by the engine's timing (yh_conv_desc.algo 9).
+#include "common.h"
+#include <stdlib.h>
+#ifndef YH_CONV_ABLATE
+#define YH_CONV_ABLATE 0
+#endif
+#ifndef H80_SPLIT
+#define H80_SPLIT 1       // 1: waves 0..3 issue the weight slices, waves 4..7 the patch DMAs and the global stores (see the kernel)
+#endif
+
+namespace {
+
+struct H80K {
+    const uint16_t* x; int ldx;
+    const uint16_t* w; int Ktot;
+    uint16_t* out0; int ld0;
+    uint16_t* out1; int ld1; int nsplit;
+    const uint16_t* res; int ldr;
+    const float* bias; const float* scale; const float* shift;
+    int act, accumulate, flip;
+    int N, B, H, W;
+    int TH, TW, PW, tx, ty, ntiles;
+    unsigned imgbytes, wbytes;
+    int dbg;                               // timing experiments (YH_H80_DBG): 1 weight slices / 2 patches only for a block's first tile, 4 no stores
+};
+
+template <int CIN, int TNC>
+struct H80Cfg {
+    static constexpr int CH = CIN / 8;                       // 16-byte chunks per pixel
+    static constexpr int Q = 9 * CH;                         // chunks of the flattened reduction
+    static constexpr int PCH = (CH % 2 == 0) ? CH + 1 : CH;  // patch row pitch in chunks: odd -> 16 consecutive rows hit 16 different bank groups
+    static constexpr int PITCH = PCH * 16;
+    static constexpr int PROWS = 324;                        // 18 x 18
+    static constexpr int PINST = (PROWS * PCH + 63) / 64;    // DMA instructions per patch
+    static constexpr int PATCH_BYTES = PINST * 1024;
+    static constexpr int SCH = 12;                           // chunks per weight slice (three MFMA steps)
+    static constexpr int TN = TNC * 16;
+    static constexpr int WINST = TN * SCH / 64;
+    static constexpr int WST_BYTES = WINST * 1024;
+    static constexpr int STG = 3;
+    static constexpr int NSTEP = (Q + SCH - 1) / SCH;
+    static constexpr int NKS = (Q + 3) / 4;
+    static constexpr int CONST_OFF = 2 * PATCH_BYTES + STG * WST_BYTES;
+    static constexpr int SMEM = CONST_OFF + 3 * TN * 4 + 256 * 4;
+    static constexpr int CP = TN + 8;
+    static_assert(CIN % 8 == 0 && (TN * SCH) % 64 == 0, "whole DMA instructions per weight slice");
+    static_assert(PINST % 8 == 0 && PINST / 8 <= NSTEP - 1, "one patch DMA instruction per wave and k-step");
+    static_assert(256 * CP * 2 <= PATCH_BYTES, "output tile must fit a patch buffer");
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(NSTEP >= 3, "ring prologue");
+};
+
+__device__ __forceinline__ bf16x8_t h80_lds16(const unsigned char* smem, int off) {
+    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + off));
+}
+
+template <int CIN, int TNC, int EPI>
+__global__ __launch_bounds__(512, 1) void conv_h80_kernel(const H80K p)
+{
+    using G = H80Cfg<CIN, TNC>;
+    constexpr int CH = G::CH, Q = G::Q, PCH = G::PCH, PITCH = G::PITCH, PINST = G::PINST, PATCH_BYTES = G::PATCH_BYTES;
+    constexpr int SCH = G::SCH, TN = G::TN, WINST = G::WINST, WST_BYTES = G::WST_BYTES, STG = G::STG, NSTEP = G::NSTEP, NKS = G::NKS;
+    constexpr int CP = G::CP, NT = 512, NWV = 8;
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(EPI == 0 || EPI == 2, "inference epilogues only");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sConst = reinterpret_cast<float*>(smem + G::CONST_OFF);                  // [3][TN]: bias | scale | shift
+    int* sPix = reinterpret_cast<int*>(smem + G::CONST_OFF + 3 * TN * 4);           // [256] output pixel of each tile row, -1 = none
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.y * TN;
+    const int H = p.H, W = p.W, TH = p.TH, TW = p.TW, PW = p.PW;
+    const int tiles_per_img = p.tx * p.ty;
+    const int ldx2 = p.ldx * 2;
+    const size_t img_elems = (size_t)H * W * p.ldx;
+
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+
+    // patch offset of reduction chunk q = 4 ks + kq (bytes, relative to the patch row of the tile pixel's top-left tap)
+    int koff[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int q = 4 * ks + kq;
+        const int tap = q / CH, c = q - tap * CH;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int sy = p.flip ? 2 - kh : kh, sx = p.flip ? 2 - kw : kw;
+        koff[ks] = q < Q ? (sy * PW + sx) * PITCH + c * 16 : 0;      // chunks past the end meet zero weights
+    }
+    // weight slice: DMA slot g = inst * 64 + lane -> (row, physical chunk); the logical chunk is un-swizzled on the source side
+    // Roles (SPLIT): the counter a wave waits on (vmcnt) retires in issue order, so a wave that issued a patch DMA (HBM latency)
+    // ahead of a weight slice (L2 latency) waits for both when it needs the slice, and a global store ahead of a DMA delays the
+    // wait for that DMA by the store's round trip.  Waves 0..3 therefore issue ONLY weight slices (and wait for them step by step);
+    // waves 4..7 issue the next tile's patch and this tile's stores and wait once per tile.
+    constexpr bool SPLIT = H80_SPLIT != 0;
+    constexpr int WWV = SPLIT ? 4 : NWV;                          // waves that issue weight slices
+    constexpr int NJ = (WINST + WWV - 1) / WWV;
+    const bool wrole = !SPLIT || wave < 4, prole = !SPLIT || wave >= 4;
+    const int pw = SPLIT ? wave - 4 : wave;                       // index among the patch-issuing waves
+    constexpr int PWV = SPLIT ? 4 : NWV, PPS = PINST / PWV / (NSTEP - 1);      // patch instructions per wave and step (steps 0 .. NSTEP-2)
+    static_assert(PINST % (PWV * (NSTEP - 1)) == 0, "patch DMA instructions spread evenly over the steps");
+    int nbw = 0;
+    unsigned voffW[NJ], voffWL[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (wrole && j * WWV + wave < WINST) ++nbw;
+        const int g = (j * WWV + (wrole ? wave : 0)) * 64 + lane;
+        const int row = g / SCH, pc = g - row * SCH;
+        const int c = pc ^ ((row >> 2) & 3);
+        voffW[j] = (unsigned)(((n0 + row) * p.Ktot + c * 8) * 2);
+        voffWL[j] = ((NSTEP - 1) * SCH + c < Q) ? voffW[j] : OOB;    // last slice: chunks past the end of the row read as zero
+    }
+    const int wlane = 2 * PATCH_BYTES + l15 * (SCH * 16) + ((kq ^ ((l15 >> 2) & 3)) << 4);
+
+    if (EPI == 2) {
+        for (int i = t; i < 3 * TN; i += NT) {
+            const int which = i / TN, c = i - which * TN;
+            const float* src = which == 0 ? p.bias : (which == 1 ? p.scale : p.shift);
+            sConst[i] = (src && n0 + c < p.N) ? src[n0 + c] : (which == 1 ? 1.f : 0.f);
+        }
+    }
+
+    auto issue_W = [&](int st, int slot_) {
+        unsigned char* sb = smem + 2 * PATCH_BYTES + slot_ * WST_BYTES + wave * 1024;
+        const int so = st * (SCH * 16);
+        const bool last = st == NSTEP - 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (j < nbw) lds_dma16(rsw, sb + j * WWV * 1024, last ? voffWL[j] : voffW[j], so);
+    };
+    // patch DMA slot g = inst * 64 + lane -> (patch row, chunk) -> (py, px, c): the same for every tile, kept per lane
+    constexpr int NPP = PINST / PWV;                 // patch DMA instructions per issuing wave and tile
+    int ppk[NPP];                                    // (py << 8) | px, -1: slot past the patch / the pad chunk of a row
+    unsigned prel[NPP];                              // byte offset of the slot's chunk relative to the patch's first pixel
+#pragma unroll
+    for (int h = 0; h < NPP; ++h) {
+        const int g = (h * PWV + (prole ? pw : 0)) * 64 + lane;
+        const int prow = g / PCH, c = g - prow * PCH;
+        const int py = prow / PW, px = prow - py * PW;
+        ppk[h] = (py < TH + 2 && c < CH) ? (py << 8) | px : -1;
+        prel[h] = (unsigned)((py * W + px) * ldx2 + c * 16);
+    }
+    struct TileAt { int img, y0, x0; };
+    auto tile_at = [&](int tl) {
+        TileAt a;
+        a.img = tl / tiles_per_img;
+        const int trem = tl - a.img * tiles_per_img;
+        const int tyi = trem / p.tx;
+        a.y0 = tyi * TH; a.x0 = (trem - tyi * p.tx) * TW;
+        return a;
+    };
+    auto issue_patch = [&](const TileAt& a, int h, int pbuf) {
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)a.img * img_elems), 0, p.imgbytes, 0x00020000);
+        const int y = a.y0 - 1 + (ppk[h] >> 8), x = a.x0 - 1 + (ppk[h] & 0xff);
+        const bool ok = ppk[h] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
+        const unsigned tbase = (unsigned)(((a.y0 - 1) * W + (a.x0 - 1)) * ldx2);
+        lds_dma16(rsx, smem + pbuf * PATCH_BYTES + (h * PWV + pw) * 1024, ok ? tbase + prel[h] : OOB, 0);
+    };
+
+    int tile = blockIdx.x;
+    int slot = 0, islot = 2, pb = 0;
+    int prev_group = 0;
+    if (tile < p.ntiles) {
+        if (prole) {
+            const TileAt a0 = tile_at(tile);
+#pragma unroll
+            for (int h = 0; h < NPP; ++h) issue_patch(a0, h, 0);
+        }
+        if (wrole) {
+            issue_W(0, 0);
+            issue_W(1, 1);
+        }
+        prev_group = nbw;                          // the slice of step 1 may stay in flight over the first barrier
+    }
+    __syncthreads();                               // sConst (drains the DMAs of the prologue too: once per block)
+
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        const bool has_next = tile + (int)gridDim.x < p.ntiles;
+        const TileAt at = tile_at(tile), an = tile_at(has_next ? tile + (int)gridDim.x : tile);
+        const int img = at.img, y0 = at.y0, x0 = at.x0;
+        int xrow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wave * 32 + i * 16 + l15;
+            const int ty = r / TW, tx = r - ty * TW;
+            const bool ok = ty < TH && y0 + ty < H && x0 + tx < W;
+            xrow[i] = pb * PATCH_BYTES + (ok ? (ty * PW + tx) * PITCH : 0);     // rows that are no output pixel multiply a valid row; never stored
+        }
+        if (t < 256) {
+            const int ty = t / TW, tx = t - ty * TW;
+            sPix[t] = (ty < TH && y0 + ty < H && x0 + tx < W) ? ((img * H + y0 + ty) * W + x0 + tx) : -1;
+        }
+
+        f32x4_t acc[2][TNC];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TNC; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            // every DMA group except the one issued at the previous step has landed (steps 0 and 1: everything older was
+            // waited for ahead of the previous tile's stores / in the prologue)
+            if (st >= 2 && wrole) {
+                if (prev_group == 0) YH_VMCNT(0);
+                else if (prev_group == 1) YH_VMCNT(1);
+                else if (prev_group == 2) YH_VMCNT(2);
+                else if (prev_group == 3) YH_VMCNT(3);
+                else YH_VMCNT(4);
+            }
+            __builtin_amdgcn_s_barrier();
+            prev_group = 0;
+            if (wrole) {
+                const int st2 = st + 2;                                   // the slice two steps ahead, wrapping into the next tile
+                const bool dw = !(p.dbg & 1) || tile == (int)blockIdx.x;
+                if (st2 < NSTEP) { if (dw) { issue_W(st2, islot); prev_group = nbw; } }
+                else if (has_next && dw) { issue_W(st2 - NSTEP, islot); prev_group = nbw; }
+            }
+            if (SPLIT) {                     // the whole patch of the next tile at step 0: a tile's time to land, nobody waits for it before the tile ends
+                if (prole && st == 0 && has_next && !(p.dbg & 2)) {
+#pragma unroll
+                    for (int h = 0; h < NPP; ++h) issue_patch(an, h, pb ^ 1);
+                }
+            } else if (st < NSTEP - 1 && has_next && !(p.dbg & 2)) {
+#pragma unroll
+                for (int h = 0; h < PPS; ++h) issue_patch(an, st * PPS + h, pb ^ 1);
+                prev_group += PPS;
+            }
+            const int sbase = wlane + slot * WST_BYTES;
+            constexpr int nsub_full = SCH / 4;
+            const int nsub = (st == NSTEP - 1) ? (NKS - (NSTEP - 1) * nsub_full) : nsub_full;
+#pragma unroll
+            for (int s = 0; s < nsub_full; ++s) {
+                if (s < nsub) {
+                    const int ks = st * nsub_full + s;
+                    bf16x8_t xf[2], wf[TNC];
+#if YH_CONV_ABLATE & 64                                  // timing build: MFMAs without the fragment reads
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) xf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(t, ks, i, xrow[i]));
+#pragma unroll
+                    for (int j = 0; j < TNC; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, make_uint4(t, ks, j, sbase));
+#else
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) xf[i] = h80_lds16(smem, xrow[i] + koff[ks < NKS ? ks : 0]);
+#pragma unroll
+                    for (int j = 0; j < TNC; ++j) wf[j] = h80_lds16(smem, sbase + j * (16 * SCH * 16) + s * 64);
+#endif
+#if YH_CONV_ABLATE & 4                                   // timing build: fragment reads without the MFMAs
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) asm volatile("" :: "v"(xf[i]));
+#pragma unroll
+                    for (int j = 0; j < TNC; ++j) asm volatile("" :: "v"(wf[j]));
+#else
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < TNC; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+#endif
+                }
+            }
+            slot = slot + 1 == STG ? 0 : slot + 1;
+            islot = islot + 1 == STG ? 0 : islot + 1;
+        }
+
+        // ---- epilogue: the tile through the (now idle) current patch buffer, stored as whole rows
+        uint16_t* sC = reinterpret_cast<uint16_t*>(smem + pb * PATCH_BYTES);
+#if YH_CONV_ABLATE & 2                                       // timing build: no epilogue
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < TNC; ++j) asm volatile("" :: "v"(acc[i][j]));
+        pb ^= 1;
+        continue;
+#endif
+        YH_LDS_BARRIER();                                                 // every wave is out of the k loop
+#pragma unroll
+        for (int j = 0; j < TNC; ++j) {
+            const int cc = j * 16 + 4 * kq;
+            float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f), ct = cb;
+            if (EPI == 2) {
+                cb = *reinterpret_cast<const float4*>(sConst + cc);
+                cs = *reinterpret_cast<const float4*>(sConst + TN + cc);
+                ct = *reinterpret_cast<const float4*>(sConst + 2 * TN + cc);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+                if (EPI == 2) {
+                    v0 = (v0 + cb.x) * cs.x + ct.x; v1 = (v1 + cb.y) * cs.y + ct.y;
+                    v2 = (v2 + cb.z) * cs.z + ct.z; v3 = (v3 + cb.w) * cs.w + ct.w;
+                    if (p.act == YH_ACT_SILU) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                }
+                *reinterpret_cast<uint2*>(sC + (wave * 32 + i * 16 + l15) * CP + cc) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+            }
+        }
+        YH_LDS_BARRIER();
+        constexpr int CPR = TN / 8;
+        constexpr int RT = NT;                                     // threads that move the tile to global memory
+        constexpr int NOI = 256 * CPR / RT;
+        static_assert(256 * CPR % RT == 0, "read-out mapping");
+        const int tr = t;
+        // the residual chunks are requested together, ahead of the stores (a load behind a store would wait for the store's round trip)
+        int oidx[NOI];
+        uint4 rv[EPI == 2 ? NOI : 1];
+#pragma unroll
+        for (int it = 0; it < NOI; ++it) {
+            const int id = tr + it * RT;
+            const int row = id / CPR;
+            const int n = n0 + (id - row * CPR) * 8;
+            oidx[it] = sPix[row];
+            if (EPI == 2) {
+                rv[it] = make_uint4(0, 0, 0, 0);
+                if (p.res != nullptr && oidx[it] >= 0 && n < p.nsplit) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)oidx[it] * p.ldr + n);
+            }
+        }
+        YH_VMCNT(0);                               // every DMA has landed: the stores below leave the counter clean for the next tile's steps
+#pragma unroll
+        for (int it = 0; it < NOI; ++it) {
+            if (oidx[it] < 0 || (p.dbg & 4)) continue;
+            const int id = tr + it * RT;
+            const int row = id / CPR;
+            const int cch = id - row * CPR;
+            const int n = n0 + cch * 8;
+            const size_t orow = (size_t)oidx[it];
+            uint4 v = *reinterpret_cast<const uint4*>(sC + row * CP + cch * 8);
+            if (EPI == 2) {
+                const bool first = n < p.nsplit;
+                uint16_t* dst = first ? p.out0 + orow * p.ld0 + n : p.out1 + orow * p.ld1 + (n - p.nsplit);
+                const bool addres = (p.res != nullptr) && first;
+                if (addres || p.accumulate) {
+                    float f[8];
+                    unpack8(v, f);
+                    if (addres) {
+                        float g2[8]; unpack8(rv[it], g2);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += g2[e];
+                    }
+                    if (p.accumulate) {
+                        const uint4 ov = *reinterpret_cast<const uint4*>(dst);
+                        float g2[8]; unpack8(ov, g2);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += g2[e];
+                    }
+                    v = pack8(f);
+                }
+                *reinterpret_cast<uint4*>(dst) = v;
+            } else {
+                *reinterpret_cast<uint4*>(p.out0 + orow * p.ld0 + n) = v;
+            }
+        }
+        YH_LDS_BARRIER();                                                 // output buffer and pixel table free for the next tile
+        pb ^= 1;
+    }
+}
+
+// TH x TW output pixels per tile: TH * TW <= 256 and (TH + 2) * (TW + 2) <= 324 patch rows; the fewest wasted MFMA rows, whole
+// 16-pixel groups per tile row preferred (a group then reads 16 consecutive patch rows)
+bool h80_geom(int H, int W, int* TH, int* TW, int* tx, int* ty)
+{
+    double best = -1.0;
+    for (int tw = 4; tw <= 64; ++tw)
+        for (int th = 1; th * tw <= 256; ++th) {
+            if ((th + 2) * (tw + 2) > 324) continue;
+            const int nx = (W + tw - 1) / tw, ny = (H + th - 1) / th;
+            double eff = (double)H * W / ((double)nx * ny * 256);
+            if (tw % 16 == 0) eff += 2e-3;
+            eff += 1e-5 * tw;
+            if (eff > best) { best = eff; *TH = th; *TW = tw; *tx = nx; *ty = ny; }
+        }
+    return best > 0.0;
+}
+
+struct H80Plan { int gx, gy, epi; H80K k; };
+
+bool h80_plan(const yh_conv_desc* d, H80Plan* pl)
+{
+    if (d->nseg != 1 || d->seg[0].ups) return false;
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hi || d->Wo != d->Wi) return false;
+    if (d->stats || d->bnr_part || d->acc_rows) return false;                       // inference epilogues only
+    if (d->seg[0].C != 80 || d->N % 80 || d->N <= 0) return false;
+    const unsigned long ib = (unsigned long)d->Hi * d->Wi * d->seg[0].ld * 2;       // one image: what a patch descriptor addresses
+    const unsigned long wb = (unsigned long)d->Npad * 9 * 80 * 2;
+    if (ib >= (1ul << 31) || wb >= (1ul << 31) || (unsigned long)d->B * d->Ho * d->Wo >= (1ul << 31)) return false;
+    H80K& k = pl->k;
+    if (!h80_geom(d->Ho, d->Wo, &k.TH, &k.TW, &k.tx, &k.ty)) return false;
+    k.PW = k.TW + 2;
+    k.x = d->seg[0].ptr; k.ldx = d->seg[0].ld;
+    k.w = d->w; k.Ktot = 9 * 80;
+    k.out0 = d->out0; k.ld0 = d->ld0; k.out1 = d->out1; k.ld1 = d->ld1; k.nsplit = d->nsplit;
+    k.res = d->res; k.ldr = d->ldr;
+    k.bias = d->bias; k.scale = d->scale; k.shift = d->shift;
+    k.act = d->act; k.accumulate = d->accumulate; k.flip = d->mode == YH_CONV_DGRAD ? 1 : 0;
+    k.N = d->N; k.B = d->B; k.H = d->Ho; k.W = d->Wo;
+    k.ntiles = d->B * k.tx * k.ty;
+    k.imgbytes = (unsigned)ib; k.wbytes = (unsigned)wb;
+    static const int dbg = getenv("YH_H80_DBG") ? atoi(getenv("YH_H80_DBG")) : 0;
+    k.dbg = dbg;
+    const bool generic = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->accumulate || d->nsplit < d->N;
+    pl->epi = generic ? 2 : 0;
+    pl->gy = d->N / 80;
+    int cap = 256 / pl->gy;
+    if (cap < 1) cap = 1;
+    if (d->grid_cap > 0) cap = d->grid_cap;
+    pl->gx = k.ntiles < cap ? k.ntiles : cap;
+    return true;
+}
+
+}  // namespace
+
+int yh_h80_rows(const yh_conv_desc* d)
+{
+    H80Plan pl;
+    return h80_plan(d, &pl) ? pl.gx : 0;
+}
+
+int yh_h80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len)
+{
+    H80Plan pl;
+    YH_CHECK_ARG(h80_plan(d, &pl), "yh_conv_igemm: algo 9 (80-channel halo kernel) is not eligible for this descriptor");
+    if (name_out) { snprintf(name_out, name_len, "conv_h80_kernel<80, 5, %d>", pl.epi); return YH_OK; }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(pl.gx, pl.gy), blk(512);
+    constexpr int sm = H80Cfg<80, 5>::SMEM;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_h80_kernel<80, 5, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)conv_h80_kernel<80, 5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        attr_set = true;
+    }
+    if (pl.epi == 2) conv_h80_kernel<80, 5, 2><<<grid, blk, sm, st>>>(pl.k);
+    else             conv_h80_kernel<80, 5, 0><<<grid, blk, sm, st>>>(pl.k);
+    YH_CHECK_LAUNCH("yh_conv_igemm(h80)");
+    return YH_OK;
+}

@@ -150,8 +150,8 @@ _WGRAD_TK64 = {
 # version prefixes of the tuning-table keys: bumped when the candidates or the meaning of a tuned value change, so that stale
 # entries of a shipped / cached table are not applied.  Stride-2 data gradients carry their own version (conv_dg2_kernel, algo 7,
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
-KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "wgrad9", "wgrad8"
-TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
+KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_H80, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad9", "wgrad8"
+TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_H80, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
 # YH_SKIP_ALGOS=<n>[,<n>]: leave these kernel families (yh_conv_desc.algo) out of the per-layer timing — A/B runs of a new family on
 # one box (use a YH_TUNE_CACHE of its own and YH_TUNE_DEFAULTS=0 for the layers concerned)
@@ -545,14 +545,15 @@ class Program:
         self._build_forward()
 
     # -- helpers -------------------------------------------------------------------------
-    def _conv_desc(self, op, train):
+    def _conv_desc(self, op, train, segs=None):
         pk = self.pack
         wp, npad, K = pk.wptr((op.name, 'fwd'))
         assert K == op.Ktot
         d = ConvDesc()
-        for i, sg in enumerate(op.segs):
+        segs = op.segs if segs is None else segs
+        for i, sg in enumerate(segs):
             d.seg[i] = hipk.make_seg(sg.sl())
-        d.nseg, d.mode = len(op.segs), YH_CONV_FWD
+        d.nseg, d.mode = len(segs), YH_CONV_FWD
         d.B, d.Ho, d.Wo, d.Hi, d.Wi = self.B, op.Ho, op.Wo, op.Hi, op.Wi
         d.KH = d.KW = op.k
         d.stride, d.pad = op.stride, op.pad
@@ -567,7 +568,8 @@ class Program:
         if os.environ.get("YH_CONV_TUNE", "1") == "0":
             return
         small3 = d.KH == 3 and d.stride == 1 and d.nseg == 1 and d.seg[0].C <= 128 and d.N <= 128 and kind != 'eval'
-        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else KEY_CONV)}:{kind}:" + ",".join(str(int(v)) for v in (
+        wide80 = d.KH == 3 and d.stride == 1 and d.nseg == 1 and d.seg[0].C == 80 and d.N % 80 == 0        # conv_h80_kernel's shapes
+        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else (KEY_CONV_H80 if wide80 else KEY_CONV))}:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
             int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), d.acc_rows))
@@ -593,13 +595,13 @@ class Program:
                 cands.append((1, tk, cap))
         d.tile_k = d.grid_cap = 0
         if os.environ.get("YH_CONV_V3", "1") != "0":
-            for algo in (2, 3, 4, 5, 6, 7, 8):
+            for algo in (2, 3, 4, 5, 6, 7, 8, 9):
                 if str(algo) in SKIP_ALGOS:
                     continue
                 d.algo = algo
                 kn = self._kernel_name(d)
                 if ("conv_v3" in kn and algo < 5) or ("conv_halo_kernel" in kn and algo == 5) or ("conv_halo160" in kn and algo == 6) or \
-                        ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8):
+                        ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8) or ("conv_h80" in kn and algo == 9):
                     cands.append((algo, 0, 0))
                     if algo < 5 and kn.endswith(", true>") and all(d.seg[i].C % 32 == 0 for i in range(d.nseg)):
                         cands.append((algo, 32, 0))    # ragged last channel block: 32-channel steps instead of 64 + tail
@@ -636,6 +638,48 @@ class Program:
         d.bnr_part = saved_part
         cache[key] = [int(best[0]), int(best[1]), int(best[2])]
 
+    def _eval_concat_plan(self):
+        """Inference only: a conv that reads concat(t, upper half of a buffer `cat`) — C3's cba3 (utils/layer_tools.py:152-169) — where
+        t is produced by ONE conv (the last bottleneck's 3x3) and cat's lower half (cba1's output) has no reader behind that conv:
+        the producer writes over the lower half instead, and the reader becomes a conv over ONE 2*mid-channel segment (whole
+        cache lines per pixel, every kernel family eligible; with 80 + 80 channels the two-segment form fell back to the generic
+        kernel).  A producer that reads the lower half as its residual does so element by element before it stores the same element.
+        Training keeps both buffers: cba1's activation is needed by the backward.  YH_EVAL_INPLACE_CAT=0: off.
+        Returns ({producer op: Ref}, {reader op: [Ref]})."""
+        outs, segs = {}, {}
+        if os.environ.get("YH_EVAL_INPLACE_CAT", "1") == "0":
+            return outs, segs
+        ops = self.ops
+        for ci, c3 in enumerate(ops):
+            if not isinstance(c3, ConvOp) or c3.kind != 'cba' or len(c3.segs) != 2:
+                continue
+            s0, s1 = c3.segs
+            cat, tb = s1.buf, s0.buf
+            if s0.ups or s1.ups or tb is cat or s0.coff or tb.C != s0.C or s1.coff != s0.C or cat.C != s0.C + s1.C:
+                continue
+            prods = [(i, o) for i, o in enumerate(ops) if isinstance(o, ConvOp) and o.kind == 'cba' and any(r.buf is tb for r in o.outs)]
+            if len(prods) != 1 or len(prods[0][1].outs) != 1 or prods[0][0] >= ci:
+                continue
+            pi, prod = prods[0]
+            lower = lambda r: r is not None and r.buf is cat and r.coff < s0.C      # noqa: E731
+            ok = True
+            for i, o in enumerate(ops):
+                if isinstance(o, PoolOp):
+                    ok &= not (o.src.buf is tb or o.dst.buf is tb or lower(o.src) or lower(o.dst))
+                    continue
+                if o is not c3 and (any(sg.buf is tb for sg in o.segs) or (o.res is not None and o.res.buf is tb)):
+                    ok = False                                   # t has another reader
+                if any(lower(sg) for sg in o.segs) and i >= pi:
+                    ok = False                                   # the lower half is a conv input at or behind the producer
+                if lower(o.res) and (i > pi or (i == pi and not (o.res.coff == 0 and o.res.C == s0.C))):
+                    ok = False
+                if o.kind == 'cba' and any(lower(r) for r in o.outs) and i >= pi:
+                    ok = False
+            if ok:
+                outs[prod] = Ref(cat, 0, s0.C)
+                segs[c3] = [Ref(cat, 0, cat.C)]
+        return outs, segs
+
     def _build_forward(self):
         """inference program (folded BatchNorm + SiLU in the conv epilogue).  The training program — raw conv outputs,
         statistics, BatchNorm work buffers, pool arg-max — is built by _build_train() at the first training forward, so an
@@ -645,6 +689,7 @@ class Program:
         self.op_state = {}
         fold_items = []                 # every BatchNorm of the net is folded to (scale, shift) by ONE launch ahead of the convs
         skip = set()
+        cat_outs, cat_segs = self._eval_concat_plan()
         for oi, op in enumerate(self.ops):
             if oi in skip:
                 continue
@@ -674,7 +719,8 @@ class Program:
                 self.cmd_eval.append((L.yh_conv_igemm, (d,), op.name, st['fam']))
                 continue
             # folded BN + SiLU (+ residual) in the conv epilogue
-            de = self._conv_desc(op, False)
+            de = self._conv_desc(op, False, cat_segs.get(op))
+            op_outs = [cat_outs[op]] if op in cat_outs else op.outs
             st['fold'] = torch.zeros(2, op.N, dtype=torch.float32, device=self.dev)
             c0 = 0
             for (conv, bn), n in zip(op.parts, op.part_N):
@@ -686,12 +732,12 @@ class Program:
                 c0 += n
             de.scale, de.shift = st['fold'].data_ptr(), st['fold'].data_ptr() + 4 * op.N
             de.act = YH_ACT_SILU
-            o0 = op.outs[0].sl()
-            de.out0, de.ld0, de.nsplit = o0.ptr(), o0.ld, op.part_N[0] if len(op.outs) > 1 else op.N
-            if len(op.outs) > 1:
-                o1 = op.outs[1].sl()
+            o0 = op_outs[0].sl()
+            de.out0, de.ld0, de.nsplit = o0.ptr(), o0.ld, op.part_N[0] if len(op_outs) > 1 else op.N
+            if len(op_outs) > 1:
+                o1 = op_outs[1].sl()
                 de.out1, de.ld1 = o1.ptr(), o1.ld
-                assert len(op.outs) == 2
+                assert len(op_outs) == 2
             if op.res is not None:
                 r = op.res.sl()
                 de.res, de.ldr = r.ptr(), r.ld
