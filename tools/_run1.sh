@@ -1,11 +1,6 @@
 set -e
-run() { YH_LIBRARY=$1 YH_H80_DBG=$2 BA_BATCH=128 BA_ONLY=s1_b_3x3 python3 tools/bench_algos.py v5x1280 eval 10 2>&1 | tail -1 | sed 's/.*h80/h80/'; }
-L=$PWD/yoloseries_amd
-timeout -k 10 600 python3 -m pytest tests/test_gpu_conv.py -x -q -m gpu -k "halo80" 2>&1 | tail -3
-for i in 1 2; do
-echo "split dbg0"; run $L/libyolohip.so 0
-echo "nosplit dbg0"; run $L/libyolohip_h80ns.so 0
-done
-echo "split dbg2"; run $L/libyolohip.so 2
-echo "split dbg4"; run $L/libyolohip.so 4
-echo "split dbg7"; run $L/libyolohip.so 7
+export YH_TUNE_CACHE=$PWD/gpurun_out/tc_f.json
+timeout -k 10 900 python3 -m pytest tests/test_gpu_model.py -x -q -m gpu -k "golden or evaluator" 2>&1 | tail -3
+YH_BENCH_LAYERS=200 python3 bench.py --workload infer --model xlarge --img 1280 --batch 128 --no-cpu-baseline --steps 6 --warmup 3 > gpurun_out/b_v5x.json 2> gpurun_out/layers_v5x.txt || { tail -20 gpurun_out/layers_v5x.txt; exit 1; }
+cut -c1-200 gpurun_out/b_v5x.json
+python3 bench.py --workload infer --model small --batch 64 --no-cpu-baseline --no-roofline --steps 6 2>&1 | tail -1 | cut -c1-200

@@ -56,8 +56,9 @@ for name, H, Cin, Cout, k, s in shapes:
         wp = hipk.pack_weight_fwd(w)
         if mode == "eval":
             sc, sh = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+            res = torch.randn(B, Ho, Ho, Cout, device=dev).to(torch.bfloat16) if os.environ.get("BA_RES") else None      # BA_RES=1: with a residual
             d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, Ho, Ho, H, H, k, s, p, wp, Cout, hipk.full(out), scale=sc, shift=sh,
-                               act=hipk.YH_ACT_SILU)
+                               act=hipk.YH_ACT_SILU, res=hipk.full(res) if res is not None else None)
         else:
             d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, Ho, Ho, H, H, k, s, p, wp, Cout, hipk.full(out))
             stats = torch.zeros(4096, 2, wp.shape[0], device=dev)

@@ -218,6 +218,13 @@ __global__ __launch_bounds__(512, 1) void conv_h80_kernel(const H80K p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
+        constexpr int CPR = TN / 8;
+        constexpr int RT = NT;                                     // threads that move the tile to global memory
+        constexpr int NOI = 256 * CPR / RT;
+        static_assert(256 * CPR % RT == 0, "read-out mapping");
+        const int tr = t;
+        int oidx[NOI];
+        uint4 rv[EPI == 2 ? NOI : 1];
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
             // every DMA group except the one issued at the previous step has landed (steps 0 and 1: everything older was
@@ -246,6 +253,22 @@ __global__ __launch_bounds__(512, 1) void conv_h80_kernel(const H80K p)
 #pragma unroll
                 for (int h = 0; h < PPS; ++h) issue_patch(an, st * PPS + h, pb ^ 1);
                 prev_group += PPS;
+            }
+            if (st == NSTEP - 1) {
+                // the residual chunks of this thread's output rows are requested behind the last DMA issue of the tile (no counted
+                // wait follows them) and land while the last step and the activation math run; a load issued after a store
+                // would wait for the store's round trip
+#pragma unroll
+                for (int it = 0; it < NOI; ++it) {
+                    const int id = tr + it * RT;
+                    const int row = id / CPR;
+                    const int n = n0 + (id - row * CPR) * 8;
+                    oidx[it] = sPix[row];
+                    if (EPI == 2) {
+                        rv[it] = make_uint4(0, 0, 0, 0);
+                        if (p.res != nullptr && oidx[it] >= 0 && n < p.nsplit) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)oidx[it] * p.ldr + n);
+                    }
+                }
             }
             const int sbase = wlane + slot * WST_BYTES;
             constexpr int nsub_full = SCH / 4;
@@ -313,25 +336,6 @@ __global__ __launch_bounds__(512, 1) void conv_h80_kernel(const H80K p)
             }
         }
         YH_LDS_BARRIER();
-        constexpr int CPR = TN / 8;
-        constexpr int RT = NT;                                     // threads that move the tile to global memory
-        constexpr int NOI = 256 * CPR / RT;
-        static_assert(256 * CPR % RT == 0, "read-out mapping");
-        const int tr = t;
-        // the residual chunks are requested together, ahead of the stores (a load behind a store would wait for the store's round trip)
-        int oidx[NOI];
-        uint4 rv[EPI == 2 ? NOI : 1];
-#pragma unroll
-        for (int it = 0; it < NOI; ++it) {
-            const int id = tr + it * RT;
-            const int row = id / CPR;
-            const int n = n0 + (id - row * CPR) * 8;
-            oidx[it] = sPix[row];
-            if (EPI == 2) {
-                rv[it] = make_uint4(0, 0, 0, 0);
-                if (p.res != nullptr && oidx[it] >= 0 && n < p.nsplit) rv[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)oidx[it] * p.ldr + n);
-            }
-        }
         YH_VMCNT(0);                               // every DMA has landed: the stores below leave the counter clean for the next tile's steps
 #pragma unroll
         for (int it = 0; it < NOI; ++it) {

@@ -1921,6 +1921,25 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
         if (has_next) { if (wave < 4) { YH_VMCNT(3); } else { YH_VMCNT(2); } } else { YH_VMCNT(0); }
         uint16_t* sC = reinterpret_cast<uint16_t*>(smem + (pb ^ 1) * PATCH_BYTES);
         constexpr int CPR = BN / 8;                   // 20 chunks of 8 channels per row
+        // bias / folded BatchNorm / SiLU of the whole tile first, by all eight waves at once: inside the phases below only the two
+        // waves of one pixel row-group are active, and the activation (80 values per lane, two quarter-rate transcendentals each)
+        // would run on two of the four SIMDs at a time
+        if (EPI == 2) {
+#pragma unroll
+            for (int j = 0; j < TNC; ++j) {
+                const int cc = wn * 80 + j * 16 + 4 * kq;
+                const float4 cb = *reinterpret_cast<const float4*>(sConst + cc);
+                const float4 cs = *reinterpret_cast<const float4*>(sConst + BN + cc);
+                const float4 ct = *reinterpret_cast<const float4*>(sConst + 2 * BN + cc);
+#pragma unroll
+                for (int i = 0; i < TMR; ++i) {
+                    float v0 = (acc[i][j][0] + cb.x) * cs.x + ct.x, v1 = (acc[i][j][1] + cb.y) * cs.y + ct.y;
+                    float v2 = (acc[i][j][2] + cb.z) * cs.z + ct.z, v3 = (acc[i][j][3] + cb.w) * cs.w + ct.w;
+                    if (d.act == YH_ACT_SILU) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                    acc[i][j][0] = v0; acc[i][j][1] = v1; acc[i][j][2] = v2; acc[i][j][3] = v3;
+                }
+            }
+        }
 #pragma unroll 1
         for (int ph = 0; ph < 4; ++ph) {
             YH_LDS_BARRIER();                         // previous phase's readers done (ph 0: every wave is out of the k loop)
@@ -1928,22 +1947,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
 #pragma unroll
                 for (int j = 0; j < TNC; ++j) {
                     const int cc = wn * 80 + j * 16 + 4 * kq;
-                    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), cs = make_float4(1.f, 1.f, 1.f, 1.f), ct = cb;
-                    if (EPI == 2) {
-                        cb = *reinterpret_cast<const float4*>(sConst + cc);
-                        cs = *reinterpret_cast<const float4*>(sConst + BN + cc);
-                        ct = *reinterpret_cast<const float4*>(sConst + 2 * BN + cc);
-                    }
 #pragma unroll
-                    for (int i = 0; i < TMR; ++i) {
-                        float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-                        if (EPI == 2) {
-                            v0 = (v0 + cb.x) * cs.x + ct.x; v1 = (v1 + cb.y) * cs.y + ct.y;
-                            v2 = (v2 + cb.z) * cs.z + ct.z; v3 = (v3 + cb.w) * cs.w + ct.w;
-                            if (d.act == YH_ACT_SILU) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
-                        }
-                        *reinterpret_cast<uint2*>(sC + (i * 16 + l15) * CP + cc) = make_uint2(pack2(v0, v1), pack2(v2, v3));
-                    }
+                    for (int i = 0; i < TMR; ++i)
+                        *reinterpret_cast<uint2*>(sC + (i * 16 + l15) * CP + cc) =
+                            make_uint2(pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3]));
                 }
             }
             YH_LDS_BARRIER();

@@ -150,8 +150,8 @@ _WGRAD_TK64 = {
 # version prefixes of the tuning-table keys: bumped when the candidates or the meaning of a tuned value change, so that stale
 # entries of a shipped / cached table are not applied.  Stride-2 data gradients carry their own version (conv_dg2_kernel, algo 7,
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
-KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_H80, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad9", "wgrad8"
-TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_H80, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
+KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad9", "wgrad8"
+TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
 # YH_SKIP_ALGOS=<n>[,<n>]: leave these kernel families (yh_conv_desc.algo) out of the per-layer timing — A/B runs of a new family on
 # one box (use a YH_TUNE_CACHE of its own and YH_TUNE_DEFAULTS=0 for the layers concerned)
@@ -568,8 +568,7 @@ class Program:
         if os.environ.get("YH_CONV_TUNE", "1") == "0":
             return
         small3 = d.KH == 3 and d.stride == 1 and d.nseg == 1 and d.seg[0].C <= 128 and d.N <= 128 and kind != 'eval'
-        wide80 = d.KH == 3 and d.stride == 1 and d.nseg == 1 and d.seg[0].C == 80 and d.N % 80 == 0        # conv_h80_kernel's shapes
-        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else (KEY_CONV_H80 if wide80 else KEY_CONV))}:{kind}:" + ",".join(str(int(v)) for v in (
+        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else (KEY_CONV_EVAL if kind == 'eval' else KEY_CONV))}:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
             int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), d.acc_rows))
