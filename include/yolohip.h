@@ -107,7 +107,9 @@ typedef struct yh_conv_desc {
                            * of 32 in, <= 128 out, forward with statistics or data gradient with the fused reduction);
                            * 9 the 80-channel halo kernel (conv_h80_kernel: 3x3 / s1 / p1 with exactly 80 input channels and N % 80 == 0,
                            * no statistics: 256-pixel x 80-channel tiles on 16x16x32 MFMAs, reduction over the flattened (tap, channel)
-                           * index — no padding of N or K) */
+                           * index — no padding of N or K);
+                           * 10 the pointwise kernel (conv_pw_kernel: 1x1 / s1 / p0 forward with exactly 80, 160 or 320 input channels and
+                           * N % 80 == 0, no statistics: pixel tiles and the weight tile whole in LDS, no k loop over memory) */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
      * contributions already in out0 are added first and the sums are taken over the rounded total):

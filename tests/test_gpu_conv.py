@@ -538,6 +538,69 @@ def test_conv_halo80_kernel(dev, B, H, W, Cout):
         _close(gx, gref.permute(0, 2, 3, 1), 1e-2, 4e-2)
 
 
+PW_CASES = [
+    # B, H, W, Cin, Cout: ConvBnAct(Cin, Cout, 1, 1) on an H x W map (YOLOv5x: C3's cba1 | cba2, cba3 and the bottlenecks' conv_bn_act_1)
+    (2, 32, 32, 80, 80),        # whole 128-pixel tiles
+    (1, 17, 23, 80, 160),       # ragged last tile, two output-channel groups
+    (2, 24, 24, 160, 160),      # 64-pixel tiles, five 32-wide reduction steps
+    (1, 9, 7, 160, 80),         # fewer pixels than a tile
+    (3, 16, 16, 160, 320),
+    (2, 20, 20, 320, 320),      # ten reduction steps, one block per CU
+    (1, 11, 13, 320, 160),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", PW_CASES)
+def test_conv_pointwise_kernel(dev, B, H, W, Cin, Cout):
+    """conv_pw_kernel (algo 10): 1x1 layers with 80 / 160 input channels, pixel tile and weight tile whole in LDS — plain store,
+    folded BatchNorm + SiLU into channel slices (split destination, the input itself a slice of a wider buffer), residual,
+    accumulate — against torch"""
+    from yoloseries_amd import hipk
+    x = _nhwc(B, H, W, Cin, dev, 101)
+    g = torch.Generator().manual_seed(102)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    ref = F.conv2d(_nchw(x), w).permute(0, 2, 3, 1)
+    xbuf = torch.full((B, H, W, 2 * Cin), float("nan"), dtype=torch.bfloat16, device=dev)       # lower half of a concat buffer
+    xbuf[..., :Cin] = x
+    xin = hipk.Slice(xbuf, 0, Cin)
+    out = torch.full((B, H, W, Cout), 7.0, dtype=torch.bfloat16, device=dev)
+    d = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, Cout, hipk.full(out))
+    d.algo = 10
+    assert "conv_pw_kernel<%d, 5, %d, 0>" % (Cin, 2 if Cin == 80 else 1) in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out, ref, 8e-3, 2e-2)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=g).to(dev)
+    a = F.silu(ref * scale + shift)
+    res = _nhwc(B, H, W, 80, dev, 103)
+    if Cout > 80:               # cba1 | cba2: the two halves into two slices; a residual on the first
+        cat = torch.full((B, H, W, Cout + 16), 5.0, dtype=torch.bfloat16, device=dev)
+        d2 = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, Cout, hipk.Slice(cat, 0, 80), nsplit=80,
+                            out1=hipk.Slice(cat, 88, Cout - 80), scale=scale, shift=shift, act=hipk.YH_ACT_SILU, res=hipk.full(res))
+    else:
+        cat = torch.full((B, H, W, 96), 5.0, dtype=torch.bfloat16, device=dev)
+        d2 = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, Cout, hipk.Slice(cat, 0, 80),
+                            scale=scale, shift=shift, act=hipk.YH_ACT_SILU, res=hipk.full(res))
+    d2.algo = 10
+    assert "conv_pw_kernel" in _kname(d2) and ", 2>" in _kname(d2), _kname(d2)
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    _close(cat[..., :80], a[..., :80].to(torch.bfloat16).float() + res.float(), 1e-2, 3e-2)
+    assert (cat[..., 80:88] == 5.0).all()
+    if Cout > 80:
+        _close(cat[..., 88:88 + Cout - 80], a[..., 80:], 8e-3, 2e-2)
+        assert (cat[..., 88 + Cout - 80:] == 5.0).all()
+    acc0 = _nhwc(B, H, W, Cout, dev, 104)
+    acc = acc0.clone()
+    d3 = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, Cout, hipk.full(acc), accumulate=1)
+    d3.algo = 10
+    hipk.conv_launch(d3)
+    torch.cuda.synchronize()
+    _close(acc, ref.to(torch.bfloat16).float() + acc0.float(), 1e-2, 3e-2)
+
+
 def _dgrad_check(dev, B, H, W, Cin, Cout, k, s, p, algo, tile_k=0, tile_n=0):
     from yoloseries_amd import hipk
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1

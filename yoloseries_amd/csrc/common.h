@@ -93,6 +93,10 @@ int yh_p3_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
 int yh_h80_rows(const yh_conv_desc* d);                 // grid rows; 0 = not eligible
 int yh_h80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
 
+// conv_pw.hip: the pointwise (1x1) kernel for the 80- / 160-channel layers of YOLOv5x (inference epilogues) behind yh_conv_igemm (algo 10)
+int yh_pw_rows(const yh_conv_desc* d);                  // grid rows; 0 = not eligible
+int yh_pw_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
+
 // conv_wgp.hip: the patch form of the weight gradient behind yh_conv_wgrad (tile_k 40)
 int yh_wgp_ok(const yh_wgrad_desc* d);
 int yh_wgp_run(const yh_wgrad_desc* d, yh_stream stream);
