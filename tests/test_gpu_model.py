@@ -399,6 +399,36 @@ def test_v5x_1280_eval_through_evaluator(dev):
     np.testing.assert_array_equal(out[0].numpy(), ref[0])
 
 
+def test_eval_inplace_concat_plan(dev, monkeypatch):
+    """inference: the last bottleneck of every C3 block writes over cba1's half of the concat buffer and cba3 reads ONE
+    segment (engine._eval_concat_plan) — same predictions as the two-buffer form (YH_EVAL_INPLACE_CAT=0), and a training
+    forward is unaffected (the training program keeps both buffers)"""
+    from yoloseries_amd import engine, models
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(7)).to(dev)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("YH_EVAL_INPLACE_CAT", flag)
+        torch.manual_seed(0)
+        m = models.YOLOV5Small(3, 80).to(dev)
+        m.train()
+        tr0 = [o.detach().float().cpu() for o in m(x)]
+        m.eval()
+        with torch.no_grad():
+            ev = [o.float().cpu() for o in m(x)]
+        prog = m._yh_program(2, 128, 128)
+        po, ps = prog._eval_concat_plan()
+        nc3 = sum(1 for o in prog.ops if isinstance(o, engine.ConvOp) and o.name.endswith("cba3"))
+        assert (len(ps) == nc3 and len(po) == nc3 and nc3 == 8) if flag == "1" else (not po and not ps)
+        cba3 = [c for _, args, name, _ in prog.cmd_eval if name.endswith("cba3") for c in args]
+        assert len(cba3) == 8 and all(d.nseg == (1 if flag == "1" else 2) for d in cba3)
+        outs[flag] = (tr0, ev)
+    for a, b in zip(outs["1"][0], outs["0"][0]):
+        assert torch.equal(a, b)                            # training forward: untouched
+    for a, b in zip(outs["1"][1], outs["0"][1]):
+        d = (a - b).abs()
+        assert d.max() <= 3e-2 * max(1.0, b.abs().max().item()) and d.mean() <= 2e-3 * max(1.0, b.abs().mean().item())
+
+
 def test_program_executor_matches_per_launch_calls(dev):
     """the compiled command arrays replayed by yh_exec (one call per pass) against one ctypes call per launch: identical forward
     outputs (same kernels, same order), gradients equal up to the atomics' summation order"""
