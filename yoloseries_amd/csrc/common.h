@@ -63,6 +63,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // ---- LDS-DMA (global -> LDS without VGPR staging) ---------------------------
 #define YH_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+// counted wait with a wave-uniform run-time count (the instruction takes an immediate)
+#define YH_VMCNT_SW(n) do { switch (n) { case 0: YH_VMCNT(0); break; case 1: YH_VMCNT(1); break; case 2: YH_VMCNT(2); break; case 3: YH_VMCNT(3); break; \
+    case 4: YH_VMCNT(4); break; case 5: YH_VMCNT(5); break; case 6: YH_VMCNT(6); break; case 7: YH_VMCNT(7); break; case 8: YH_VMCNT(8); break; \
+    case 9: YH_VMCNT(9); break; default: YH_VMCNT(10); break; } } while (0)
 // workgroup barrier that orders LDS accesses only: unlike __syncthreads() it does not drain LDS-DMA transfers in flight
 #define YH_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 

@@ -1444,12 +1444,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
 #if YH_CONV_ABLATE & 1
                 YH_VMCNT(0);
 #else
-                if (kt > 0) {
-                    if (prev_group == 0) YH_VMCNT(0);
-                    else if (prev_group == 1) YH_VMCNT(1);
-                    else if (prev_group == 2) YH_VMCNT(2);
-                    else YH_VMCNT(3);
-                }
+                if (kt > 0) YH_VMCNT_SW(prev_group);
 #endif
 #if !(YH_CONV_ABLATE & 256)
                 __builtin_amdgcn_s_barrier();
@@ -1470,7 +1465,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
                         for (int j = 0; j < NB; ++j) lds_dma16(rsw, sb + j * (NWV * RPI * ROWB), voffB[j], sw);
                         prev_group = NB;
                     }
-                    if (tap < NPW) {
+                    if (tap < NPW && !(YH_CONV_ABLATE & 512)) {
                         if (!last_blk) prev_group += issue_patch_part(voffP, tap, cblk + 1, pb ^ 1);
                         else if (has_next) prev_group += issue_patch_part(voffN, tap, 0, pb ^ 1);
                     }
@@ -1860,13 +1855,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
             for (int tap = 0; tap < 9; ++tap) {
                 const int kt = cblk * 9 + tap;
                 // all DMA groups except the one issued at the previous step must have landed (step 0: waited before the tile)
-                if (kt > 0) {
-                    if (prev_group == 0) YH_VMCNT(0);
-                    else if (prev_group == 1) YH_VMCNT(1);
-                    else if (prev_group == 2) YH_VMCNT(2);
-                    else if (prev_group == 3) YH_VMCNT(3);
-                    else YH_VMCNT(4);
-                }
+                if (kt > 0) YH_VMCNT_SW(prev_group);
                 __builtin_amdgcn_s_barrier();
                 prev_group = 0;
                 {
@@ -1877,7 +1866,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
                         issue_W(tapB, cblkB < ncb ? cblkB : 0, islot);
                         prev_group = nbw;
                     }
-                    if (tap < NPW) {
+                    if (tap < NPW && !(YH_CONV_ABLATE & 512)) {
                         if (!last_blk) prev_group += issue_patch_part(voffP, tap, cblk + 1, pb ^ 1);
                         else if (has_next) prev_group += issue_patch_part(voffN, tap, 0, pb ^ 1);
                     }
