@@ -20,9 +20,6 @@
 #ifndef YH_CONV_ABLATE
 #define YH_CONV_ABLATE 0
 #endif
-#ifndef H80_SPLIT
-#define H80_SPLIT 1       // 1: waves 0..3 issue the weight slices, waves 4..7 the patch DMAs and the global stores (see the kernel)
-#endif
 
 namespace {
 
@@ -76,7 +73,7 @@ __global__ __launch_bounds__(512, 1) void conv_h80_kernel(const H80K p)
     using G = H80Cfg<CIN, TNC>;
     constexpr int CH = G::CH, Q = G::Q, PCH = G::PCH, PITCH = G::PITCH, PINST = G::PINST, PATCH_BYTES = G::PATCH_BYTES;
     constexpr int SCH = G::SCH, TN = G::TN, WINST = G::WINST, WST_BYTES = G::WST_BYTES, STG = G::STG, NSTEP = G::NSTEP, NKS = G::NKS;
-    constexpr int CP = G::CP, NT = 512, NWV = 8;
+    constexpr int CP = G::CP, NT = 512;
     constexpr unsigned OOB = 0x80000000u;
     static_assert(EPI == 0 || EPI == 2, "inference epilogues only");
 
@@ -106,18 +103,17 @@ __global__ __launch_bounds__(512, 1) void conv_h80_kernel(const H80K p)
         const int sy = p.flip ? 2 - kh : kh, sx = p.flip ? 2 - kw : kw;
         koff[ks] = q < Q ? (sy * PW + sx) * PITCH + c * 16 : 0;      // chunks past the end meet zero weights
     }
+    // Roles: the counter a wave waits on (vmcnt) retires in issue order, so a wave that issued a patch DMA (HBM latency) ahead of a
+    // weight slice (L2 latency) waits for both when it needs the slice.  Waves 0..3 therefore issue the weight slices (and wait for
+    // them step by step), waves 4..7 the next tile's whole patch at step 0 (and wait for it once, ahead of the tile's stores).
+    // Measured against one patch part per wave and step from all eight waves: 745 vs 746 TFLOP/s once the slot -> pixel arithmetic
+    // of the patch was taken out of the tile loop (it was 13 % of the tile time) — kept for the simpler counted waits.
     // weight slice: DMA slot g = inst * 64 + lane -> (row, physical chunk); the logical chunk is un-swizzled on the source side
-    // Roles (SPLIT): the counter a wave waits on (vmcnt) retires in issue order, so a wave that issued a patch DMA (HBM latency)
-    // ahead of a weight slice (L2 latency) waits for both when it needs the slice, and a global store ahead of a DMA delays the
-    // wait for that DMA by the store's round trip.  Waves 0..3 therefore issue ONLY weight slices (and wait for them step by step);
-    // waves 4..7 issue the next tile's patch and this tile's stores and wait once per tile.
-    constexpr bool SPLIT = H80_SPLIT != 0;
-    constexpr int WWV = SPLIT ? 4 : NWV;                          // waves that issue weight slices
+    constexpr int WWV = 4, PWV = 4;                               // waves that issue weight slices / patch DMAs
     constexpr int NJ = (WINST + WWV - 1) / WWV;
-    const bool wrole = !SPLIT || wave < 4, prole = !SPLIT || wave >= 4;
-    const int pw = SPLIT ? wave - 4 : wave;                       // index among the patch-issuing waves
-    constexpr int PWV = SPLIT ? 4 : NWV, PPS = PINST / PWV / (NSTEP - 1);      // patch instructions per wave and step (steps 0 .. NSTEP-2)
-    static_assert(PINST % (PWV * (NSTEP - 1)) == 0, "patch DMA instructions spread evenly over the steps");
+    const bool wrole = wave < 4, prole = wave >= 4;
+    const int pw = wave - 4;                                      // index among the patch-issuing waves
+    static_assert(PINST % PWV == 0, "whole patch DMA instructions per issuing wave");
     int nbw = 0;
     unsigned voffW[NJ], voffWL[NJ];
 #pragma unroll
@@ -244,15 +240,10 @@ __global__ __launch_bounds__(512, 1) void conv_h80_kernel(const H80K p)
                 if (st2 < NSTEP) { if (dw) { issue_W(st2, islot); prev_group = nbw; } }
                 else if (has_next && dw) { issue_W(st2 - NSTEP, islot); prev_group = nbw; }
             }
-            if (SPLIT) {                     // the whole patch of the next tile at step 0: a tile's time to land, nobody waits for it before the tile ends
-                if (prole && st == 0 && has_next && !(p.dbg & 2)) {
+            // the whole patch of the next tile at step 0: a tile's time to land, nobody waits for it before the tile ends
+            if (prole && st == 0 && has_next && !(p.dbg & 2)) {
 #pragma unroll
-                    for (int h = 0; h < NPP; ++h) issue_patch(an, h, pb ^ 1);
-                }
-            } else if (st < NSTEP - 1 && has_next && !(p.dbg & 2)) {
-#pragma unroll
-                for (int h = 0; h < PPS; ++h) issue_patch(an, st * PPS + h, pb ^ 1);
-                prev_group += PPS;
+                for (int h = 0; h < NPP; ++h) issue_patch(an, h, pb ^ 1);
             }
             if (st == NSTEP - 1) {
                 // the residual chunks of this thread's output rows are requested behind the last DMA issue of the tile (no counted

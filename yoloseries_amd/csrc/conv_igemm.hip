@@ -1714,7 +1714,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
     constexpr int NWV = 8, NT = 512;
     constexpr int TMR = 4, TNC = 5;                  // 16-pixel / 16-channel tiles per wave (64 x 80)
     constexpr int ROWB = BKT * 2, CHR = 8, RPI = 8;
-    constexpr int NBI = BN / RPI;                    // 20 weight-tile DMA instructions per k-step: 3 for waves 0..3, 2 for waves 4..7
+    // BN / RPI = 20 weight-tile DMA instructions per k-step: 3 for waves 0..3, 2 for waves 4..7
     constexpr int NPW = 5;                           // patch DMA instructions per wave and channel block (<= 5*8*8 = 320 rows)
     constexpr int PATCH_ROWS = 304;
     constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;   // 38912
