@@ -279,7 +279,8 @@ int yh_maxpool5_fwd(const yh_bf16* x, int ldx, int B, int H, int W, int C,
 int yh_maxpool5_bwd(const yh_bf16* gout, int ldgo, const int8_t* idx, int B, int H, int W, int C,
                     yh_bf16* gin, int ldgi, int accumulate, yh_stream stream);
 /* FastSPP's chain x2 = mp(x), x3 = mp(x2), x4 = mp(x3) (utils/layer_tools.py:282-288) in one launch per direction for maps of
- * <= 480 pixels (yh_sppf_pool3_ok; 20 x 20 at 640^2 input): the map of one image x 64 channels lives in LDS, the pools run
+ * <= 1920 pixels (yh_sppf_pool3_ok; 20 x 20 at 640^2 input, 40 x 40 at 1280^2): the map of one image x 32 / 16 / 8 channels (maps of up to
+ * 480 / 960 / 1920 pixels) lives in LDS, the pools run
  * separably.  Bit-identical to three yh_maxpool5_fwd / yh_maxpool5_bwd launches (arg-max rule, summation order, rounding points).
  * Backward: g1..g3 = gradients of x2..x4 as they stand before the pools' backward (ld ldg), gx (+)= the chain's gradient w.r.t. x;
  * the intermediate sums g(x3)', g(x2)' are not written back. */

@@ -201,14 +201,15 @@ def test_maxpool5_fwd_bwd(dev, B, H, W, C):
     assert torch.equal(out2.float()[ok], ref2[ok])
 
 
-@pytest.mark.parametrize("B,H,W,C", [(3, 20, 20, 256), (2, 12, 17, 72), (1, 5, 3, 8), (2, 20, 24, 128)])
+@pytest.mark.parametrize("B,H,W,C", [(3, 20, 20, 256), (2, 12, 17, 72), (1, 5, 3, 8), (2, 20, 24, 128), (2, 24, 32, 80), (1, 40, 40, 72), (2, 40, 48, 16)])
 def test_sppf_fused_pools_bit_identical(dev, B, H, W, C):
     """FastSPP's three chained 5x5 pools in one launch per direction (csrc/sppf.hip) against three yh_maxpool5_fwd / _bwd launches:
-    outputs, arg-max bytes and the input gradient BIT-identical — with ties (coarse values), NaNs and a ragged channel count"""
+    outputs, arg-max bytes and the input gradient BIT-identical — with ties (coarse values), NaNs and a ragged channel count; maps of
+    up to 480 / 960 / 1920 pixels run with 32 / 16 / 8 channels per block (40 x 40: YOLOv5x at 1280 x 1280)"""
     import ctypes as C_
     from yoloseries_amd import hipk
     from yoloseries_amd._lib import check, lib, stream_ptr
-    assert lib().yh_sppf_pool3_ok(H, W, C) == 1 and lib().yh_sppf_pool3_ok(40, 40, C) == 0
+    assert lib().yh_sppf_pool3_ok(H, W, C) == 1 and lib().yh_sppf_pool3_ok(40, 40, C) == 1 and lib().yh_sppf_pool3_ok(40, 49, C) == 0
     cat = torch.zeros(B, H, W, 4 * C, dtype=torch.bfloat16, device=dev)
     x = (_rand_bf16((B, H, W, C), dev, 16).float() * 2).round().div(2).to(torch.bfloat16)
     x[0, H // 2, W // 2, :3] = float("nan")

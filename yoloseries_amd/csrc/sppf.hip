@@ -1,6 +1,6 @@
 // FastSPP's chain of three 5x5 / stride-1 / pad-2 max-pools (utils/layer_tools.py:282-288: x2 = mp(x1), x3 = mp(x2), x4 = mp(x3))
-// in ONE launch per direction.  A block owns one image x 32 channels: the whole map (<= 480 pixels: 20 x 20 at 640^2 input) lives
-// in LDS, so x1 is read from HBM once, the three pools run separably (row maxima, then column maxima: 10 comparisons per output
+// in ONE launch per direction.  A block owns one image x 32 channels (16 / 8 on larger maps): the whole map (<= 480 / 960 / 1920
+// pixels: 20 x 20 at 640^2 input, 40 x 40 at 1280^2) lives in LDS, so x1 is read from HBM once, the three pools run separably (row maxima, then column maxima: 10 comparisons per output
 // instead of 25 — the single-pool kernel is VALU-bound on its 25-tap scan) and a pool's output is the next pool's input without a
 // round trip.  Results are bit-identical to three yh_maxpool5_fwd / yh_maxpool5_bwd launches: same arg-max (first maximum in
 // row-major window order; a NaN takes over and the last NaN wins, as the one-pass scan does — the separable scan provably ends on
@@ -10,9 +10,8 @@
 namespace {
 
 constexpr int SP_NT = 512;
-constexpr int SP_CH = 32;            // channels per block (4 chunks of 16 bytes per pixel): 64 KB of LDS at 20 x 20, two blocks per CU
-constexpr int SP_CPP = SP_CH / 8;    // 16-byte chunks per pixel
-constexpr int SP_MAXPX = 480;
+constexpr int SP_MAXPX = 480;        // map pixels with 32 channels per block (4 chunks of 16 bytes per pixel): 64 KB of LDS at 20 x 20, two blocks per CU;
+                                     // twice / four times the pixels with 16 / 8 channels per block (template parameter SP_CH)
 
 // one step of the scan: the current best (value, position) against a new value
 __device__ __forceinline__ void scan_step(float f, int pos, bool& any, float& best, int& bi) {
@@ -20,10 +19,12 @@ __device__ __forceinline__ void scan_step(float f, int pos, bool& any, float& be
     any = true;
 }
 
+template <int SP_CH>
 __global__ __launch_bounds__(SP_NT) void sppf_pool3_fwd_kernel(const uint16_t* __restrict__ x, int ldx, int H, int W, int C,
                                                                uint16_t* __restrict__ o1, uint16_t* __restrict__ o2, uint16_t* __restrict__ o3, int ldo,
                                                                int8_t* __restrict__ i1, int8_t* __restrict__ i2, int8_t* __restrict__ i3)
 {
+    constexpr int SP_CPP = SP_CH / 8;    // 16-byte chunks per pixel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int HW = H * W;
     uint16_t* sV0 = reinterpret_cast<uint16_t*>(smem);                 // [HW][SP_CH] current pool input
@@ -101,10 +102,12 @@ __global__ __launch_bounds__(SP_NT) void sppf_pool3_fwd_kernel(const uint16_t* _
 
 // backward of the chain: t = g(x4);  g(x3)' = g(x3) + P3^T t;  g(x2)' = g(x2) + P2^T g(x3)';  g(x1) += P1^T g(x2)'  — the intermediate
 // sums are rounded to bf16 where the three single launches store them, and only g(x1) is written back
+template <int SP_CH>
 __global__ __launch_bounds__(SP_NT) void sppf_pool3_bwd_kernel(const uint16_t* __restrict__ g1, const uint16_t* __restrict__ g2, const uint16_t* __restrict__ g3,
                                                                int ldg, const int8_t* __restrict__ i1, const int8_t* __restrict__ i2, const int8_t* __restrict__ i3,
                                                                int H, int W, int C, uint16_t* __restrict__ gx, int ldx, int acc)
 {
+    constexpr int SP_CPP = SP_CH / 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int HW = H * W;
     uint16_t* sT = reinterpret_cast<uint16_t*>(smem);                  // [HW][SP_CH] gradient of the current pool's output
@@ -172,24 +175,36 @@ __global__ __launch_bounds__(SP_NT) void sppf_pool3_bwd_kernel(const uint16_t* _
     }
 }
 
-size_t sppf_smem(int HW) { return (size_t)HW * SP_CH * (2 + 2 + 1); }
+// channels per block for a map of HW pixels (the LDS footprint HW * ch * 5 bytes stays below 77 KB); 0 = map too large
+int sppf_ch(int HW) { return HW <= SP_MAXPX ? 32 : (HW <= 2 * SP_MAXPX ? 16 : (HW <= 4 * SP_MAXPX ? 8 : 0)); }
+size_t sppf_smem(int HW, int ch) { return (size_t)HW * ch * (2 + 2 + 1); }
 
 }  // namespace
 
 /* 1 if the fused SPPF kernels take this map (else the caller runs three yh_maxpool5_* launches) */
-extern "C" int yh_sppf_pool3_ok(int H, int W, int C) { return H > 0 && W > 0 && H * W <= SP_MAXPX && C > 0 && C % 8 == 0; }
+extern "C" int yh_sppf_pool3_ok(int H, int W, int C) { return H > 0 && W > 0 && sppf_ch(H * W) > 0 && C > 0 && C % 8 == 0; }
 
 extern "C" int yh_sppf_pool3_fwd(const yh_bf16* x, int ldx, int B, int H, int W, int C, yh_bf16* o1, yh_bf16* o2, yh_bf16* o3, int ldo,
                                  int8_t* i1, int8_t* i2, int8_t* i3, yh_stream stream)
 {
-    YH_CHECK_ARG(yh_sppf_pool3_ok(H, W, C) && B > 0, "yh_sppf_pool3_fwd: map of more than 480 pixels / bad dims (use yh_maxpool5_fwd)");
+    YH_CHECK_ARG(yh_sppf_pool3_ok(H, W, C) && B > 0, "yh_sppf_pool3_fwd: map of more than 1920 pixels / bad dims (use yh_maxpool5_fwd)");
     YH_CHECK_ARG(x && o1 && o2 && o3 && yh_aligned16(x) && yh_aligned16(o1) && yh_aligned16(o2) && yh_aligned16(o3) && ldx % 8 == 0 && ldo % 8 == 0,
                  "yh_sppf_pool3_fwd: null / unaligned slices");
     YH_CHECK_ARG((i1 == nullptr) == (i2 == nullptr) && (i2 == nullptr) == (i3 == nullptr), "yh_sppf_pool3_fwd: all three arg-max buffers or none");
-    const size_t sm = sppf_smem(H * W);
+    const int ch = sppf_ch(H * W);
+    const size_t sm = sppf_smem(H * W, ch);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)sppf_pool3_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sppf_smem(SP_MAXPX)); attr = true; }
-    sppf_pool3_fwd_kernel<<<dim3(B, (C + SP_CH - 1) / SP_CH), dim3(SP_NT), sm, (hipStream_t)stream>>>(x, ldx, H, W, C, o1, o2, o3, ldo, i1, i2, i3);
+    if (!attr) {
+        const int mx = (int)sppf_smem(SP_MAXPX, 32);
+        (void)hipFuncSetAttribute((const void*)sppf_pool3_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        (void)hipFuncSetAttribute((const void*)sppf_pool3_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        (void)hipFuncSetAttribute((const void*)sppf_pool3_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        attr = true;
+    }
+    const dim3 grid(B, (C + ch - 1) / ch), blk(SP_NT);
+    if (ch == 32)      sppf_pool3_fwd_kernel<32><<<grid, blk, sm, (hipStream_t)stream>>>(x, ldx, H, W, C, o1, o2, o3, ldo, i1, i2, i3);
+    else if (ch == 16) sppf_pool3_fwd_kernel<16><<<grid, blk, sm, (hipStream_t)stream>>>(x, ldx, H, W, C, o1, o2, o3, ldo, i1, i2, i3);
+    else               sppf_pool3_fwd_kernel<8><<<grid, blk, sm, (hipStream_t)stream>>>(x, ldx, H, W, C, o1, o2, o3, ldo, i1, i2, i3);
     YH_CHECK_LAUNCH("yh_sppf_pool3_fwd");
     return YH_OK;
 }
@@ -197,13 +212,23 @@ extern "C" int yh_sppf_pool3_fwd(const yh_bf16* x, int ldx, int B, int H, int W,
 extern "C" int yh_sppf_pool3_bwd(const yh_bf16* g1, const yh_bf16* g2, const yh_bf16* g3, int ldg, const int8_t* i1, const int8_t* i2, const int8_t* i3,
                                  int B, int H, int W, int C, yh_bf16* gx, int ldx, int accumulate, yh_stream stream)
 {
-    YH_CHECK_ARG(yh_sppf_pool3_ok(H, W, C) && B > 0, "yh_sppf_pool3_bwd: map of more than 480 pixels / bad dims (use yh_maxpool5_bwd)");
+    YH_CHECK_ARG(yh_sppf_pool3_ok(H, W, C) && B > 0, "yh_sppf_pool3_bwd: map of more than 1920 pixels / bad dims (use yh_maxpool5_bwd)");
     YH_CHECK_ARG(g1 && g2 && g3 && gx && i1 && i2 && i3 && yh_aligned16(g1) && yh_aligned16(g2) && yh_aligned16(g3) && yh_aligned16(gx) &&
                  ldg % 8 == 0 && ldx % 8 == 0, "yh_sppf_pool3_bwd: null / unaligned slices");
-    const size_t sm = sppf_smem(H * W);
+    const int ch = sppf_ch(H * W);
+    const size_t sm = sppf_smem(H * W, ch);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)sppf_pool3_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sppf_smem(SP_MAXPX)); attr = true; }
-    sppf_pool3_bwd_kernel<<<dim3(B, (C + SP_CH - 1) / SP_CH), dim3(SP_NT), sm, (hipStream_t)stream>>>(g1, g2, g3, ldg, i1, i2, i3, H, W, C, gx, ldx, accumulate);
+    if (!attr) {
+        const int mx = (int)sppf_smem(SP_MAXPX, 32);
+        (void)hipFuncSetAttribute((const void*)sppf_pool3_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        (void)hipFuncSetAttribute((const void*)sppf_pool3_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        (void)hipFuncSetAttribute((const void*)sppf_pool3_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        attr = true;
+    }
+    const dim3 grid(B, (C + ch - 1) / ch), blk(SP_NT);
+    if (ch == 32)      sppf_pool3_bwd_kernel<32><<<grid, blk, sm, (hipStream_t)stream>>>(g1, g2, g3, ldg, i1, i2, i3, H, W, C, gx, ldx, accumulate);
+    else if (ch == 16) sppf_pool3_bwd_kernel<16><<<grid, blk, sm, (hipStream_t)stream>>>(g1, g2, g3, ldg, i1, i2, i3, H, W, C, gx, ldx, accumulate);
+    else               sppf_pool3_bwd_kernel<8><<<grid, blk, sm, (hipStream_t)stream>>>(g1, g2, g3, ldg, i1, i2, i3, H, W, C, gx, ldx, accumulate);
     YH_CHECK_LAUNCH("yh_sppf_pool3_bwd");
     return YH_OK;
 }
