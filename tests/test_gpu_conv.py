@@ -289,6 +289,55 @@ def test_conv_wgrad_fused_bn_backward(dev, Cout, tile_k):
     _close(got, rw, 1e-2, 1e-2 * rw.abs().max().item())
 
 
+@pytest.mark.parametrize("Cout", [32, 48, 64])
+def test_conv_wgrad_patch_form_fused_bn_backward(dev, Cout):
+    """the patch form of the stem's weight gradient with the BatchNorm+SiLU backward apply inside the staging of its gy tile
+    (conv_wgpf_kernel: tile_k 40 + yh_wgrad_desc.bn_*): the staged gz is the apply pass's gz bit for bit, so the result equals the
+    plain patch form on yh_bn_silu_bwd_apply's output up to the order of the fp32 atomics; ragged map (pixels past the edge must
+    stay zero although gz = D there) and a channel count that is not a multiple of 32"""
+    import ctypes as C
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import lib
+    B, H, W, Cin, k = 3, 21, 40, 16, 3
+    M = B * H * W
+    g = torch.Generator().manual_seed(190 + Cout)
+    x = _nhwc(B, H, W, Cin, dev, 191)
+    ga = _nhwc(B, H, W, Cout, dev, 192)
+    z = _nhwc(B, H, W, Cout, dev, 193)
+    z[0, :2] = 0.0
+    ga[0, 0] = 0.0
+    mean, invstd = torch.randn(Cout, generator=g) * 0.3, torch.rand(Cout, generator=g) + 0.5
+    gamma = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    beta = torch.randn(Cout, generator=g) * 0.2
+    scale = gamma.cpu() * invstd
+    ws = torch.cat([scale, beta - mean * scale, mean, invstd]).to(dev)
+    coef = torch.cat([torch.randn(Cout, generator=g) * 0.05, torch.randn(Cout, generator=g) * 0.05]).to(dev)
+    gz = torch.zeros(B, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    hipk.bn_silu_bwd_apply(hipk.full(ga), hipk.full(z), ws, gamma, coef, M, hipk.full(gz))
+
+    def run(gy_t, fused):
+        dw = torch.zeros(Cout, k * k * Cin, device=dev)
+        d = hipk.wgrad_desc(hipk.full(gy_t), Cout, hipk.full(x), 0, Cin, B, H, W, H, W, k, 1, 1, dw, 0)
+        d.tile_k = 40
+        if fused:
+            d.bn_z, d.bn_ldz = z.data_ptr(), Cout
+            d.bn_ws, d.bn_gamma, d.bn_coef = ws.data_ptr(), gamma.data_ptr(), coef.data_ptr()
+        assert lib().yh_conv_wgrad_patch_ok(C.byref(d)) == 1
+        buf = C.create_string_buffer(96)
+        lib().yh_conv_wgrad_patch_name(C.byref(d), buf, 96)
+        assert buf.value.decode().startswith("conv_wgpf_kernel<5" if fused else "conv_wgp_kernel<5"), buf.value
+        hipk.wgrad_launch(d)
+        torch.cuda.synchronize()
+        return dw
+    ref_dw = run(gz, False)
+    got = run(ga, True)
+    assert (got - ref_dw).abs().max().item() <= 2e-5 * ref_dw.abs().max().item() + 1e-6
+    w = torch.zeros(Cout, Cin, k, k, device=dev, requires_grad=True)
+    (rw,) = torch.autograd.grad(F.conv2d(_nchw(x), w, padding=1), w, _nchw(gz))
+    rw = rw.permute(0, 2, 3, 1).reshape(Cout, -1)
+    _close(got, rw, 1e-2, 1e-2 * rw.abs().max().item())
+
+
 @pytest.mark.parametrize("C0,C1,Cout", [(32, 64, 64), (512, 448, 128)])
 def test_conv_wgrad_segment_upsampled(dev, C0, C1, Cout):
     """wgrad of one segment of a concat input, read through the 2x upsample (wide tiling; general tiling)."""

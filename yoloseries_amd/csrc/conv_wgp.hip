@@ -39,6 +39,8 @@ struct WgpK {
     int ntile_n, ntile_c, ntiles_acc, tpw;      // accumulator tiles: n-tiles x channel-tiles (over the taps), tiles per wave
     int ntaps, kw_, pad;                        // 9 taps (3x3, pad 1) or 1 (1x1, pad 0: the "patch" is the region itself)
     unsigned gybytes, xbytes;
+    // fused BatchNorm+SiLU backward apply (conv_wgpf_kernel): gy holds ga, gz = A*dz + (Bc*z + D) is formed while the tile is staged
+    const uint16_t* z; int ldz; const float* ws; const float* gamma; const float* coef; unsigned zbytes;
 };
 
 // PG / PX: LDS pitches (elements) of the gy tile and of the patch: 64 or 192 bytes mod 256 (conflict-free transposing reads)
@@ -46,8 +48,8 @@ constexpr int wgp_pitch(int cols) { const int r = (cols + 31) / 32 * 32; return 
 
 // NW waves per block (chosen so that the accumulator tiles divide evenly over them), TPW accumulator tiles per wave, NGI / NXI
 // 16-byte chunks per thread of the gy tile / of the patch
-template <int NW, int TPW, int NGI, int NXI>
-__global__ __launch_bounds__(64 * NW, (NW >= 8 ? 1 : (TPW <= 2 ? WGP_MINB : 2))) void conv_wgp_kernel(const WgpK p, const int PG, const int PX)
+template <int NW, int TPW, int NGI, int NXI, bool FBN>
+__device__ __forceinline__ void wgp_body(const WgpK& p, const int PG, const int PX)
 {
     constexpr int NT = 64 * NW;
     constexpr unsigned OOB = 0x80000000u;
@@ -61,6 +63,22 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 ? 1 : (TPW <= 2 ? WGP_MINB : 2)))
     const int s = p.stride;
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.gy, 0, p.gybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)(FBN ? p.z : p.gy), 0, FBN ? p.zbytes : p.gybytes, 0x00020000);
+    // FBN: gz = A*dz + (Bc*z + D), dz = ga*silu'(z*sc + sh) — bn_silu_bwd_apply_kernel's arithmetic (elementwise.hip), the five
+    // per-channel constants in LDS behind the patch: sCst[5][64] = sc | sh | A | Bc | D
+    float* const sCst = reinterpret_cast<float*>(sX + p.npatch * PX);
+    if (FBN) {
+        for (int c = t; c < 64; c += NT) {
+            const int cc = c < p.N ? c : 0;
+            const float mu = p.ws[2 * p.N + cc], is = p.ws[3 * p.N + cc];
+            const float gi = p.gamma[cc] * is;
+            const float c1 = p.coef[cc], c2 = p.coef[p.N + cc];
+            sCst[c] = p.ws[cc]; sCst[64 + c] = p.ws[p.N + cc];
+            sCst[128 + c] = gi;
+            sCst[192 + c] = -gi * is * c2;
+            sCst[256 + c] = gi * (mu * is * c2 - c1);
+        }
+    }
 
     // ---- staging maps: 16-byte chunks of the gy tile / the patch, dealt over the threads
     const int gch = (p.N + 7) / 8, xch = p.C / 8;               // chunks per pixel
@@ -98,7 +116,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 ? 1 : (TPW <= 2 ? WGP_MINB : 2)))
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-    u32x4_t rg[NGI], rx[NXI];
+    u32x4_t rg[NGI], rx[NXI], rz[FBN ? NGI : 1];
+    unsigned gok = 0;                                           // FBN: which of this thread's gy chunks are pixels of the map
     auto tile_origin = [&](int tile, int& b, int& i0, int& j0) {
         const int per = p.tx * p.ty;
         b = tile / per;
@@ -117,6 +136,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 ? 1 : (TPW <= 2 ? WGP_MINB : 2)))
             const int gi = i0 + i, gj = j0 + jj;
             const bool ok = id < ng_items && gi < p.Ho && gj < p.Wo;
             rg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsg, ok ? (unsigned)(((b * p.Ho + gi) * p.Wo + gj) * (p.ldg * 2) + chn * 16) : OOB, 0, 0);
+            if (FBN) {
+                rz[j] = __builtin_amdgcn_raw_buffer_load_b128(rsz, ok ? (unsigned)(((b * p.Ho + gi) * p.Wo + gj) * (p.ldz * 2) + chn * 16) : OOB, 0, 0);
+                gok = (gok & ~(1u << j)) | ((ok ? 1u : 0u) << j);
+            }
         }
         const int pi0 = i0 * s - p.pad, pj0 = j0 * s - p.pad;
 #pragma unroll
@@ -133,7 +156,31 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 ? 1 : (TPW <= 2 ? WGP_MINB : 2)))
 #pragma unroll
         for (int j = 0; j < NGI; ++j) {
             const int id = t + j * NT;
-            if (id < ng_items) { const int px = id / gch, chn = id - px * gch; *reinterpret_cast<u32x4_t*>(sG + px * PG + chn * 8) = rg[j]; }
+            if (id < ng_items) {
+                const int px = id / gch, chn = id - px * gch;
+                u32x4_t v = rg[j];
+                if (FBN) {
+                    float g[8], z[8], o[8];
+                    unpack8(make_uint4(rg[j].x, rg[j].y, rg[j].z, rg[j].w), g);
+                    unpack8(make_uint4(rz[j].x, rz[j].y, rz[j].z, rz[j].w), z);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = chn * 8 + e;
+                        const float a = z[e] * sCst[c] + sCst[64 + c];
+                        const float sg = sigmoid_fast(a);
+                        const float dz = g[e] * (sg * (1.f + a * (1.f - sg)));
+                        o[e] = sCst[128 + c] * dz + (sCst[192 + c] * z[e] + sCst[256 + c]);
+                    }
+                    // pixels past the map / padded channels were loaded as zeros: dz = 0, but Bc*0 + D is not — they stay zero
+                    const uint4 w = ((gok >> j) & 1u) ? pack8(o) : make_uint4(0, 0, 0, 0);
+                    v = u32x4_t{w.x, w.y, w.z, w.w};
+                    if (chn * 8 + 8 > p.N) {                    // ragged last chunk: channels >= N stay zero
+                        uint16_t* q = reinterpret_cast<uint16_t*>(&v);
+                        for (int e = 0; e < 8; ++e) if (chn * 8 + e >= p.N) q[e] = 0;
+                    }
+                }
+                *reinterpret_cast<u32x4_t*>(sG + px * PG + chn * 8) = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NXI; ++j) {
@@ -191,6 +238,18 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 ? 1 : (TPW <= 2 ? WGP_MINB : 2)))
     }
 }
 
+template <int NW, int TPW, int NGI, int NXI>
+__global__ __launch_bounds__(64 * NW, (NW >= 8 ? 1 : (TPW <= 2 ? WGP_MINB : 2))) void conv_wgp_kernel(const WgpK p, const int PG, const int PX)
+{
+    wgp_body<NW, TPW, NGI, NXI, false>(p, PG, PX);
+}
+// the stem's form: BatchNorm+SiLU backward apply inside the staging of the gy tile (yh_wgrad_desc.bn_z)
+template <int NW, int TPW, int NGI, int NXI>
+__global__ __launch_bounds__(64 * NW, (NW >= 8 ? 1 : (TPW <= 2 ? WGP_MINB : 2))) void conv_wgpf_kernel(const WgpK p, const int PG, const int PX)
+{
+    wgp_body<NW, TPW, NGI, NXI, true>(p, PG, PX);
+}
+
 struct WgpPlan { WgpK k; int nw, tpw, ngi, nxi, PG, PX, gx, smem; };
 
 bool wgp_plan(const yh_wgrad_desc* d, WgpPlan* pl)
@@ -198,7 +257,7 @@ bool wgp_plan(const yh_wgrad_desc* d, WgpPlan* pl)
     const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2);
     const bool k1 = d->KH == 1 && d->KW == 1 && d->pad == 0 && d->stride == 1;
     if (!(k3 || k1) || d->seg.ups) return false;
-    if (d->bn_z || d->partial) return false;
+    if (d->partial) return false;
     const int C = d->seg.C, N = d->N;
     if (!(C == 16 || C == 32 || C == 64) || N < 8 || N > 64) return false;      // staging registers: <= 8 gy chunks per pixel
     if (d->stride == 2 && C > 32) return false;                                    // ... and <= 11 patch chunks per thread
@@ -223,6 +282,7 @@ bool wgp_plan(const yh_wgrad_desc* d, WgpPlan* pl)
     // 151 us on YOLOv5s), else four (measured: 3 waves x 3 tiles for the 9-tile layers equal, 6 x 3 for the 18-tile layer 20 % slower)
     const int na = k.ntiles_acc;
     const int nw = (na == 5 || na == 10) ? 5 : (na > 20 ? 8 : 4);      // > 20 tiles (64 -> 64, 3x3): eight waves x 5
+    if (d->bn_z && nw != 5) return false;               // fused BatchNorm backward: the stem shapes only
     pl->nw = nw;
     k.tpw = (na + nw - 1) / nw;
     if (k.tpw > 5) return false;                        // <= 5 x 16 accumulator registers per lane
@@ -235,9 +295,16 @@ bool wgp_plan(const yh_wgrad_desc* d, WgpPlan* pl)
     k.dw = d->dw; k.Ktot = k.ntaps * d->Ctot; k.Ctot = d->Ctot; k.coff_k = d->coff_k;
     k.B = d->B; k.Ho = d->Ho; k.Wo = d->Wo; k.Hi = d->Hi; k.Wi = d->Wi; k.stride = s;
     k.gybytes = (unsigned)gyb; k.xbytes = (unsigned)xb;
+    k.z = d->bn_z; k.ldz = d->bn_ldz; k.ws = d->bn_ws; k.gamma = d->bn_gamma; k.coef = d->bn_coef; k.zbytes = 0;
+    if (d->bn_z) {
+        if (!d->bn_ws || !d->bn_gamma || !d->bn_coef || d->bn_ldz % 8 || (((uintptr_t)d->bn_z) & 15)) return false;
+        const unsigned long zb = ((unsigned long)d->B * d->Ho * d->Wo - 1) * d->bn_ldz * 2 + (unsigned long)((N + 7) / 8 * 8) * 2;
+        if (zb >= (1ul << 31)) return false;
+        k.zbytes = (unsigned)zb;
+    }
     pl->PG = wgp_pitch(k.ntile_n * 32);
     pl->PX = wgp_pitch(C < 32 ? 32 : C);
-    pl->smem = (k.TH * WGP_TW * pl->PG + k.npatch * pl->PX) * 2;
+    pl->smem = (k.TH * WGP_TW * pl->PG + k.npatch * pl->PX) * 2 + (d->bn_z ? 5 * 64 * 4 : 0);
     int occ = (150 * 1024) / pl->smem;
     const int occ_max = nw >= 8 ? 1 : (k.tpw <= 2 ? WGP_MINB : 2);      // __launch_bounds__
     if (occ > occ_max) occ = occ_max;
@@ -270,7 +337,7 @@ extern "C" int yh_conv_wgrad_patch_name(const yh_wgrad_desc* d, char* buf, int b
     buf[0] = 0;
     if (!d || !wgp_plan(d, &pl)) return YH_OK;
     const int i = wgp_pick(pl);
-    if (i >= 0) snprintf(buf, buflen, "conv_wgp_kernel<%d, %d, %d, %d>", kWgpInst[i][0], kWgpInst[i][1], kWgpInst[i][2], kWgpInst[i][3]);
+    if (i >= 0) snprintf(buf, buflen, "conv_wgp%s_kernel<%d, %d, %d, %d>", d->bn_z ? "f" : "", kWgpInst[i][0], kWgpInst[i][1], kWgpInst[i][2], kWgpInst[i][3]);
     return YH_OK;
 }
 
@@ -287,6 +354,18 @@ int yh_wgp_run(const yh_wgrad_desc* d, yh_stream stream)
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgp_kernel<NW_, TPW_, NGI_, NXI_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; } \
         conv_wgp_kernel<NW_, TPW_, NGI_, NXI_><<<dim3(pl.gx), dim3(64 * NW_), pl.smem, st>>>(pl.k, pl.PG, pl.PX);  \
     }
+#define YH_TRY_WGPF(I_, NW_, TPW_, NGI_, NXI_)                                                                    \
+    if (inst == I_ && d->bn_z) {                                                                                  \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgpf_kernel<NW_, TPW_, NGI_, NXI_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; } \
+        conv_wgpf_kernel<NW_, TPW_, NGI_, NXI_><<<dim3(pl.gx), dim3(64 * NW_), pl.smem, st>>>(pl.k, pl.PG, pl.PX); \
+        YH_CHECK_LAUNCH("yh_conv_wgrad(patch, fused BatchNorm backward)");                                        \
+        return YH_OK;                                                                                             \
+    }
+    YH_TRY_WGPF(0, 5, 1, 4, 3)
+    YH_TRY_WGPF(1, 5, 2, 7, 3)
+#undef YH_TRY_WGPF
+    YH_CHECK_ARG(!d->bn_z, "yh_conv_wgrad: the patch form fuses the BatchNorm backward for the stem shapes only");
     YH_TRY_WGP(0, 5, 1, 4, 3)        // stem, <= 32 outputs (C = 16: 5 tiles, one per wave)
     YH_TRY_WGP(1, 5, 2, 7, 3)        // stem, 64 outputs (10 tiles)
     YH_TRY_WGP(2, 4, 1, 8, 8)        // 1x1 layers: <= 64 channels on both sides (<= 4 tiles)

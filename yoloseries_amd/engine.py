@@ -127,11 +127,14 @@ MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct
 # order by a second kernel (yh_wgrad_desc.partial) instead of fp32 atomics: BIT-REPRODUCIBLE gradients.  Measured on the YOLOv5s
 # step: the weight-gradient kernels themselves get 4 % faster (3.67 -> 3.52 ms), the step 1.6 % slower (the 2.5 GB of partial
 # tiles are written and read back next to an HBM-bound main chain) — so the atomic form stays the default.
-# YH_FUSE_STEM_BWD=1: the BatchNorm backward apply of a layer without a data gradient (the stem) runs inside its weight gradient's
-# operand loader (yh_wgrad_desc.bn_*; bit-identical, tests/test_gpu_conv.py).  Measured on the YOLOv5s step: the fused kernel takes
-# 0.55 ms against 0.22 (apply pass, HBM-bound) + 0.25 (weight gradient) — the sigmoid of 210 M elements is hidden behind HBM time in
-# the streaming pass but not between the barriers of a 15-wave-per-CU GEMM — and the step gets 1 % slower: opt-in.
-FUSE_STEM_BWD = os.environ.get("YH_FUSE_STEM_BWD", "0") == "1"
+# YH_FUSE_STEM_BWD: the BatchNorm backward apply of a layer without a data gradient (the stem) runs inside its weight gradient's
+# operand staging (yh_wgrad_desc.bn_*; the staged gz is the apply pass's gz bit for bit, tests/test_gpu_conv.py): the last pass of
+# the backward's critical path and the gz round trip through HBM disappear.  1 (default): where the patch form of the weight
+# gradient takes the layer (conv_wgpf_kernel: <= 64 output channels) — measured on the YOLOv5s step 12.70 -> 12.58..12.64 ms (+0.8 %,
+# profiles/r03_step_experiments.txt m); 2: also through the im2col form (conv_wgrad_kernel<..., FBN>: 0.55 ms against 0.22 + 0.25 —
+# the sigmoid of 210 M elements is hidden behind HBM time in a streaming pass but not between the barriers of a 15-wave-per-CU GEMM;
+# the step gets 1 % slower); 0: never.
+FUSE_STEM_BWD = int(os.environ.get("YH_FUSE_STEM_BWD", "1"))
 SPPF_FUSE = os.environ.get("YH_SPPF_FUSE", "1") != "0"      # FastSPP's three pools in one launch per direction (csrc/sppf.hip)
 WG_WS_BYTES = (256 << 20) if os.environ.get("YH_WGRAD_PARTIAL", "0") == "1" else 0
 NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weight gradients may lag behind by
@@ -889,6 +892,20 @@ class Program:
         out = 2.0 * d.B * d.Ho * d.Wo * d.N
         return rd + out * (2.0 if d.accumulate else 1.0) + (out * min(1.0, d.nsplit / max(d.N, 1)) if d.res else 0.0) + (out if d.bnr_part else 0.0)
 
+    def _stem_patch_ok(self, op):
+        """does the patch form of the weight gradient (conv_wgpf_kernel) take this layer with the fused BatchNorm backward?"""
+        wd = WgradDesc()
+        wd.gy, wd.ldg, wd.N = op.y.t.data_ptr(), op.N, op.N
+        wd.bn_z, wd.bn_ldz = op.y.t.data_ptr(), op.y.C
+        wd.bn_ws = wd.bn_gamma = wd.bn_coef = op.y.t.data_ptr()          # placeholders: eligibility only looks at null / alignment
+        wd.seg = hipk.make_seg(op.segs[0].sl())
+        wd.coff_k, wd.Ctot = 0, op.Ctot
+        wd.B, wd.Ho, wd.Wo, wd.Hi, wd.Wi = self.B, op.Ho, op.Wo, op.Hi, op.Wi
+        wd.KH = wd.KW = op.k
+        wd.stride, wd.pad = op.stride, op.pad
+        wd.tile_k = 40
+        return bool(self.L.yh_conv_wgrad_patch_ok(C.byref(wd)))
+
     def _fam_conv(self, op, d):
         M = self.B * op.Ho * op.Wo
         return (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else op.Ctot), self._conv_bytes(d))
@@ -1116,7 +1133,8 @@ class Program:
                 Kseg0 = op.k * op.k * op.segs[0].C
                 fused_stem = (FUSE_STEM_BWD and not BN_ACC and len(op.parts) == 1 and len(op.segs) == 1 and op.res is None and
                               not op.segs[0].buf.needs_grad and op.N % 8 == 0 and
-                              ((op.N <= 32 and Kseg0 <= 256) or (op.N > 32 and 128 < Kseg0 <= 256)))
+                              ((op.N <= 32 and Kseg0 <= 256) or (op.N > 32 and 128 < Kseg0 <= 256)) and
+                              (FUSE_STEM_BWD >= 2 or (self.wg_ws is None and self._stem_patch_ok(op))))
                 merged = (MERGE_PARTS and not BN_ACC and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and
                           not (op.res is not None and op.res.buf.needs_grad))
                 bwd_parts = (BnPart * len(op.parts))() if merged else None
@@ -1312,7 +1330,7 @@ class Program:
             tks = tks + (128,)              # the general 128-column tiling on a layer that defaults to a wide one
         best, best_ms = None, None
         wd.tile_k = 40
-        if not wd.partial and not wd.bn_z and self.L.yh_conv_wgrad_patch_ok(C.byref(wd)):
+        if not wd.partial and self.L.yh_conv_wgrad_patch_ok(C.byref(wd)):
             tks = tks + (40,)               # patch form (conv_wgp_kernel): the input patch of a pixel region staged once in LDS
         for tk in tks:
             wd.tile_k = tk
