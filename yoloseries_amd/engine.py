@@ -989,6 +989,7 @@ class Program:
     def _build_backward(self):
         B, pk, L = self.B, self.pack, self.L
         cmds = []
+        self._wgrad_on_main = set()      # ids of the weight-gradient descriptors that stay on the main stream
         max_gy = 0
         for b in self.bufs:
             b.ginit = np.zeros(b.C, dtype=bool)
@@ -1208,8 +1209,12 @@ class Program:
                     cmds.append((L.yh_bn_silu_bwd_apply_parts, (op.y.t.data_ptr(), op.y.C, M, bwd_parts, len(op.parts), gys.data_ptr(), op.N),
                                  op.name, ('yh_bn_silu_bwd_apply_parts', 0, 6.0 * M * op.N)))
                 gy_ld, gyN = op.N, op.N
-            # wgrad per segment (side stream: starts when gz is ready)
-            cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
+            # wgrad per segment (side stream: starts when gz is ready).  The fused stem's weight gradient is the LAST link of the backward's
+            # critical chain (it waits for the finalize behind the last data gradient): it stays on the main stream, beside the side
+            # stream's last weight gradient instead of behind it
+            on_main = op.kind == 'cba' and fused_stem
+            if not on_main:
+                cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
             coff_k = 0
             for si, sg in enumerate(op.segs):
                 wd = WgradDesc()
@@ -1231,10 +1236,13 @@ class Program:
                 ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
                 wd.splits = self._tune_wgrad_splits(wd, M, ntile, op)
                 self._keep.append(wd)
+                if on_main:
+                    self._wgrad_on_main.add(id(wd))
                 cmds.append(('wgrad', op, wd, (self._wgrad_name(L, wd), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C),
                                                2.0 * M * gy_ld * (2 if wd.bn_z else 1) + 2.0 * B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.C)))
                 coff_k += sg.C
-            cmds.append(('wg_end', (n_cba - 1) % NGZ if op.kind == 'cba' else None, None, ('sync', 0, 0.0)))
+            if not on_main:
+                cmds.append(('wg_end', (n_cba - 1) % NGZ if op.kind == 'cba' else None, None, ('sync', 0, 0.0)))
             # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
             marks.append((len(cmds), pk.gloc[op.name]))
             # dgrad per segment
@@ -1446,7 +1454,7 @@ class Program:
                 _, op, wd, _m = cmd
                 if "wgrad" in ABL_SKIP:
                     continue
-                cc.call(L.yh_conv_wgrad, (wd,), 1 if two else 0, op.name)
+                cc.call(L.yh_conv_wgrad, (wd,), 1 if two and id(wd) not in self._wgrad_on_main else 0, op.name)
                 if op.kind == 'plain':
                     patches.append(('wgrad', wd, op.name, -1))
             elif fn == 'dgrad':
@@ -1560,7 +1568,7 @@ class Program:
                         self._ev_wg[cmd[1]].record(side)
                         pending[cmd[1]] = True
                 continue
-            on_side = two and fn == 'wgrad'
+            on_side = two and fn == 'wgrad' and id(cmd[2]) not in self._wgrad_on_main
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side if on_side else None)
@@ -1576,7 +1584,7 @@ class Program:
                 _, op, wd, _m = cmd
                 if op.kind == 'plain':
                     wd.gy = heads[op.name].data_ptr()
-                rc = L.yh_conv_wgrad(C.byref(wd), st_side if two else st)
+                rc = L.yh_conv_wgrad(C.byref(wd), st_side if on_side else st)
                 if rc:
                     check(rc, f"yh_conv_wgrad [{op.name}]")
             elif fn == 'dgrad':
