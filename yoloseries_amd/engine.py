@@ -892,6 +892,16 @@ class Program:
         out = 2.0 * d.B * d.Ho * d.Wo * d.N
         return rd + out * (2.0 if d.accumulate else 1.0) + (out * min(1.0, d.nsplit / max(d.N, 1)) if d.res else 0.0) + (out if d.bnr_part else 0.0)
 
+    def _is_fused_stem(self, op):
+        """a ConvBnAct without a data gradient (the stem) whose BatchNorm backward apply runs inside its weight gradient (YH_FUSE_STEM_BWD)"""
+        if not isinstance(op, ConvOp) or op.kind != 'cba':
+            return False
+        Kseg0 = op.k * op.k * op.segs[0].C
+        return bool(FUSE_STEM_BWD and not BN_ACC and len(op.parts) == 1 and len(op.segs) == 1 and op.res is None and
+                    not op.segs[0].buf.needs_grad and op.N % 8 == 0 and
+                    ((op.N <= 32 and Kseg0 <= 256) or (op.N > 32 and 128 < Kseg0 <= 256)) and
+                    (FUSE_STEM_BWD >= 2 or (self.wg_ws is None and self._stem_patch_ok(op))))
+
     def _stem_patch_ok(self, op):
         """does the patch form of the weight gradient (conv_wgpf_kernel) take this layer with the fused BatchNorm backward?"""
         wd = WgradDesc()
@@ -1131,11 +1141,7 @@ class Program:
                 # a layer without a data gradient (the stem: its input is the image) hands gz to nobody but its own weight
                 # gradient: that kernel forms gz from (ga, z) in its operand loader (yh_wgrad_desc.bn_*), the apply pass — the
                 # last 0.2 ms of the backward's critical path on YOLOv5s — and the gz round trip through HBM disappear
-                Kseg0 = op.k * op.k * op.segs[0].C
-                fused_stem = (FUSE_STEM_BWD and not BN_ACC and len(op.parts) == 1 and len(op.segs) == 1 and op.res is None and
-                              not op.segs[0].buf.needs_grad and op.N % 8 == 0 and
-                              ((op.N <= 32 and Kseg0 <= 256) or (op.N > 32 and 128 < Kseg0 <= 256)) and
-                              (FUSE_STEM_BWD >= 2 or (self.wg_ws is None and self._stem_patch_ok(op))))
+                fused_stem = self._is_fused_stem(op)
                 merged = (MERGE_PARTS and not BN_ACC and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and
                           not (op.res is not None and op.res.buf.needs_grad))
                 bwd_parts = (BnPart * len(op.parts))() if merged else None
