@@ -135,6 +135,7 @@ MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct
 # the sigmoid of 210 M elements is hidden behind HBM time in a streaming pass but not between the barriers of a 15-wave-per-CU GEMM;
 # the step gets 1 % slower); 0: never.
 FUSE_STEM_BWD = int(os.environ.get("YH_FUSE_STEM_BWD", "1"))
+HEAD_COLSUM_SIDE = os.environ.get("YH_HEAD_COLSUM_SIDE", "1") != "0"    # bias gradients of the head layers on the weight-gradient stream
 SPPF_FUSE = os.environ.get("YH_SPPF_FUSE", "1") != "0"      # FastSPP's three pools in one launch per direction (csrc/sppf.hip)
 WG_WS_BYTES = (256 << 20) if os.environ.get("YH_WGRAD_PARTIAL", "0") == "1" else 0
 NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weight gradients may lag behind by
@@ -892,6 +893,12 @@ class Program:
         out = 2.0 * d.B * d.Ho * d.Wo * d.N
         return rd + out * (2.0 if d.accumulate else 1.0) + (out * min(1.0, d.nsplit / max(d.N, 1)) if d.res else 0.0) + (out if d.bnr_part else 0.0)
 
+    def _head_scratch(self, op, two):
+        """partial-sum scratch of a head layer's bias gradient: its own buffer when the column sums run on the side stream"""
+        if two and HEAD_COLSUM_SIDE and op.y.C * 1024 * 2 <= self.head_scratch.numel():
+            return self.head_scratch.data_ptr()
+        return self.part_scratch.data_ptr()
+
     def _is_fused_stem(self, op):
         """a ConvBnAct without a data gradient (the stem) whose BatchNorm backward apply runs inside its weight gradient (YH_FUSE_STEM_BWD)"""
         if not isinstance(op, ConvOp) or op.kind != 'cba':
@@ -1016,6 +1023,9 @@ class Program:
         self.gy_ring = [self.gy_scratch] + ([torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev) for _ in range(NGZ - 1)] if self.two_streams else [self.gy_scratch] * (NGZ - 1))
         n_cba = 0
         self.part_scratch = torch.zeros(1024 * 2 * 2048, dtype=torch.float32, device=self.dev)
+        # partial sums of the head layers' bias gradients (column sums of the head gradients): these run on the SIDE stream (they feed
+        # nothing but the packed gradient arena; the largest takes 76 us on YOLOv5s) and may not share a scratch with the main stream
+        self.head_scratch = torch.zeros(1024 * 2 * 256, dtype=torch.float32, device=self.dev)
         self.coef_scratch = {}
         self.ups_scratch = {}
         self.wgrad_tuned = {}
@@ -1453,8 +1463,8 @@ class Program:
             elif fn == 'head_colsum':
                 _, op, boff, _m = cmd
                 if boff is not None:
-                    i = cc.call(L.yh_colsum, (0, op.y.C, op.y.C, self.B * op.Ho * op.Wo, self.part_scratch.data_ptr(),
-                                              self.pack.gpack.data_ptr() + 4 * boff), 0, op.name)
+                    i = cc.call(L.yh_colsum, (0, op.y.C, op.y.C, self.B * op.Ho * op.Wo, self._head_scratch(op, two),
+                                              self.pack.gpack.data_ptr() + 4 * boff), 1 if two and HEAD_COLSUM_SIDE else 0, op.name)
                     patches.append(('colsum', None, op.name, i))
             elif fn == 'wgrad':
                 _, op, wd, _m = cmd
@@ -1574,7 +1584,7 @@ class Program:
                         self._ev_wg[cmd[1]].record(side)
                         pending[cmd[1]] = True
                 continue
-            on_side = two and fn == 'wgrad' and id(cmd[2]) not in self._wgrad_on_main
+            on_side = two and ((fn == 'wgrad' and id(cmd[2]) not in self._wgrad_on_main) or (fn == 'head_colsum' and HEAD_COLSUM_SIDE))
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side if on_side else None)
@@ -1582,8 +1592,8 @@ class Program:
                 _, op, boff, _m = cmd
                 g = heads[op.name]
                 if boff is not None:
-                    rc = L.yh_colsum(g.data_ptr(), op.y.C, op.y.C, self.B * op.Ho * op.Wo, self.part_scratch.data_ptr(),
-                                     pk.gpack.data_ptr() + 4 * boff, st)
+                    rc = L.yh_colsum(g.data_ptr(), op.y.C, op.y.C, self.B * op.Ho * op.Wo, self._head_scratch(op, two),
+                                     pk.gpack.data_ptr() + 4 * boff, st_side if on_side else st)
                     if rc:
                         check(rc, "yh_colsum")
             elif fn == 'wgrad':
