@@ -357,6 +357,81 @@ def test_conv_wgrad_segment_upsampled(dev, C0, C1, Cout):
     _close(dw, ref, 2e-3, 2e-3 * ref.abs().max().item())
 
 
+WGS_CASES = [
+    # B, H, W, Cin (segment), Cout, k, s, coff_k, Ctot, ups
+    (2, 20, 20, 128, 128, 3, 1, 0, 128, 0),      # YOLOv5s stage-3 bottleneck class: 9 tiles, 20-wide map (a 16-pixel stage wraps rows)
+    (2, 16, 16, 128, 256, 3, 2, 0, 128, 0),      # stride 2, two n-tiles
+    (1, 16, 24, 256, 192, 3, 1, 0, 256, 0),      # two column tiles per tap, ragged n-tile (192 = 128 + 64)
+    (2, 20, 20, 256, 255, 1, 1, 0, 256, 0),      # pointwise (scalar walk), N not a multiple of 8 (Detect)
+    (2, 8, 8, 128, 128, 3, 1, 128, 384, 0),      # a segment of a concat input: columns [128, 256) of every tap; 8 x 8 map (a stage spans two rows)
+    (2, 16, 16, 128, 64, 1, 1, 0, 256, 1),       # segment read through the 2x upsample (not the pointwise walk), half-empty n-tile
+    (1, 4, 8, 128, 128, 3, 1, 0, 128, 0),        # ONE work unit: three of the four waves have nothing to do
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,coff,Ctot,ups", WGS_CASES)
+@pytest.mark.parametrize("groups", [1, 7, -1, 256])
+def test_conv_wgrad_wave_private_tiles(dev, B, H, W, Cin, Cout, k, s, coff, Ctot, ups, groups):
+    """conv_wgs_kernel (tile_k 129): wave-private 128 x 128 tiles fed by per-wave LDS-DMA rings, stream-K over `splits`
+    workgroups (1: one workgroup walks every tile; 7: workgroups end one tile and begin the next; -1: the exact tiles x 3 grid
+    with the XCD-aware block map; 256), partial tiles combined through LDS and added to what dw holds.  The operands are slices
+    of wider NaN-filled buffers: bytes outside the slices never reach an MFMA."""
+    import ctypes as C
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import lib
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    ldg = ((Cout + 7) // 8) * 8
+    gyw = torch.full((B, Ho, Wo, ldg + 16), float("nan"), dtype=torch.bfloat16, device=dev)
+    gyw[..., :ldg] = 0
+    gyw[..., :Cout] = _nhwc(B, Ho, Wo, Cout, dev, 20)
+    Hs, Ws = H >> ups, W >> ups
+    xw = torch.full((B, Hs, Ws, Cin + 32), float("nan"), dtype=torch.bfloat16, device=dev)
+    xw[..., 16:16 + Cin] = _nhwc(B, Hs, Ws, Cin, dev, 21)
+    dw = torch.full((Cout, k * k * Ctot), 0.5, device=dev)
+    d = hipk.wgrad_desc(hipk.Slice(gyw, 0, ldg), Cout, hipk.Slice(xw, 16, Cin, ups=ups), coff, Ctot, B, Ho, Wo, H, W, k, s, p, dw, 1)
+    d.tile_k = 129
+    T = lib().yh_conv_wgrad_wave_tiles(C.byref(d))
+    assert T == ((Cout + 127) // 128) * k * k * (Cin // 128)
+    d.splits = 3 * T if groups < 0 else groups
+    assert lib().yh_conv_wgrad_wave_name(C.byref(d)).decode().startswith("conv_wgs_kernel<")
+    hipk.wgrad_launch(d)
+    torch.cuda.synchronize()
+    xin = _nchw(xw[..., 16:16 + Cin])
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    w = torch.zeros(Cout, Cin, k, k, device=dev, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xin, w, stride=s, padding=p), w, _nchw(gyw[..., :Cout]))
+    ref = ref.permute(0, 2, 3, 1)                                  # [Cout][kh][kw][Cin]
+    got = dw.reshape(Cout, k, k, Ctot)
+    assert not torch.isnan(dw).any()
+    _close(got[..., coff:coff + Cin] - 0.5, ref, 2e-3, 2e-3 * ref.abs().max().item())
+    mask = torch.ones(Ctot, dtype=torch.bool, device=dev)
+    mask[coff:coff + Cin] = False
+    assert (got[..., mask] == 0.5).all()                           # the other segments' columns are untouched
+
+
+def test_conv_wgrad_wave_private_tiles_eligibility(dev):
+    """layers the form does not cover fall through to the im2col forms (yh_conv_wgrad_wave_tiles == 0, tile_k 129 ignored)"""
+    import ctypes as C
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import lib
+    for (B, H, W, Cin, Cout, k) in [(2, 16, 16, 64, 128, 3), (1, 13, 13, 128, 128, 3), (2, 16, 16, 128, 32, 1)]:
+        p = k // 2
+        gy = _nhwc(B, H, W, Cout, dev, 22)
+        x = _nhwc(B, H, W, Cin, dev, 23)
+        dw = torch.zeros(Cout, k * k * Cin, device=dev)
+        d = hipk.wgrad_desc(hipk.full(gy), Cout, hipk.full(x), 0, Cin, B, H, W, H, W, k, 1, p, dw, 4)
+        d.tile_k = 129
+        assert lib().yh_conv_wgrad_wave_tiles(C.byref(d)) == 0
+        hipk.wgrad_launch(d)
+        torch.cuda.synchronize()
+        w = torch.zeros(Cout, Cin, k, k, device=dev, requires_grad=True)
+        (ref,) = torch.autograd.grad(F.conv2d(_nchw(x), w, padding=p), w, _nchw(gy))
+        ref = ref.permute(0, 2, 3, 1).reshape(Cout, -1)
+        _close(dw, ref, 2e-3, 2e-3 * ref.abs().max().item())
+
+
 # ---- kernel families: the register-staged kernel (algo 1) and the LDS-DMA ring kernel with its three tiles (algo 2..4)
 V3_CASES = [
     # B, H, W, Cin, Cout, k, s, p

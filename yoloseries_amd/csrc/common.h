@@ -105,4 +105,10 @@ int yh_pw_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
 int yh_wgp_ok(const yh_wgrad_desc* d);
 int yh_wgp_run(const yh_wgrad_desc* d, yh_stream stream);
 
+// conv_wgs.hip: wave-private 128 x 128 tiles + stream-K for the K-heavy layers behind yh_conv_wgrad (tile_k 129)
+int yh_wgs_ok(const yh_wgrad_desc* d);
+int yh_wgs_tiles(const yh_wgrad_desc* d);
+const char* yh_wgs_name(const yh_wgrad_desc* d);
+int yh_wgs_run(const yh_wgrad_desc* d, yh_stream stream);
+
 static inline bool yh_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -432,6 +432,9 @@ extern "C" const char* yh_conv_wgrad_kernel_name2(int N, int Kseg, int tile_k)
 extern "C" const char* yh_conv_wgrad_kernel_name(int N, int Kseg) { return yh_conv_wgrad_kernel_name2(N, Kseg, 0); }
 /* 1 if the patch form (tile_k 40, conv_wgp_kernel) applies to this descriptor */
 extern "C" int yh_conv_wgrad_patch_ok(const yh_wgrad_desc* d) { return d ? yh_wgp_ok(d) : 0; }
+/* tile_k 129 (conv_wgs_kernel): number of 128 x 128 tiles of the layer, 0 when the form does not apply; its profiler name */
+extern "C" int yh_conv_wgrad_wave_tiles(const yh_wgrad_desc* d) { return d ? yh_wgs_tiles(d) : 0; }
+extern "C" const char* yh_conv_wgrad_wave_name(const yh_wgrad_desc* d) { return d ? yh_wgs_name(d) : ""; }
 
 /* tile the kernel will use for a layer: rows (out channels) x im2col columns per block; used by the host to size `splits` */
 extern "C" int yh_conv_wgrad_tiles2(int N, int Kseg, int tile_k)
@@ -479,6 +482,7 @@ extern "C" int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream)
     const unsigned long x_img = (unsigned long)(d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups) * d->seg.ld * 2;
     const unsigned long lim = (1ul << 31) - 4096;
     if (d->partial) YH_CHECK_ARG(yh_aligned16(d->partial) && d->partial_bytes >= yh_conv_wgrad_ws_bytes(d), "yh_conv_wgrad: workspace too small / unaligned");
+    if (d->tile_k == 129 && yh_wgs_ok(d)) return yh_wgs_run(d, stream);   // wave-private tiles + stream-K (conv_wgs.hip), else the forms below
     if (d->tile_k == 40 && yh_wgp_ok(d)) {          // patch form (conv_wgp.hip) where it is eligible, else the im2col form below
         YH_CHECK_ARG(d->gy && yh_aligned16(d->gy) && d->ldg % 8 == 0 && d->seg.ptr && yh_aligned16(d->seg.ptr) && d->seg.ld % 8 == 0 && d->dw &&
                      d->coff_k % 8 == 0 && d->coff_k + d->seg.C <= d->Ctot, "yh_conv_wgrad: bad operands");

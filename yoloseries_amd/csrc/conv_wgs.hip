@@ -1,0 +1,384 @@
+// Weight gradient of the NHWC bf16 convolution for the K-heavy layers (>= 128 input channels per tap), gfx950:
+//
+//   dW[n][tap*Ctot + coff_k + c] += sum_m gy[m][n] * X[pixel(m, tap)][c]          (the GEMM gy^T (N x M) * im2col(X) (M x K))
+//
+// Structure (yh_wgrad_desc.tile_k == 129; round 4):
+//   * ONE workgroup of four waves per CU, one wave per SIMD with the whole 512-register file: every wave owns a complete
+//     128 x 128 fp32 output tile (256 accumulator registers) over ITS OWN range of pixels, so the waves share nothing in the
+//     main loop and there is NO workgroup barrier in it;
+//   * every wave feeds a private ring of four LDS stages (16 pixels each: gy [16][128] | X [16][128], 8 KB) by LDS-DMA
+//     (buffer_load ... lds, 1 KiB per instruction) and waits only on its own counted vmcnt: three stages stay in flight;
+//   * both MFMA operands have the reduction index (pixel) as their slow LDS axis: fragments come from ds_read_b64_tr_b16
+//     (transposing read), ONE read per v_mfma_f32_32x32x16_bf16 (16 reads feed 16 MFMAs), requested one k-step ahead;
+//     the LDS rows are unpadded (DMA writes lane * 16 B), bank conflicts are avoided by an XOR of the 16-byte chunk index
+//     with (pixel & 3) << 2 applied on the SOURCE side of the DMA and again on the reads;
+//   * the im2col address of a pixel row is computed by ONE lane per row and handed to the 16 lanes of the row by a DPP
+//     quad broadcast (a row's 16 chunks differ by a lane constant);
+//   * stream-K: the (tile, 32 pixels) units of the layer are dealt evenly to the workgroups (a workgroup may end one
+//     tile and begin the next), so 144 tiles on 256 CUs cost 0.56 tile-times, not one;
+//   * the four partial tiles of a workgroup are combined through LDS (reduce-scatter in two exchange rounds of plain 16-byte
+//     stores / loads, every wave ends with one quarter) and leave as ONE set of fp32 atomics per workgroup and tile: half the
+//     adds of two independent blocks per CU.
+// Replaces autograd's conv weight gradient (train_yolov5.py:337 -> utils/layer_tools.py:82-94).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short v4s;
+typedef __attribute__((ext_vector_type(8))) short v8s;
+
+constexpr int WGS_STG = 4;                           // ring stages per wave
+constexpr int WGS_STAGE = 8192;                      // bytes per stage: A [16 px][128 ch] | B [16 px][128 cols]
+constexpr int WGS_WAVE_LDS = WGS_STG * WGS_STAGE;    // 32 KB per wave
+constexpr int WGS_LDS = 4 * WGS_WAVE_LDS;            // 128 KB per workgroup
+constexpr unsigned WGS_OOB = 0x80000000u;
+
+struct WgsK {
+    yh_wgrad_desc d;
+    unsigned long long* stamps;   // diagnostics (yh_wgs_set_stamps): [workgroup][wave][8] shader-clock stamps of the first segment
+    int Ktot;          // columns of a dw row
+    int nk;            // 32-pixel work units of the layer (M / 32); a unit is two 16-pixel steps
+    int nct, cpt, T;   // column tiles per n-tile, column tiles per tap, tiles
+    int G, S;          // virtual workgroups; S > 0: exact T x S grid (XCD-aware block map)
+    long U;            // T * nk work units
+    unsigned gybytes, xbytes;
+};
+
+__device__ __forceinline__ v4s wgs_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
+}
+// fragment of 32 channels x 16 pixels: pixels 8h .. 8h+3 and 8h+4 .. 8h+7 of the lane's channel
+__device__ __forceinline__ bf16x8_t wgs_frag(const unsigned char* p) {
+    const v4s lo = wgs_tr(p);
+    const v4s hi = wgs_tr(p + 4 * 256);
+    const v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+template <int I> __device__ __forceinline__ unsigned wgs_quad(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, I * 0x55, 0xf, 0xf, false);
+}
+// One LDS-DMA wave instruction, 64 lanes x 16 bytes -> LDS bytes [lds, lds + 1024), as inline asm: the compiler then neither
+// counts it in its s_waitcnt bookkeeping nor treats it as an LDS write (behind the builtin form it drains vmcnt to 0 in front
+// of EVERY LDS read: SIInsertWaitcnts cannot tell the slots of the ring apart).  The waits for these transfers are the
+// hand-counted YH_VMCNT() of the main loop; soff is excluded from the descriptor's range check, voff is not (0x80000000: zeros).
+__device__ __forceinline__ void wgs_dma(unsigned lds, unsigned voff, const __amdgpu_buffer_rsrc_t rs, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
+// PW: 1x1 / stride 1 / pad 0 layer on a plain segment (the im2col row IS the pixel's row: scalar walk)
+template <bool PW>
+__global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const yh_wgrad_desc& d = p.d;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* const wbase = smem + wave * WGS_WAVE_LDS;
+
+    // virtual workgroup.  Workgroups are dealt round-robin to the 8 XCDs by linear id, ONE per CU: XCD x (ids x, x + 8, ...) takes
+    // a contiguous range of the split-major order (split s, tile t) of an exact T x S grid, so the T tiles of a pixel split
+    // (which read the same gy / X rows) run on one XCD at the same time and share its L2, and no XCD gets more workgroups than
+    // CUs.  Stream-K grids keep the identity map (workgroups 16 apart cover the same pixels of tiles that share an operand).
+    int v = blockIdx.x;
+    if (p.S > 0) {
+        const int b = blockIdx.x, x = b & 7, q = p.G >> 3, r = p.G & 7;
+        const int vsm = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        const int s = vsm / p.T;
+        v = (vsm - s * p.T) * p.S + s;
+    }
+    const long u0 = p.U * v / p.G, u1 = p.U * (v + 1) / p.G;
+
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)d.gy, 0, p.gybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg.ptr, 0, p.xbytes, 0x00020000);
+
+    // loader geometry: a transfer fills 4 pixel rows x 256 B; this lane's row inside it, its chunk position inside the LDS
+    // row and the source chunk that position holds
+    const int lrow = lane >> 4;
+    const int srcch = (lane & 15) ^ ((lrow & 3) << 2);
+    // fragment reads: lane 4q+pp of a 16-lane group supplies row q, columns 4pp .. 4pp+3 of the group's 4 x 16 block
+    const int g16 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int rdc = (8 * (g16 >> 1) + q) * 256 + ((g16 & 1) << 5) + ((pp >> 1) << 4) + ((pp & 1) << 3);
+    // Physical accumulator [i][j] of wave w holds the logical sub-tile (x, y) = (i ^ 2 hx, j ^ 2 hy), hx = w & 1, hy = w >> 1 (a
+    // permutation of the fragment read addresses, free): the quarter a wave keeps in the combine is then ALWAYS the physical
+    // [0..1][0..1] and what it gives away [2..3][*] and [0..1][2..3] — the exchange below is straight-line code for every wave.
+    const int hx = wave & 1, hy = wave >> 1;
+    int rdA[4], rdB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rdA[i] = rdc + (((i ^ (hx << 1)) ^ q) << 6);
+        rdB[i] = rdc + (((i ^ (hy << 1)) ^ q) << 6) + 4096;
+    }
+
+    const int ups = d.seg.ups;
+    const int Hs = d.Hi >> ups, Ws = d.Wi >> ups;
+    const int HoWo = d.Ho * d.Wo;
+    const int stepH = 16 / d.Wo, stepW = 16 - stepH * d.Wo;
+    const unsigned pixb = (unsigned)(d.seg.ld * 2);
+    const int sshift = d.stride - 1;
+
+#define WGS_STAMP(I) do { if (p.stamps && first && lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + (I)] = __builtin_amdgcn_s_memtime(); } while (0)
+    bool first = true;
+    long u = u0;
+    while (u < u1) {
+        WGS_STAMP(0);
+        // ---- segment: tile t, units [ka, kb)
+        const int t = (int)(u / p.nk);
+        const int ka = (int)(u - (long)t * p.nk);
+        const long left = u1 - u;
+        const int kb = (left < (long)(p.nk - ka)) ? ka + (int)left : p.nk;
+        u += kb - ka;
+        const int ntile = t / p.nct, ctile = t - ntile * p.nct;
+        const int n0 = ntile * 128;
+        const int tap = ctile / p.cpt;
+        const int c0 = (ctile - tap * p.cpt) * 128;
+        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        // this wave's share of the segment
+        const int ns = kb - ka, nsb = ns >> 2, nsr = ns & 3;
+        const int k0 = 2 * (ka + wave * nsb + (wave < nsr ? wave : nsr));      // in 16-pixel steps
+        const int k1 = k0 + 2 * (nsb + (wave < nsr ? 1 : 0));
+
+        unsigned voffA[4], voffB[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            voffA[i] = (n0 + srcch * 8 < d.N) ? (unsigned)(((4 * i + lrow) * d.ldg + n0 + srcch * 8) * 2) : WGS_OOB;
+            voffB[i] = (unsigned)(((4 * i + lrow) * d.seg.ld + c0 + srcch * 8) * 2);
+        }
+        const unsigned chunkB = (unsigned)((c0 + srcch * 8) * 2);
+        // the pixel of the row this lane OWNS (row lrow + 4 * (lane & 3): the quad's lane i owns the row of transfer i)
+        int pim = 0, pho = 0, pwo = 0;
+        if (!PW && k0 < k1) {
+            const int m = 16 * k0 + lrow + 4 * (lane & 3);
+            pim = m / HoWo;
+            const int rem = m - pim * HoWo;
+            pho = rem / d.Wo;
+            pwo = rem - pho * d.Wo;
+        }
+
+        f32x16_t acc[4][4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+
+        // The im2col offset of the owned row for the stage about to be issued, then the walk to the next stage (16 pixels on:
+        // at most one row wrap and one image wrap, Ho * Wo >= 16).  `oob` (scalar) turns a stage past the wave's range into a dummy.
+        unsigned boff = 0;
+        auto b_addr = [&](unsigned oob) {
+            const int hi = (pho << sshift) - d.pad + kh, wi = (pwo << sshift) - d.pad + kw;
+            const bool ok = (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+            const unsigned pix = (unsigned)__umul24((unsigned)__umul24(pim, Hs) + (unsigned)(hi >> ups), Ws) + (unsigned)(wi >> ups);
+            // a pixel outside the image (its pix is garbage) or a dummy stage: bit 31 puts the offset past the descriptor's range
+            boff = (pix * pixb) | (ok ? 0u : WGS_OOB) | oob;
+            pwo += stepW; pho += stepH;
+            const bool cw = pwo >= d.Wo;
+            pwo -= cw ? d.Wo : 0; pho += cw ? 1 : 0;
+            const bool ch = pho >= d.Ho;
+            pho -= ch ? d.Ho : 0; pim += ch ? 1 : 0;
+        };
+        // transfer i (0..3: gy rows 4i .. 4i+3, 4..7: X rows) of stage s into the slot at LDS address la
+#define WGS_DMA_A(I, LA, SA, OOB_) wgs_dma(LA + (I) * 1024, voffA[I] | (OOB_), rsg, SA)
+#define WGS_DMA_B(I, LA, SB, OOB_)                                                          \
+        do {                                                                                 \
+            if (PW) wgs_dma(LA + 4096 + (I) * 1024, voffB[I] | (OOB_), rsx, SB);             \
+            else    wgs_dma(LA + 4096 + (I) * 1024, wgs_quad<I>(boff) + chunkB, rsx, 0);     \
+        } while (0)
+        // A wave's range is a whole number of 32-pixel units, i.e. an even number of steps: the loop body is two steps with the
+        // fragment sets named statically (no runtime-indexed register arrays) and nothing conditional touches the accumulators.
+        // Step K multiplies the fragments of stage K (in registers), requests those of stage K+1 and refills the slot of stage K
+        // with stage K+4 (a dummy of out-of-range offsets past the wave's range: every step issues 8 transfers and every wait is
+        // the same counted vmcnt).  The body is ONE basic block cut into 8 groups of {2 MFMA, 1 fragment = 2 transposing reads,
+        // 1 transfer} by scheduling fences: the issue order in the binary is the order written here.
+        bf16x8_t fa0[4], fb0[4], fa1[4], fb1[4];
+        if (k0 < k1) {
+            const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)wbase);
+#pragma unroll
+            for (int s = 0; s < WGS_STG; ++s) {
+                const unsigned oob = (k0 + s < k1) ? 0u : WGS_OOB;
+                const unsigned la = lbase + s * WGS_STAGE;
+                const int sa = (k0 + s) * 16 * d.ldg * 2, sb = (k0 + s) * 16 * d.seg.ld * 2;
+                if (!PW) b_addr(oob);
+                WGS_DMA_A(0, la, sa, oob); WGS_DMA_A(1, la, sa, oob); WGS_DMA_A(2, la, sa, oob); WGS_DMA_A(3, la, sa, oob);
+                WGS_DMA_B(0, la, sb, oob); WGS_DMA_B(1, la, sb, oob); WGS_DMA_B(2, la, sb, oob); WGS_DMA_B(3, la, sb, oob);
+            }
+            YH_VMCNT(24);
+            WGS_STAMP(1);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { fa0[x] = wgs_frag(wbase + rdA[x]); fb0[x] = wgs_frag(wbase + rdB[x]); }
+            int slot = 0;
+#define WGS_MM(CA, CB, I) acc[(I) >> 2][(I) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(CA[(I) >> 2], CB[(I) & 3], acc[(I) >> 2][(I) & 3], 0, 0, 0)
+#define WGS_STEP(K, CA, CB, NA_, NB_)                                                            \
+            {                                                                                    \
+                YH_VMCNT(16);                                  /* stage K+1 has landed */        \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* stage K is in registers: its slot is free */ \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                const int s4 = (K) + WGS_STG;                                                    \
+                const unsigned oob = s4 < k1 ? 0u : WGS_OOB;                                     \
+                const unsigned la = lbase + slot * WGS_STAGE;                                    \
+                const int sa = s4 * 16 * d.ldg * 2, sb = s4 * 16 * d.seg.ld * 2;                 \
+                slot = (slot + 1) & (WGS_STG - 1);                                               \
+                const unsigned char* const rb = wbase + slot * WGS_STAGE;                        \
+                WGS_MM(CA, CB, 0); WGS_MM(CA, CB, 1); NA_[0] = wgs_frag(rb + rdA[0]);          WGS_DMA_A(0, la, sa, oob); if (!PW) b_addr(oob); \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                WGS_MM(CA, CB, 2); WGS_MM(CA, CB, 3); NB_[0] = wgs_frag(rb + rdB[0]);   WGS_DMA_A(1, la, sa, oob); \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                WGS_MM(CA, CB, 4); WGS_MM(CA, CB, 5); NA_[1] = wgs_frag(rb + rdA[1]);          WGS_DMA_A(2, la, sa, oob); \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                WGS_MM(CA, CB, 6); WGS_MM(CA, CB, 7); NB_[1] = wgs_frag(rb + rdB[1]);   WGS_DMA_A(3, la, sa, oob); \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                WGS_MM(CA, CB, 8); WGS_MM(CA, CB, 9); NA_[2] = wgs_frag(rb + rdA[2]);          WGS_DMA_B(0, la, sb, oob); \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                WGS_MM(CA, CB, 10); WGS_MM(CA, CB, 11); NB_[2] = wgs_frag(rb + rdB[2]); WGS_DMA_B(1, la, sb, oob); \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                WGS_MM(CA, CB, 12); WGS_MM(CA, CB, 13); NA_[3] = wgs_frag(rb + rdA[3]);        WGS_DMA_B(2, la, sb, oob); \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+                WGS_MM(CA, CB, 14); WGS_MM(CA, CB, 15); NB_[3] = wgs_frag(rb + rdB[3]); WGS_DMA_B(3, la, sb, oob); \
+                __builtin_amdgcn_sched_barrier(0);                                               \
+            }
+            for (int k = k0; k < k1; k += 2) {
+                WGS_STEP(k, fa0, fb0, fa1, fb1)
+                WGS_STEP(k + 1, fa1, fb1, fa0, fb0)
+            }
+#undef WGS_STEP
+#undef WGS_MM
+            YH_VMCNT(0);       // the dummies behind the last stage
+        }
+#undef WGS_DMA_A
+#undef WGS_DMA_B
+
+        // ---- combine the four partial tiles through LDS, reduce-scatter in two rounds of plain 16-byte stores / loads (LDS float
+        // atomics serialise per lane: 150 000 cycles for this exchange).  Round 1: waves w and w^1 split the tile over x (n):
+        // each stores the half it gives away into its own ring (32 KB: nothing of it is in flight) and adds the partner's copy of
+        // the half it keeps; round 2: w and w^2 split what is left over y (columns).  The kept data is acc[0..1][0..1] in every wave.
+        // Every sub-tile is fenced for the scheduler: at most 16 loaded values are live at a time.
+        float4* const mine = reinterpret_cast<float4*>(wbase) + lane;
+        const float4* const px = reinterpret_cast<const float4*>(smem + (wave ^ 1) * WGS_WAVE_LDS) + lane;
+        const float4* const py = reinterpret_cast<const float4*>(smem + (wave ^ 2) * WGS_WAVE_LDS) + lane;
+        auto put = [&](int sidx, const f32x16_t& a) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) mine[(sidx * 4 + r4) * 64] = make_float4(a[4 * r4], a[4 * r4 + 1], a[4 * r4 + 2], a[4 * r4 + 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto add = [&](const float4* from, int sidx, f32x16_t& a) {
+            float4 o[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) o[r4] = from[(sidx * 4 + r4) * 64];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) { a[4 * r4] += o[r4].x; a[4 * r4 + 1] += o[r4].y; a[4 * r4 + 2] += o[r4].z; a[4 * r4 + 3] += o[r4].w; }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        WGS_STAMP(2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) put(i, acc[2 + (i >> 2)][i & 3]);
+        __syncthreads();
+        WGS_STAMP(3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) add(px, i, acc[i >> 2][i & 3]);
+        __syncthreads();       // the partner has read my round-1 bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) put(i, acc[i >> 1][2 + (i & 1)]);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) add(py, i, acc[i >> 1][i & 1]);
+        WGS_STAMP(4);
+
+        // ---- this wave's quarter (x = 2 hx + xx, y = 2 hy + yy) -> dw.  C[n][col]: the lane holds column lane & 31, register r
+        // holds row (r & 3) + 8 (r >> 2) + 4 (lane >> 5): one wave instruction adds two 128-byte row segments
+        float* const dwb = d.dw + (size_t)tap * d.Ctot + d.coff_k + c0 + 64 * hy + (lane & 31);
+#pragma unroll
+        for (int xx = 0; xx < 2; ++xx) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 64 * hx + 32 * xx + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < d.N) {
+                    float* const row = dwb + (size_t)n * p.Ktot;
+                    atomicAdd(row, acc[xx][0][r]);
+                    atomicAdd(row + 32, acc[xx][1][r]);
+                }
+            }
+        }
+        WGS_STAMP(5);
+        if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        WGS_STAMP(6);
+        __syncthreads();       // the partner has read my round-2 bytes: the areas are rings again
+        first = false;
+    }
+}
+
+// eligibility of the layer and the launch plan shared by the queries and the launcher
+struct WgsPlan { long M; int nk, ntn, nct, cpt, T, G, S, grid; bool pw; };
+
+bool wgs_plan(const yh_wgrad_desc* d, WgsPlan* pl)
+{
+    if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->N < 64 || d->KH <= 0 || d->KW <= 0) return false;
+    if (d->KH > 7 || d->KW > 7 || (d->stride != 1 && d->stride != 2) || d->pad < 0) return false;
+    if (d->seg.C <= 0 || d->seg.C % 128 != 0 || d->seg.ld % 8 != 0 || d->ldg % 8 != 0 || d->ldg < (d->N + 7) / 8 * 8) return false;
+    if (d->bn_z || d->partial) return false;
+    if ((d->Hi + 2 * d->pad - d->KH) / d->stride + 1 != d->Ho || (d->Wi + 2 * d->pad - d->KW) / d->stride + 1 != d->Wo) return false;
+    if (d->seg.ups && (d->Hi % 2 || d->Wi % 2)) return false;
+    const long M = (long)d->B * d->Ho * d->Wo;
+    if (M % 32 != 0 || M >= (1L << 31) - 256 || d->Ho * d->Wo < 16) return false;
+    const unsigned long gyb = ((unsigned long)(M - 1) * d->ldg + (d->N + 7) / 8 * 8) * 2;
+    const unsigned long npix = (unsigned long)d->B * (d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups);
+    const unsigned long xb = ((npix - 1) * d->seg.ld + d->seg.C) * 2;
+    if (gyb >= (1ul << 31) - 4096 || xb >= (1ul << 31) - 4096) return false;
+    pl->M = M;
+    pl->nk = (int)(M / 32);
+    pl->ntn = (d->N + 127) / 128;
+    pl->cpt = d->seg.C / 128;
+    pl->nct = d->KH * d->KW * pl->cpt;
+    pl->T = pl->ntn * pl->nct;
+    pl->pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->seg.ups;
+    int G = d->splits < 1 ? 1 : (d->splits > 4096 ? 4096 : d->splits);
+    const long U = (long)pl->T * pl->nk;
+    if ((long)G > U) G = (int)U;
+    pl->G = G;
+    pl->S = (G % pl->T == 0) ? G / pl->T : 0;
+    pl->grid = G;
+    return true;
+}
+
+}  // namespace
+
+static unsigned long long* g_wgs_stamps = nullptr;
+/* diagnostics: a device buffer of grid x 4 x 8 uint64 that receives shader-clock stamps of every wave's first segment (NULL: off) */
+extern "C" void yh_wgs_set_stamps(void* p) { g_wgs_stamps = (unsigned long long*)p; }
+
+int yh_wgs_ok(const yh_wgrad_desc* d) { WgsPlan pl; return wgs_plan(d, &pl) ? 1 : 0; }
+/* tiles (128 out channels x 128 im2col columns) of the layer: workgroups = `splits` are dealt (tile, 32 pixels) units */
+int yh_wgs_tiles(const yh_wgrad_desc* d) { WgsPlan pl; return wgs_plan(d, &pl) ? pl.T : 0; }
+const char* yh_wgs_name(const yh_wgrad_desc* d)
+{
+    WgsPlan pl;
+    if (!wgs_plan(d, &pl)) return "";
+    return pl.pw ? "conv_wgs_kernel<true>" : "conv_wgs_kernel<false>";
+}
+
+int yh_wgs_run(const yh_wgrad_desc* d, yh_stream stream)
+{
+    WgsPlan pl;
+    YH_CHECK_ARG(wgs_plan(d, &pl), "yh_conv_wgrad(tile_k 129): layer not eligible");
+    YH_CHECK_ARG(d->gy && yh_aligned16(d->gy) && d->seg.ptr && yh_aligned16(d->seg.ptr) && d->dw, "yh_conv_wgrad(tile_k 129): bad operands");
+    YH_CHECK_ARG(d->coff_k % 8 == 0 && d->coff_k + d->seg.C <= d->Ctot, "yh_conv_wgrad(tile_k 129): bad channel offset");
+    WgsK k;
+    k.d = *d;
+    k.stamps = g_wgs_stamps;
+    k.Ktot = d->KH * d->KW * d->Ctot;
+    k.nk = pl.nk; k.nct = pl.nct; k.cpt = pl.cpt; k.T = pl.T; k.G = pl.G; k.S = pl.S;
+    k.U = (long)pl.T * pl.nk;
+    k.gybytes = (unsigned)(((unsigned long)(pl.M - 1) * d->ldg + (d->N + 7) / 8 * 8) * 2);
+    const unsigned long npix = (unsigned long)d->B * (d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups);
+    k.xbytes = (unsigned)(((npix - 1) * d->seg.ld + d->seg.C) * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wgs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
+        (void)hipFuncSetAttribute((const void*)conv_wgs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (pl.pw) conv_wgs_kernel<true><<<dim3(pl.grid), dim3(256), WGS_LDS, st>>>(k);
+    else       conv_wgs_kernel<false><<<dim3(pl.grid), dim3(256), WGS_LDS, st>>>(k);
+    YH_CHECK_LAUNCH("yh_conv_wgrad(tile_k 129)");
+    return YH_OK;
+}

@@ -154,7 +154,7 @@ _WGRAD_TK64 = {
 # version prefixes of the tuning-table keys: bumped when the candidates or the meaning of a tuned value change, so that stale
 # entries of a shipped / cached table are not applied.  Stride-2 data gradients carry their own version (conv_dg2_kernel, algo 7,
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
-KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad9", "wgrad8"
+KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad10", "wgrad8"
 TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
 # YH_SKIP_ALGOS=<n>[,<n>]: leave these kernel families (yh_conv_desc.algo) out of the per-layer timing — A/B runs of a new family on
@@ -1356,9 +1356,16 @@ class Program:
         wd.tile_k = 40
         if not wd.partial and self.L.yh_conv_wgrad_patch_ok(C.byref(wd)):
             tks = tks + (40,)               # patch form (conv_wgp_kernel): the input patch of a pixel region staged once in LDS
+        wtiles = 0 if (wd.partial or wd.bn_z or os.environ.get("YH_WGRAD_WAVE", "1") == "0") else self.L.yh_conv_wgrad_wave_tiles(C.byref(wd))
+        if wtiles > 0:
+            tks = tks + (129,)              # wave-private 128 x 128 tiles + stream-K (conv_wgs_kernel): `splits` = workgroups, one per CU
         for tk in tks:
             wd.tile_k = tk
-            for sp in ([1024] if tk == 40 else sorted({splits_for(t, tk) for t in (256, 512, 768, 1024, 1536)})):
+            if tk == 129:                   # an exact tiles x splits grid where it fills the chip, else 256 workgroups dealt (tile, 32 pixels) units
+                sps = sorted({256} | ({wtiles * (256 // wtiles)} if wtiles <= 256 else set()))
+            else:
+                sps = [1024] if tk == 40 else sorted({splits_for(t, tk) for t in (256, 512, 768, 1024, 1536)})
+            for sp in sps:
                 wd.splits = sp
                 if wd.partial and self.L.yh_conv_wgrad_ws_bytes(C.byref(wd)) > wd.partial_bytes:
                     continue                   # more partial tiles than the workspace holds
@@ -1387,6 +1394,8 @@ class Program:
             name = _WGRAD_TK64.get(name, name)
         if wd.bn_z:                        # last template argument: BatchNorm backward fused into the operand loader
             name = name[:-len(", false>")] + ", true>"
+        if wd.tile_k == 129 and L.yh_conv_wgrad_wave_tiles(C.byref(wd)) > 0:
+            return L.yh_conv_wgrad_wave_name(C.byref(wd)).decode()
         if wd.tile_k == 40 and L.yh_conv_wgrad_patch_ok(C.byref(wd)):
             buf = C.create_string_buffer(64)
             L.yh_conv_wgrad_patch_name(C.byref(wd), buf, 64)
