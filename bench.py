@@ -126,6 +126,26 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def visible_gpus():
+    """GPUs this process may use, WITHOUT touching the HIP runtime (torch.cuda.device_count() can fall back to hipGetDeviceCount,
+    which initialises it in the launcher parent): the visibility variables if set, else the KFD topology (a GPU node has a non-zero
+    simd_count).  None when neither says anything: every rank then checks its own device (worker())."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     """`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself, the way the reference's
     driver does (train_yolov5.py:858-870 -> utils/launch.py:39-110), BEFORE anything here touches the GPU — the parent only
@@ -141,8 +161,8 @@ def main():
         return worker(args)
     if args.gpus == 1:
         return worker(args)
-    ndev = torch.cuda.device_count()                          # counting devices does not initialise HIP
-    if backend == "nccl" and args.gpus > ndev:
+    ndev = visible_gpus()                                     # from the environment / sysfs: the parent never calls into HIP
+    if backend == "nccl" and ndev is not None and args.gpus > ndev:
         sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible (one rank per GPU over RCCL)")
     from yoloseries_amd.utils.launch import launch
     launch(worker, args.gpus, num_machines=1, machine_rank=0, backend=backend, dist_url="auto", args=(args,))
@@ -485,6 +505,8 @@ def _limiter(name, f_mfma, f_hbm, traffic, algo_bytes):
     """what binds a kernel family that sits under 30 % of BOTH roofs (measured in DESIGN.md section 5, not inferred here)"""
     if max(f_mfma, f_hbm) >= 0.3:
         return "mfma" if f_mfma >= f_hbm else "hbm"
+    if name.startswith("conv_wgs"):
+        return "LDS-DMA feed (512 B per MFMA through the CU's vector memory path: the loop is issue-bound at ~62 % of the MFMA rate) + one 64 KB tile of fp32 atomics per workgroup"
     if name.startswith("conv_wgrad"):
         return "split-M epilogue: fp32 atomics / partial tiles per block (work per block too small to amortise a 64 KB tile)"
     if name.startswith(("yh_bn_finalize", "yh_bn_bwd_finalize", "yh_colsum")):
@@ -511,6 +533,43 @@ def _family_roofline(name, d, pmc, pmc_mfma=None):
     if f_mfma >= f_hbm:
         return {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f_mfma, 4), **common}
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_hbm, 4), **common}
+
+
+def _group_of(name):
+    """the five groups of the step's engine kernels (VERDICT r03 #7: the per-template `dominant kernel` hides the largest group)"""
+    if name.startswith(("conv_wgrad", "conv_wgs", "conv_wgp")):
+        return "wgrad"
+    if name.startswith("conv_"):
+        return "conv"                                   # forward convolutions and data gradients
+    if name.startswith(("yh_bn_finalize", "yh_bn_bwd_finalize", "yh_bn_frozen")):
+        return "finalize"
+    if name.startswith(("yh_bn_silu", "yh_bn_")):
+        return "bn_silu"
+    return "other"                                      # pools, upsample backward, column sums, input conversion
+
+
+def _groups(fam, nsteps, pmc):
+    """per group: time, launches, aggregate TFLOP/s and GB/s on the ALGORITHMIC work (the same flops / bytes the per-family
+    entries use), the fractions of both roofs, and PMC HBM traffic over algorithmic bytes where the committed counter file covers
+    the group's kernels (`traffic_coverage` = share of the group's launches it covers)"""
+    out = {}
+    for name, v in fam.items():
+        g = out.setdefault(_group_of(name), {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "traffic": 0.0, "tbytes": 0.0, "tl": 0})
+        g["ms"] += v["ms"]; g["launches"] += v["launches"]; g["flops"] += v["flops"]; g["bytes"] += v["bytes"]
+        t = _pmc_bytes(pmc, name)
+        if t is not None and v["launches"] > 0:
+            g["traffic"] += t * v["launches"]; g["tbytes"] += v["bytes"]; g["tl"] += v["launches"]
+    res = {}
+    for k, g in sorted(out.items(), key=lambda kv: -kv[1]["ms"]):
+        sec = g["ms"] * 1e-3
+        if sec <= 0:
+            continue
+        tf, gbs = g["flops"] / sec / 1e12, g["bytes"] / sec / 1e9
+        res[k] = {"ms_per_step": round(g["ms"] / nsteps, 3), "launches_per_step": g["launches"] // nsteps,
+                  "tflops": round(tf, 1), "gbs": round(gbs, 1), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 4), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                  "traffic_over_algorithmic": round(g["traffic"] / g["tbytes"], 3) if g["tbytes"] > 0 else None,
+                  "traffic_coverage": round(g["tl"] / g["launches"], 3) if g["launches"] else None}
+    return res
 
 
 def measure_roofline(model, step, B, nsteps=3):
@@ -565,6 +624,7 @@ def measure_roofline(model, step, B, nsteps=3):
     roof["hbm_bytes_per_step"] = round(pmc["hbm_bytes_per_step"]) if pmc is not None and pmc.get("hbm_bytes_per_step") else None
     roof["mfma_util_step"] = pmc_mfma.get("mfma_util_all_kernels") if pmc_mfma else None
     roof["family_ms_per_step"] = {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+    roof["groups"] = _groups(fam, nsteps, pmc)
     roof["engine_kernel_ms_per_step"] = round(total_ms, 3)
     return roof
 

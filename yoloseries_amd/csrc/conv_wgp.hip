@@ -317,8 +317,6 @@ bool wgp_plan(const yh_wgrad_desc* d, WgpPlan* pl)
 
 }  // namespace
 
-int yh_wgp_ok(const yh_wgrad_desc* d) { WgpPlan pl; return wgp_plan(d, &pl) ? 1 : 0; }
-
 // instantiation table shared by the launcher and the name query: (accumulator tiles per wave, gy chunks, patch chunks per thread)
 // (waves, accumulator tiles per wave, gy chunks, patch chunks per thread)
 static const int kWgpInst[7][4] = {{5, 1, 4, 3}, {5, 2, 7, 3}, {4, 1, 8, 8}, {4, 3, 4, 6}, {4, 5, 4, 10}, {4, 5, 8, 11}, {8, 5, 4, 6}};
@@ -328,6 +326,9 @@ static int wgp_pick(const WgpPlan& pl)
         if (pl.nw == kWgpInst[i][0] && pl.tpw <= kWgpInst[i][1] && pl.ngi <= kWgpInst[i][2] && pl.nxi <= kWgpInst[i][3]) return i;
     return -1;
 }
+// eligibility == a plan AND an instantiation for it: the query, the name query and the launcher agree (C = 16 / stride 2 has a plan
+// but no instance: yh_conv_wgrad then takes the im2col form instead of failing)
+int yh_wgp_ok(const yh_wgrad_desc* d) { WgpPlan pl; return (wgp_plan(d, &pl) && wgp_pick(pl) >= 0) ? 1 : 0; }
 
 /* profiler spelling of the instantiation the patch form launches for this descriptor ("" when it does not apply) */
 extern "C" int yh_conv_wgrad_patch_name(const yh_wgrad_desc* d, char* buf, int buflen)

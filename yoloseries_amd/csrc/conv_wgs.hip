@@ -21,6 +21,7 @@
 //     adds of two independent blocks per CU.
 // Replaces autograd's conv weight gradient (train_yolov5.py:337 -> utils/layer_tools.py:82-94).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -41,7 +42,7 @@ struct WgsK {
     int nct, cpt, T;   // column tiles per n-tile, column tiles per tap, tiles
     int G, S;          // virtual workgroups; S > 0: exact T x S grid (XCD-aware block map)
     long U;            // T * nk work units
-    unsigned gybytes, xbytes;
+    unsigned gybytes, xbytes, dwbytes;
 };
 
 __device__ __forceinline__ v4s wgs_tr(const unsigned char* p) {
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
 
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)d.gy, 0, p.gybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg.ptr, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)d.dw, 0, p.dwbytes, 0x00020000);
 
     // loader geometry: a transfer fills 4 pixel rows x 256 B; this lane's row inside it, its chunk position inside the LDS
     // row and the source chunk that position holds
@@ -260,12 +262,24 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
             for (int r4 = 0; r4 < 4; ++r4) mine[(sidx * 4 + r4) * 64] = make_float4(a[4 * r4], a[4 * r4 + 1], a[4 * r4 + 2], a[4 * r4 + 3]);
             __builtin_amdgcn_sched_barrier(0);
         };
+        // a += the partner's copy.  The accumulators live in AGPRs and VALU reads none: written as plain C the allocator copies the
+        // whole kept half (128 values) to arch VGPRs at the loop exit, and the kernel's STATIC register allocation — what decides
+        // which other waves may share the SIMD with this one — grows by them.  So the add is spelled out per element:
+        // v_accvgpr_read -> v_add_f32 -> v_accvgpr_write through four temporaries.
         auto add = [&](const float4* from, int sidx, f32x16_t& a) {
-            float4 o[4];
+            float4 ov[4];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) o[r4] = from[(sidx * 4 + r4) * 64];
+            for (int r4 = 0; r4 < 4; ++r4) ov[r4] = from[(sidx * 4 + r4) * 64];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) { a[4 * r4] += o[r4].x; a[4 * r4 + 1] += o[r4].y; a[4 * r4 + 2] += o[r4].z; a[4 * r4 + 3] += o[r4].w; }
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 o = ov[r4];
+                float t0, t1, t2, t3;
+                asm volatile("v_accvgpr_read_b32 %4, %0\n\tv_accvgpr_read_b32 %5, %1\n\tv_accvgpr_read_b32 %6, %2\n\tv_accvgpr_read_b32 %7, %3\n\t"
+                             "v_add_f32 %4, %4, %8\n\tv_add_f32 %5, %5, %9\n\tv_add_f32 %6, %6, %10\n\tv_add_f32 %7, %7, %11\n\t"
+                             "v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
+                             : "+a"(a[4 * r4]), "+a"(a[4 * r4 + 1]), "+a"(a[4 * r4 + 2]), "+a"(a[4 * r4 + 3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                             : "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         WGS_STAMP(2);
@@ -284,17 +298,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
         WGS_STAMP(4);
 
         // ---- this wave's quarter (x = 2 hx + xx, y = 2 hy + yy) -> dw.  C[n][col]: the lane holds column lane & 31, register r
-        // holds row (r & 3) + 8 (r >> 2) + 4 (lane >> 5): one wave instruction adds two 128-byte row segments
-        float* const dwb = d.dw + (size_t)tap * d.Ctot + d.coff_k + c0 + 64 * hy + (lane & 31);
+        // holds row (r & 3) + 8 (r >> 2) + 4 (lane >> 5): one wave instruction adds two 128-byte row segments.  Buffer atomics:
+        // the row walk is a SCALAR offset (no address arithmetic per add, one offset register), rows past N carry an
+        // out-of-range offset instead of an exec mask.
+        {
+            const int nl = n0 + 64 * hx + 4 * (lane >> 5);
+            const unsigned voff = (unsigned)((nl * p.Ktot + tap * d.Ctot + d.coff_k + c0 + 64 * hy + (lane & 31)) * 4);
 #pragma unroll
-        for (int xx = 0; xx < 2; ++xx) {
+            for (int xx = 0; xx < 2; ++xx) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + 64 * hx + 32 * xx + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < d.N) {
-                    float* const row = dwb + (size_t)n * p.Ktot;
-                    atomicAdd(row, acc[xx][0][r]);
-                    atomicAdd(row + 32, acc[xx][1][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = 32 * xx + (r & 3) + 8 * (r >> 2);
+                    const unsigned vo = (nl + ro < d.N) ? voff : WGS_OOB;
+                    const int so = ro * p.Ktot * 4;
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[xx][0][r], rsd, vo, so, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[xx][1][r], rsd, vo, so + 128, 0);
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -323,6 +342,7 @@ bool wgs_plan(const yh_wgrad_desc* d, WgsPlan* pl)
     const unsigned long npix = (unsigned long)d->B * (d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups);
     const unsigned long xb = ((npix - 1) * d->seg.ld + d->seg.C) * 2;
     if (gyb >= (1ul << 31) - 4096 || xb >= (1ul << 31) - 4096) return false;
+    if ((unsigned long)(d->N + 127) * d->KH * d->KW * d->Ctot * 4 >= (1ul << 31)) return false;      // dw is addressed with 32-bit offsets
     pl->M = M;
     pl->nk = (int)(M / 32);
     pl->ntn = (d->N + 127) / 128;
@@ -370,6 +390,12 @@ int yh_wgs_run(const yh_wgrad_desc* d, yh_stream stream)
     k.gybytes = (unsigned)(((unsigned long)(pl.M - 1) * d->ldg + (d->N + 7) / 8 * 8) * 2);
     const unsigned long npix = (unsigned long)d->B * (d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups);
     k.xbytes = (unsigned)(((npix - 1) * d->seg.ld + d->seg.C) * 2);
+    k.dwbytes = (unsigned)((unsigned long)d->N * d->KH * d->KW * d->Ctot * 4);
+    // timing-only diagnostics (results wrong): YH_WGS_ABL bit 0: zero-record operand descriptors (every transfer returns zeros without
+    // touching memory: the loop's issue-bound time), bit 1: zero-record dw descriptor (the atomics are dropped by the range check)
+    static const int abl = [] { const char* e = getenv("YH_WGS_ABL"); return e ? atoi(e) : 0; }();
+    if (abl & 1) k.gybytes = k.xbytes = 0;
+    if (abl & 2) k.dwbytes = 0;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);

@@ -760,6 +760,8 @@ class Program:
             if b.t is None and not getattr(b, "is_head", False):
                 b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=self.dev)
         self.cmd_train = []
+        self.cmd_frozen = None           # derived from cmd_train (evaluation-mode BatchNorm under autograd): rebuilt with it
+        self.cmd_bwd_frozen = None
         self._acc_fwd_elems = 0
         skip = set()
         for oi, op in enumerate(self.ops):
@@ -893,11 +895,16 @@ class Program:
         out = 2.0 * d.B * d.Ho * d.Wo * d.N
         return rd + out * (2.0 if d.accumulate else 1.0) + (out * min(1.0, d.nsplit / max(d.N, 1)) if d.res else 0.0) + (out if d.bnr_part else 0.0)
 
+    def _head_on_side(self, op, two):
+        """does a head layer's bias gradient (column sums of the head gradient) run on the weight-gradient stream?  Only with a
+        scratch of its own: `part_scratch` belongs to the main stream's BatchNorm reductions (a layer wider than `head_scratch` was
+        sized for — it is sized from the widest plain op of the graph, so none today — falls back to the main stream, never to a
+        shared buffer on another stream)"""
+        return bool(two and HEAD_COLSUM_SIDE and op.y.C * 1024 * 2 <= self.head_scratch.numel())
+
     def _head_scratch(self, op, two):
         """partial-sum scratch of a head layer's bias gradient: its own buffer when the column sums run on the side stream"""
-        if two and HEAD_COLSUM_SIDE and op.y.C * 1024 * 2 <= self.head_scratch.numel():
-            return self.head_scratch.data_ptr()
-        return self.part_scratch.data_ptr()
+        return self.head_scratch.data_ptr() if self._head_on_side(op, two) else self.part_scratch.data_ptr()
 
     def _is_fused_stem(self, op):
         """a ConvBnAct without a data gradient (the stem) whose BatchNorm backward apply runs inside its weight gradient (YH_FUSE_STEM_BWD)"""
@@ -1025,7 +1032,8 @@ class Program:
         self.part_scratch = torch.zeros(1024 * 2 * 2048, dtype=torch.float32, device=self.dev)
         # partial sums of the head layers' bias gradients (column sums of the head gradients): these run on the SIDE stream (they feed
         # nothing but the packed gradient arena; the largest takes 76 us on YOLOv5s) and may not share a scratch with the main stream
-        self.head_scratch = torch.zeros(1024 * 2 * 256, dtype=torch.float32, device=self.dev)
+        head_c = max([256] + [op.y.C for op in self.ops if isinstance(op, ConvOp) and op.kind == 'plain'])
+        self.head_scratch = torch.zeros(1024 * 2 * head_c, dtype=torch.float32, device=self.dev)
         self.coef_scratch = {}
         self.ups_scratch = {}
         self.wgrad_tuned = {}
@@ -1362,7 +1370,15 @@ class Program:
         for tk in tks:
             wd.tile_k = tk
             if tk == 129:                   # an exact tiles x splits grid where it fills the chip, else 256 workgroups dealt (tile, 32 pixels) units
-                sps = sorted({256} | ({wtiles * (256 // wtiles)} if wtiles <= 256 else set()))
+                # Workgroups (= CUs: the form holds a whole CU) a weight gradient may take.  Alone on the chip 256 is fastest; in the
+                # two-stream backward the main chain (data gradients, BatchNorm passes) runs beside it and the step is shortest when
+                # the weight gradients leave a quarter of the CUs alone (YOLOv5s 12.20 -> 12.02 ms, YOLOv5l 42.9 -> 42.4 ms: r04
+                # experiments).  Half of that is timed too: on the small layers the atomics (one partial tile per workgroup) dominate.
+                gmax = int(os.environ.get("YH_WGS_G", "192"))
+                sps = set()
+                for g in (gmax, gmax // 2):
+                    sps |= {g} | ({wtiles * (g // wtiles)} if wtiles <= g else set())
+                sps = sorted(sps)
             else:
                 sps = [1024] if tk == 40 else sorted({splits_for(t, tk) for t in (256, 512, 768, 1024, 1536)})
             for sp in sps:
@@ -1473,7 +1489,7 @@ class Program:
                 _, op, boff, _m = cmd
                 if boff is not None:
                     i = cc.call(L.yh_colsum, (0, op.y.C, op.y.C, self.B * op.Ho * op.Wo, self._head_scratch(op, two),
-                                              self.pack.gpack.data_ptr() + 4 * boff), 1 if two and HEAD_COLSUM_SIDE else 0, op.name)
+                                              self.pack.gpack.data_ptr() + 4 * boff), 1 if self._head_on_side(op, two) else 0, op.name)
                     patches.append(('colsum', None, op.name, i))
             elif fn == 'wgrad':
                 _, op, wd, _m = cmd
@@ -1526,7 +1542,8 @@ class Program:
         two = self.two_streams
         if two:
             if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(device=self.dev)
+                # YH_SIDE_PRIO: priority of the weight-gradient stream (ROCm: -1 high, 0 normal, 1 low)
+                self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("YH_SIDE_PRIO", "0")))
                 self._ev_gz = torch.cuda.Event()
                 self._ev_wg = [torch.cuda.Event() for _ in range(NGZ)]
                 self._ev_all = torch.cuda.Event()
@@ -1593,7 +1610,7 @@ class Program:
                         self._ev_wg[cmd[1]].record(side)
                         pending[cmd[1]] = True
                 continue
-            on_side = two and ((fn == 'wgrad' and id(cmd[2]) not in self._wgrad_on_main) or (fn == 'head_colsum' and HEAD_COLSUM_SIDE))
+            on_side = two and ((fn == 'wgrad' and id(cmd[2]) not in self._wgrad_on_main) or (fn == 'head_colsum' and self._head_on_side(cmd[1], two)))
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side if on_side else None)
@@ -1766,6 +1783,13 @@ class HipModuleMixin:
         # a differentiable forward runs the training program (raw conv outputs kept for the backward); in evaluation mode its
         # BatchNorms use the running statistics, exactly as nn.BatchNorm2d.eval() does under autograd
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in pk.params)):
+            if not self.training and not getattr(self, "_yh_warned_eval_grad", False):
+                self.__dict__['_yh_warned_eval_grad'] = True
+                import warnings
+                warnings.warn("yoloseries_amd: model.eval() called with gradients enabled: this runs the TRAINING program with frozen "
+                              "BatchNorm (raw conv outputs kept, no folded inference kernels) and is several times slower and larger "
+                              "than the inference program; wrap evaluation in torch.no_grad() unless the gradients are wanted "
+                              "(INTEGRATION.md, 'Evaluation under autograd')", stacklevel=3)
             return _NetFn.apply(self, prog, x, *pk.params)
         prog.forward(self.training)
         return tuple(self._yh_outputs(prog))
