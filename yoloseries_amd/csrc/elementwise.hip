@@ -805,8 +805,7 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n)
 
 inline int ew_grid(long nthreads) {
     long g = (nthreads + EW_THREADS - 1) / EW_THREADS;
-    static const int bpc = [] { const char* e = getenv("YH_EW_BPC"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
-    if (g > 256 * bpc) g = 256 * bpc;          // 8 blocks of 256 threads per CU: measured against 4 / 6 / 10 / 16 / 32 and 128- / 512-thread blocks on the train step
+    if (g > 256 * 8) g = 256 * 8;          // 8 blocks of 256 threads per CU: measured against 4 / 6 / 10 / 16 / 32 and 128- / 512-thread blocks on the train step
     if (g < 1) g = 1;
     return (int)g;
 }
