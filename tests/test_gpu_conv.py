@@ -366,6 +366,11 @@ WGS_CASES = [
     (2, 8, 8, 128, 128, 3, 1, 128, 384, 0),      # a segment of a concat input: columns [128, 256) of every tap; 8 x 8 map (a stage spans two rows)
     (2, 16, 16, 128, 64, 1, 1, 0, 256, 1),       # segment read through the 2x upsample (not the pointwise walk), half-empty n-tile
     (1, 4, 8, 128, 128, 3, 1, 0, 128, 0),        # ONE work unit: three of the four waves have nothing to do
+    (2, 24, 24, 64, 64, 3, 1, 0, 64, 0),         # 64 channels: a column tile is TWO taps (per-lane taps), the fifth tile is half empty (tap 9)
+    (1, 32, 32, 64, 128, 3, 2, 0, 64, 0),        # YOLOv5s stage-2 conv class (stride 2, 64 -> 128)
+    (2, 16, 16, 96, 160, 3, 1, 0, 96, 0),        # YOLOv5m width: tiles straddle taps at 32-column groups (864 columns: 6.75 tiles)
+    (2, 16, 16, 32, 64, 3, 2, 0, 32, 0),         # 32 channels: four taps per tile
+    (2, 16, 16, 160, 80, 1, 1, 32, 320, 0),      # pointwise on a 160-channel segment of a 320-channel concat (YOLOv5x): second tile a quarter full
 ]
 
 
@@ -392,7 +397,7 @@ def test_conv_wgrad_wave_private_tiles(dev, B, H, W, Cin, Cout, k, s, coff, Ctot
     d = hipk.wgrad_desc(hipk.Slice(gyw, 0, ldg), Cout, hipk.Slice(xw, 16, Cin, ups=ups), coff, Ctot, B, Ho, Wo, H, W, k, s, p, dw, 1)
     d.tile_k = 129
     T = lib().yh_conv_wgrad_wave_tiles(C.byref(d))
-    assert T == ((Cout + 127) // 128) * k * k * (Cin // 128)
+    assert T == ((Cout + 127) // 128) * ((k * k * Cin + 127) // 128)
     d.splits = 3 * T if groups < 0 else groups
     assert lib().yh_conv_wgrad_wave_name(C.byref(d)).decode().startswith("conv_wgs_kernel<")
     hipk.wgrad_launch(d)
@@ -416,7 +421,7 @@ def test_conv_wgrad_wave_private_tiles_eligibility(dev):
     import ctypes as C
     from yoloseries_amd import hipk
     from yoloseries_amd._lib import lib
-    for (B, H, W, Cin, Cout, k) in [(2, 16, 16, 64, 128, 3), (1, 13, 13, 128, 128, 3), (2, 16, 16, 128, 32, 1)]:
+    for (B, H, W, Cin, Cout, k) in [(2, 16, 16, 48, 128, 3), (1, 13, 13, 128, 128, 3), (2, 16, 16, 128, 32, 1)]:
         p = k // 2
         gy = _nhwc(B, H, W, Cout, dev, 22)
         x = _nhwc(B, H, W, Cin, dev, 23)

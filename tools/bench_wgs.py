@@ -17,6 +17,8 @@ shapes = [("s3_b_3x3",      40,  128, 128, 3, 1), ("s4_b_3x3",      20,  256, 25
           ("s3_conv",       80,  128, 256, 3, 2), ("s4_conv",       40,  256, 512, 3, 2),
           ("s3_cba12",      40,  256, 256, 1, 1), ("s4_cba3",       20,  512, 512, 1, 1), ("spp_cba2", 20, 1024, 512, 1, 1),
           ("s3_b_1x1",      40,  128, 128, 1, 1),
+          ("s2_b_3x3",      80,  64,  64,  3, 1), ("s2_conv",       160, 64,  128, 3, 2), ("s1_conv", 320, 32, 64, 3, 2),
+          ("l1_b_3x3",      160, 64,  64,  3, 1), ("l1_conv",       320, 64,  128, 3, 2),
           ("l2_b_3x3",      80,  128, 128, 3, 1), ("l3_b_3x3",      40,  256, 256, 3, 1), ("l4_b_3x3", 20, 512, 512, 3, 1),
           ("l4_conv",       40,  512, 1024, 3, 2), ("l3_cba3",      40,  512, 512, 1, 1), ("l4_cba3", 20, 1024, 1024, 1, 1)]
 if os.environ.get("WG_ONLY"):

@@ -8,6 +8,12 @@ OUT=gpurun_out/tune
 mkdir -p $OUT
 export YH_TUNE_CACHE=$PWD/$OUT/wg_local.json YH_TUNE_ITERS=${YH_TUNE_ITERS:-12}
 rm -f $YH_TUNE_CACHE
+cp yoloseries_amd/tune_defaults.json $OUT/shipped_before.json
+python3 - <<'PY'
+import json
+t = json.load(open("yoloseries_amd/tune_defaults.json"))
+json.dump({k: v for k, v in t.items() if not k.startswith("wgrad")}, open("yoloseries_amd/tune_defaults.json", "w"), indent=0, sort_keys=True)
+PY
 python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 python3 bench.py --workload yolox --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 python3 bench.py --model large --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1

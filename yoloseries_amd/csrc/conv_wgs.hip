@@ -1,4 +1,4 @@
-// Weight gradient of the NHWC bf16 convolution for the K-heavy layers (>= 128 input channels per tap), gfx950:
+// Weight gradient of the NHWC bf16 convolution for the K-heavy layers (input channels a multiple of 32, >= 64 outputs), gfx950:
 //
 //   dW[n][tap*Ctot + coff_k + c] += sum_m gy[m][n] * X[pixel(m, tap)][c]          (the GEMM gy^T (N x M) * im2col(X) (M x K))
 //
@@ -39,7 +39,7 @@ struct WgsK {
     unsigned long long* stamps;   // diagnostics (yh_wgs_set_stamps): [workgroup][wave][8] shader-clock stamps of the first segment
     int Ktot;          // columns of a dw row
     int nk;            // 32-pixel work units of the layer (M / 32); a unit is two 16-pixel steps
-    int nct, cpt, T;   // column tiles per n-tile, column tiles per tap, tiles
+    int nct, T;        // column tiles (128 im2col columns of the segment: column = tap * C + c) per n-tile, tiles
     int G, S;          // virtual workgroups; S > 0: exact T x S grid (XCD-aware block map)
     long U;            // T * nk work units
     unsigned gybytes, xbytes, dwbytes;
@@ -131,9 +131,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
         u += kb - ka;
         const int ntile = t / p.nct, ctile = t - ntile * p.nct;
         const int n0 = ntile * 128;
-        const int tap = ctile / p.cpt;
-        const int c0 = (ctile - tap * p.cpt) * 128;
-        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        // this lane's 16-byte chunk of a row: im2col column colv = tap * C + channel.  The four lanes of a quad hold 32 consecutive
+        // columns, C is a multiple of 32: a quad never straddles a tap, so the lane that OWNS a row (below) computes the row's
+        // offset for ITS quad's tap (C = 64: a tile is two taps; C >= 128: one tap or a part of one)
+        const int colv = ctile * 128 + srcch * 8;
+        const int tapv = colv / d.seg.C;
+        const int chv = colv - tapv * d.seg.C;
+        const int khv = tapv / d.KW, kwv = tapv - khv * d.KW;
+        const bool tapok = tapv < d.KH * d.KW;
         // this wave's share of the segment
         const int ns = kb - ka, nsb = ns >> 2, nsr = ns & 3;
         const int k0 = 2 * (ka + wave * nsb + (wave < nsr ? wave : nsr));      // in 16-pixel steps
@@ -143,9 +148,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             voffA[i] = (n0 + srcch * 8 < d.N) ? (unsigned)(((4 * i + lrow) * d.ldg + n0 + srcch * 8) * 2) : WGS_OOB;
-            voffB[i] = (unsigned)(((4 * i + lrow) * d.seg.ld + c0 + srcch * 8) * 2);
+            voffB[i] = tapok ? (unsigned)(((4 * i + lrow) * d.seg.ld + chv) * 2) : WGS_OOB;
         }
-        const unsigned chunkB = (unsigned)((c0 + srcch * 8) * 2);
+        const unsigned chunkB = (unsigned)(chv * 2);
         // the pixel of the row this lane OWNS (row lrow + 4 * (lane & 3): the quad's lane i owns the row of transfer i)
         int pim = 0, pho = 0, pwo = 0;
         if (!PW && k0 < k1) {
@@ -168,8 +173,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
         // at most one row wrap and one image wrap, Ho * Wo >= 16).  `oob` (scalar) turns a stage past the wave's range into a dummy.
         unsigned boff = 0;
         auto b_addr = [&](unsigned oob) {
-            const int hi = (pho << sshift) - d.pad + kh, wi = (pwo << sshift) - d.pad + kw;
-            const bool ok = (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+            const int hi = (pho << sshift) - d.pad + khv, wi = (pwo << sshift) - d.pad + kwv;
+            const bool ok = (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi && tapok;
             const unsigned pix = (unsigned)__umul24((unsigned)__umul24(pim, Hs) + (unsigned)(hi >> ups), Ws) + (unsigned)(wi >> ups);
             // a pixel outside the image (its pix is garbage) or a dummy stage: bit 31 puts the offset past the descriptor's range
             boff = (pix * pixb) | (ok ? 0u : WGS_OOB) | oob;
@@ -303,16 +308,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
         // out-of-range offset instead of an exec mask.
         {
             const int nl = n0 + 64 * hx + 4 * (lane >> 5);
-            const unsigned voff = (unsigned)((nl * p.Ktot + tap * d.Ctot + d.coff_k + c0 + 64 * hy + (lane & 31)) * 4);
+            // the two 32-column groups of this wave's quarter: tap and channel of a group are wave-uniform (32 | C)
+            const int col0 = ctile * 128 + 64 * hy, col1 = col0 + 32;
+            const int tap0 = col0 / d.seg.C, tap1 = col1 / d.seg.C;
+            const int ntap = d.KH * d.KW;
+            const unsigned voff0 = (unsigned)((nl * p.Ktot + tap0 * d.Ctot + d.coff_k + (col0 - tap0 * d.seg.C) + (lane & 31)) * 4);
+            const unsigned voff1 = (unsigned)((nl * p.Ktot + tap1 * d.Ctot + d.coff_k + (col1 - tap1 * d.seg.C) + (lane & 31)) * 4);
+            const unsigned dead0 = tap0 < ntap ? 0u : WGS_OOB, dead1 = tap1 < ntap ? 0u : WGS_OOB;    // columns past the last tap
 #pragma unroll
             for (int xx = 0; xx < 2; ++xx) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = 32 * xx + (r & 3) + 8 * (r >> 2);
-                    const unsigned vo = (nl + ro < d.N) ? voff : WGS_OOB;
+                    const unsigned rowdead = (nl + ro < d.N) ? 0u : WGS_OOB;
                     const int so = ro * p.Ktot * 4;
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[xx][0][r], rsd, vo, so, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[xx][1][r], rsd, vo, so + 128, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[xx][0][r], rsd, voff0 | dead0 | rowdead, so, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[xx][1][r], rsd, voff1 | dead1 | rowdead, so, 0);
                     if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -326,13 +337,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
 }
 
 // eligibility of the layer and the launch plan shared by the queries and the launcher
-struct WgsPlan { long M; int nk, ntn, nct, cpt, T, G, S, grid; bool pw; };
+struct WgsPlan { long M; int nk, ntn, nct, T, G, S, grid; bool pw; };
 
 bool wgs_plan(const yh_wgrad_desc* d, WgsPlan* pl)
 {
     if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->N < 64 || d->KH <= 0 || d->KW <= 0) return false;
     if (d->KH > 7 || d->KW > 7 || (d->stride != 1 && d->stride != 2) || d->pad < 0) return false;
-    if (d->seg.C <= 0 || d->seg.C % 128 != 0 || d->seg.ld % 8 != 0 || d->ldg % 8 != 0 || d->ldg < (d->N + 7) / 8 * 8) return false;
+    if (d->seg.C <= 0 || d->seg.C % 32 != 0 || d->seg.ld % 8 != 0 || d->ldg % 8 != 0 || d->ldg < (d->N + 7) / 8 * 8) return false;
     if (d->bn_z || d->partial) return false;
     if ((d->Hi + 2 * d->pad - d->KH) / d->stride + 1 != d->Ho || (d->Wi + 2 * d->pad - d->KW) / d->stride + 1 != d->Wo) return false;
     if (d->seg.ups && (d->Hi % 2 || d->Wi % 2)) return false;
@@ -346,8 +357,7 @@ bool wgs_plan(const yh_wgrad_desc* d, WgsPlan* pl)
     pl->M = M;
     pl->nk = (int)(M / 32);
     pl->ntn = (d->N + 127) / 128;
-    pl->cpt = d->seg.C / 128;
-    pl->nct = d->KH * d->KW * pl->cpt;
+    pl->nct = (d->KH * d->KW * d->seg.C + 127) / 128;
     pl->T = pl->ntn * pl->nct;
     pl->pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->seg.ups;
     int G = d->splits < 1 ? 1 : (d->splits > 4096 ? 4096 : d->splits);
@@ -385,7 +395,7 @@ int yh_wgs_run(const yh_wgrad_desc* d, yh_stream stream)
     k.d = *d;
     k.stamps = g_wgs_stamps;
     k.Ktot = d->KH * d->KW * d->Ctot;
-    k.nk = pl.nk; k.nct = pl.nct; k.cpt = pl.cpt; k.T = pl.T; k.G = pl.G; k.S = pl.S;
+    k.nk = pl.nk; k.nct = pl.nct; k.T = pl.T; k.G = pl.G; k.S = pl.S;
     k.U = (long)pl.T * pl.nk;
     k.gybytes = (unsigned)(((unsigned long)(pl.M - 1) * d->ldg + (d->N + 7) / 8 * 8) * 2);
     const unsigned long npix = (unsigned long)d->B * (d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups);
