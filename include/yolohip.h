@@ -159,7 +159,10 @@ typedef struct yh_wgrad_desc {
                                          on the general tiling: 32 = 32-pixel k-steps (two blocks per CU), 35 = four waves of
                                          64 x 64 on 32-pixel k-steps; 40 = the patch form (conv_wgp_kernel: 3x3 layers with 16 / 32 /
                                          64 input channels and <= 64 outputs: the input patch of a pixel region staged once in LDS,
-                                         persistent blocks, `splits` caps their number) where yh_conv_wgrad_patch_ok() */
+                                         persistent blocks, `splits` caps their number) where yh_conv_wgrad_patch_ok();
+                                         129 = wave-private 128 x 128 tiles + stream-K (conv_wgs_kernel: input channels a multiple
+                                         of 32, >= 64 outputs, B*Ho*Wo a multiple of 32; `splits` = workgroups, one per CU) where
+                                         yh_conv_wgrad_wave_tiles() > 0 */
     /* optional workspace of >= yh_conv_wgrad_ws_bytes() bytes (16-byte aligned, caller-owned, may be shared by launches on ONE
      * stream): the split-M partial tiles are written there with plain stores and summed into dw by a second kernel in split
      * order — bit-reproducible, and faster than the fp32 atomics of the default form (NULL), which are bound by the atomic rate
@@ -175,6 +178,13 @@ typedef struct yh_wgrad_desc {
      * conv_wgrad.hip (wide tilings of up to 256 im2col columns); others return YH_EINVAL.                                      */
     const yh_bf16* bn_z; int32_t bn_ldz; int32_t reserved0;
     const float* bn_ws; const float* bn_gamma; const float* bn_coef;
+    /* tile_k 129 only: an optional SECOND input segment of the same layer (seg2.ptr != NULL; a concat input:
+     * utils/layer_tools.py:106-114, models/normal/yolov5s.py head) whose weight-gradient columns start at channel coff_k2 of every
+     * tap — both segments in ONE launch: gy is read once per pixel split, one set of partial tiles / atomics instead of two.  The
+     * other forms ignore it (callers launch once per segment). */
+    yh_seg   seg2;
+    int32_t  coff_k2;
+    int32_t  reserved1;
 } yh_wgrad_desc;
 int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
 size_t yh_conv_wgrad_ws_bytes(const yh_wgrad_desc* d);

@@ -416,6 +416,42 @@ def test_conv_wgrad_wave_private_tiles(dev, B, H, W, Cin, Cout, k, s, coff, Ctot
     assert (got[..., mask] == 0.5).all()                           # the other segments' columns are untouched
 
 
+@pytest.mark.parametrize("k,C0,C1,ups0,Cout,groups", [(1, 128, 64, 1, 128, 5), (1, 64, 64, 0, 256, 96), (3, 64, 64, 0, 128, 7), (3, 128, 32, 0, 64, 20), (1, 256, 256, 1, 255, 256)])
+def test_conv_wgrad_wave_private_tiles_two_segments(dev, k, C0, C1, ups0, Cout, groups):
+    """both segments of a concat input in ONE launch of conv_wgs_kernel (yh_wgrad_desc.seg2): the column tiles of segment 0, then
+    those of segment 1 (its own buffer, pitch, upsample flag and channel offset); gy is read once"""
+    import ctypes as C
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import lib
+    B, H, W = 2, 16, 16
+    p = k // 2
+    ldg = ((Cout + 7) // 8) * 8
+    gy = torch.zeros(B, H, W, ldg, dtype=torch.bfloat16, device=dev)
+    gy[..., :Cout] = _nhwc(B, H, W, Cout, dev, 30)
+    s0 = _nhwc(B, H >> ups0, W >> ups0, C0, dev, 31)
+    s1w = torch.full((B, H, W, C1 + 32), float("nan"), dtype=torch.bfloat16, device=dev)
+    s1w[..., 32:] = _nhwc(B, H, W, C1, dev, 32)
+    Ctot = C0 + C1
+    dw = torch.zeros(Cout, k * k * Ctot, device=dev)
+    d = hipk.wgrad_desc(hipk.full(gy) if ldg == Cout else hipk.Slice(gy, 0, ldg), Cout, hipk.Slice(s0, 0, C0, ups=ups0), 0, Ctot, B, H, W, H, W, k, 1, p, dw, groups)
+    d.seg2 = hipk.make_seg(hipk.Slice(s1w, 32, C1))
+    d.coff_k2 = C0
+    d.tile_k = 129
+    T = lib().yh_conv_wgrad_wave_tiles(C.byref(d))
+    assert T == ((Cout + 127) // 128) * ((k * k * C0 + 127) // 128 + (k * k * C1 + 127) // 128)
+    hipk.wgrad_launch(d)
+    torch.cuda.synchronize()
+    x0 = _nchw(s0)
+    if ups0:
+        x0 = F.interpolate(x0, scale_factor=2, mode="nearest")
+    xin = torch.cat([x0, _nchw(s1w[..., 32:])], 1)
+    w = torch.zeros(Cout, Ctot, k, k, device=dev, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(xin, w, padding=p), w, _nchw(gy[..., :Cout]))
+    ref = ref.permute(0, 2, 3, 1).reshape(Cout, -1)
+    assert not torch.isnan(dw).any()
+    _close(dw, ref, 2e-3, 2e-3 * ref.abs().max().item())
+
+
 def test_conv_wgrad_wave_private_tiles_eligibility(dev):
     """layers the form does not cover fall through to the im2col forms (yh_conv_wgrad_wave_tiles == 0, tile_k 129 ignored)"""
     import ctypes as C

@@ -50,6 +50,7 @@ class WgradDesc(C.Structure):
         ("partial", C.c_void_p), ("partial_bytes", C.c_uint64),
         ("bn_z", C.c_void_p), ("bn_ldz", C.c_int32), ("reserved0", C.c_int32),
         ("bn_ws", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_coef", C.c_void_p),
+        ("seg2", Seg), ("coff_k2", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 

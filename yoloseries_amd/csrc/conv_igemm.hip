@@ -1273,7 +1273,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
 // by the patch row index on the source side of the DMA (as in conv_v3); the patch of the next channel block is prefetched
 // in six parts behind the taps 0..5 of the current one; weight tiles go through a 3-stage ring.  MFMA rows that are not an
 // output pixel of the tile (ragged tiles) read a zero line, so their accumulators are exact zeros for the statistics.
-struct HaloGeom { int TH, TW, PW, NP, tiles_x, tiles_y; };
+struct HaloGeom { int TH, TW, PW, NP, tiles_x, tiles_y, gx, gy, rowmajor; };
+
+// Block -> (persistent tile slot bx, output-channel tile by) of the halo kernels, launched as ONE row of gx * gy workgroups.  The gy
+// channel tiles of a pixel tile stage the SAME input patch: as grid rows (by = blockIdx.y) their linear ids are gx apart, i.e. they
+// land on different XCDs at different times and every one fetches the patch again (PMC, YOLOv5x at 1280^2: 2.78x the algorithmic
+// bytes on the 320-channel layers).  Workgroups are dealt round-robin to the 8 XCDs by linear id: XCD x takes a contiguous range of
+// the order (slot, channel tile), so the gy readers of a patch sit on one XCD, dispatched back to back, and share its L2.
+__device__ __forceinline__ void halo_block_map(const HaloGeom& hg, int& bx, int& by)
+{
+    if (hg.rowmajor) { by = blockIdx.x / hg.gx; bx = blockIdx.x - by * hg.gx; return; }     // YH_HALO_MAP=0: the round-3 order (A/B)
+    const int nb = hg.gx * hg.gy, lin = blockIdx.x, x = lin & 7, q = nb >> 3, r = nb & 7;
+    const int vid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+    bx = vid / hg.gy;
+    by = vid - bx * hg.gy;
+}
 
 // TL (tail): the channel count is a multiple of 16 but not of 64 (YOLOv5m / v5x widths: 96, 80, 160): the last channel block
 // runs only (C % 64) / 16 of its four 16-channel sub-steps.  Its DMA still fetches whole 128-byte rows (the bytes behind the
@@ -1306,7 +1320,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.y * BN;
+    int bx, by;
+    halo_block_map(hg, bx, by);
+    const int n0 = by * BN;
     const int ncb = (p.Ctot + BKT - 1) / BKT;
     const int tailn = TL ? (p.Ctot % BKT) / 16 : BKT / 16;   // 16-channel sub-steps of the last channel block
     const int H = d.Ho, W = d.Wo;                    // stride 1, pad 1: input grid == output grid
@@ -1388,7 +1404,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
         for (int j = 0; j < NB; ++j) lds_dma16(rsw, sb + j * (NWV * RPI * ROWB), voffB[j], sw);
     };
 
-    int tile = blockIdx.x;
+    int tile = bx;
     unsigned voffP[NPW], voffN[NPW];
     int slot = 0, islot = STG - 1, pb = 0;
     if (tile < ntiles) {
@@ -1400,8 +1416,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
         issue_B(2, 2);
         YH_VMCNT(NB);                                // patch and the weight tiles of steps 0, 1 have landed; the third stays in flight
     }
-    for (; tile < ntiles; tile += gridDim.x) {
-        const bool has_next = tile + (int)gridDim.x < ntiles;
+    for (; tile < ntiles; tile += hg.gx) {
+        const bool has_next = tile + hg.gx < ntiles;
         const int img = tile / tiles_per_img;
         const int trem = tile - img * tiles_per_img;
         const int tyi = trem / hg.tiles_x;
@@ -1436,7 +1452,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
         for (int cblk = 0; cblk < ncb; ++cblk) {
             const bool last_blk = cblk + 1 == ncb;
             const int ksn = (TL && last_blk) ? tailn : BKT / 16;      // wave-uniform
-            if (last_blk && has_next) patch_offsets(tile + gridDim.x, voffN);
+            if (last_blk && has_next) patch_offsets(tile + hg.gx, voffN);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kt = cblk * 9 + tap;
@@ -1692,8 +1708,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
             const int which = i / BN, c = i - which * BN;
             float v = 0.f;
             for (int j = c / 8; j < NT; j += CPR2) v += sRed[j * 16 + which * 8 + (c & 7)];
-            if (EPI == 1) put_stat(d, blockIdx.x, which, n0 + c, v);
-            else if (n0 + c < d.N) put_bnr(d, blockIdx.x, which, n0 + c, v);
+            if (EPI == 1) put_stat(d, bx, which, n0 + c, v);
+            else if (n0 + c < d.N) put_bnr(d, bx, which, n0 + c, v);
         }
     }
 }
@@ -1735,7 +1751,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.y * BN;
+    int bx, by;
+    halo_block_map(hg, bx, by);
+    const int n0 = by * BN;
     const int ncb = TL ? (p.Ctot + BKT - 1) / BKT : p.Ctot / BKT;
     const int tailn = TL ? (p.Ctot % BKT) / 32 : BKT / 32;   // 32-channel sub-steps of the last channel block (TL: C % 32 == 0 needed)
     const int H = d.Ho, W = d.Wo;
@@ -1806,7 +1824,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
         if (wave < 4) lds_dma16(rsw, sb + 2 * NWV * RPI * ROWB, voffB[2], sw);
     };
 
-    int tile = blockIdx.x;
+    int tile = bx;
     unsigned voffP[NPW], voffN[NPW];
     int slot = 0, islot = STG - 1, pb = 0;
     if (tile < ntiles) {
@@ -1818,8 +1836,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
         issue_W(2, 0, 2);
         if (wave < 4) { YH_VMCNT(3); } else { YH_VMCNT(2); }   // patch + the weight tiles of steps 0, 1 landed; the third stays in flight
     }
-    for (; tile < ntiles; tile += gridDim.x) {
-        const bool has_next = tile + (int)gridDim.x < ntiles;
+    for (; tile < ntiles; tile += hg.gx) {
+        const bool has_next = tile + hg.gx < ntiles;
         const int img = tile / tiles_per_img;
         const int trem = tile - img * tiles_per_img;
         const int tyi = trem / hg.tiles_x;
@@ -1850,7 +1868,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
         for (int cblk = 0; cblk < ncb; ++cblk) {
             const bool last_blk = cblk + 1 == ncb;
             const int ksn = (TL && last_blk) ? tailn : BKT / 32;
-            if (last_blk && has_next) patch_offsets(tile + gridDim.x, voffN);
+            if (last_blk && has_next) patch_offsets(tile + hg.gx, voffN);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kt = cblk * 9 + tap;
@@ -2578,7 +2596,9 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         const bool tl = (k.Ctot % 64) != 0;
         if (name_out) { snprintf(name_out, name_len, tl ? "conv_halo160_kernel<%d, true>" : "conv_halo160_kernel<%d, false>", epi); return YH_OK; }
         hipStream_t sth = (hipStream_t)stream;
-        const dim3 gridh(gx, gy), blkh(512);
+        static const int rowmajor = [] { const char* e = getenv("YH_HALO_MAP"); return (e && atoi(e) == 0) ? 1 : 0; }();
+        hgeo.gx = gx; hgeo.gy = gy; hgeo.rowmajor = (rowmajor || gy == 1) ? 1 : 0;
+        const dim3 gridh(gx * gy), blkh(512);              // one row of workgroups: halo_block_map
         const size_t sm = conv_halo160_smem_bytes();
         static bool attr_set = false;
         if (!attr_set) {
@@ -2599,7 +2619,9 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         const bool tl = (k.Ctot % 64) != 0;
         if (name_out) { snprintf(name_out, name_len, tl ? "conv_halo_kernel<%d, %d, true>" : "conv_halo_kernel<%d, %d, false>", bn, epi); return YH_OK; }
         hipStream_t sth = (hipStream_t)stream;
-        const dim3 gridh(gx, gy), blkh(512);
+        static const int rowmajor = [] { const char* e = getenv("YH_HALO_MAP"); return (e && atoi(e) == 0) ? 1 : 0; }();
+        hgeo.gx = gx; hgeo.gy = gy; hgeo.rowmajor = (rowmajor || gy == 1) ? 1 : 0;
+        const dim3 gridh(gx * gy), blkh(512);              // one row of workgroups: halo_block_map
 #define YH_LAUNCH_HALO(BN_, TL_)                                                                                     \
         do {                                                                                                         \
             const size_t sm = conv_halo_smem_bytes<BN_>();                                                           \

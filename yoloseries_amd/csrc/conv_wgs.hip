@@ -39,10 +39,11 @@ struct WgsK {
     unsigned long long* stamps;   // diagnostics (yh_wgs_set_stamps): [workgroup][wave][8] shader-clock stamps of the first segment
     int Ktot;          // columns of a dw row
     int nk;            // 32-pixel work units of the layer (M / 32); a unit is two 16-pixel steps
-    int nct, T;        // column tiles (128 im2col columns of the segment: column = tap * C + c) per n-tile, tiles
+    int nct, T;        // column tiles (128 im2col columns of a segment: column = tap * C + c) per n-tile, tiles
+    int nct0;          // ... of them in the first segment (the rest belong to d.seg2)
     int G, S;          // virtual workgroups; S > 0: exact T x S grid (XCD-aware block map)
     long U;            // T * nk work units
-    unsigned gybytes, xbytes, dwbytes;
+    unsigned gybytes, xbytes, xbytes2, dwbytes;
 };
 
 __device__ __forceinline__ v4s wgs_tr(const unsigned char* p) {
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
     const long u0 = p.U * v / p.G, u1 = p.U * (v + 1) / p.G;
 
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)d.gy, 0, p.gybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg.ptr, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg.ptr, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg2.ptr, 0, p.xbytes2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)d.dw, 0, p.dwbytes, 0x00020000);
 
     // loader geometry: a transfer fills 4 pixel rows x 256 B; this lane's row inside it, its chunk position inside the LDS
@@ -111,11 +113,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
         rdB[i] = rdc + (((i ^ (hy << 1)) ^ q) << 6) + 4096;
     }
 
-    const int ups = d.seg.ups;
-    const int Hs = d.Hi >> ups, Ws = d.Wi >> ups;
     const int HoWo = d.Ho * d.Wo;
     const int stepH = 16 / d.Wo, stepW = 16 - stepH * d.Wo;
-    const unsigned pixb = (unsigned)(d.seg.ld * 2);
     const int sshift = d.stride - 1;
 
 #define WGS_STAMP(I) do { if (p.stamps && first && lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + (I)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -129,14 +128,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
         const long left = u1 - u;
         const int kb = (left < (long)(p.nk - ka)) ? ka + (int)left : p.nk;
         u += kb - ka;
-        const int ntile = t / p.nct, ctile = t - ntile * p.nct;
+        const int ntile = t / p.nct, ctile_all = t - ntile * p.nct;
         const int n0 = ntile * 128;
+        // the input segment of this tile (a concat input: the tiles of segment 0, then those of segment 1) — all scalar
+        const bool second = ctile_all >= p.nct0;
+        const int ctile = second ? ctile_all - p.nct0 : ctile_all;
+        const int segC = second ? d.seg2.C : d.seg.C, segld = second ? d.seg2.ld : d.seg.ld, ups = second ? d.seg2.ups : d.seg.ups;
+        const int coffk = second ? d.coff_k2 : d.coff_k;
+        const __amdgpu_buffer_rsrc_t rsx = second ? rsx1 : rsx0;
+        const int Hs = d.Hi >> ups, Ws = d.Wi >> ups;
+        const unsigned pixb = (unsigned)(segld * 2);
         // this lane's 16-byte chunk of a row: im2col column colv = tap * C + channel.  The four lanes of a quad hold 32 consecutive
         // columns, C is a multiple of 32: a quad never straddles a tap, so the lane that OWNS a row (below) computes the row's
         // offset for ITS quad's tap (C = 64: a tile is two taps; C >= 128: one tap or a part of one)
         const int colv = ctile * 128 + srcch * 8;
-        const int tapv = colv / d.seg.C;
-        const int chv = colv - tapv * d.seg.C;
+        const int tapv = colv / segC;
+        const int chv = colv - tapv * segC;
         const int khv = tapv / d.KW, kwv = tapv - khv * d.KW;
         const bool tapok = tapv < d.KH * d.KW;
         // this wave's share of the segment
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             voffA[i] = (n0 + srcch * 8 < d.N) ? (unsigned)(((4 * i + lrow) * d.ldg + n0 + srcch * 8) * 2) : WGS_OOB;
-            voffB[i] = tapok ? (unsigned)(((4 * i + lrow) * d.seg.ld + chv) * 2) : WGS_OOB;
+            voffB[i] = tapok ? (unsigned)(((4 * i + lrow) * segld + chv) * 2) : WGS_OOB;
         }
         const unsigned chunkB = (unsigned)(chv * 2);
         // the pixel of the row this lane OWNS (row lrow + 4 * (lane & 3): the quad's lane i owns the row of transfer i)
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
             for (int s = 0; s < WGS_STG; ++s) {
                 const unsigned oob = (k0 + s < k1) ? 0u : WGS_OOB;
                 const unsigned la = lbase + s * WGS_STAGE;
-                const int sa = (k0 + s) * 16 * d.ldg * 2, sb = (k0 + s) * 16 * d.seg.ld * 2;
+                const int sa = (k0 + s) * 16 * d.ldg * 2, sb = (k0 + s) * 16 * segld * 2;
                 if (!PW) b_addr(oob);
                 WGS_DMA_A(0, la, sa, oob); WGS_DMA_A(1, la, sa, oob); WGS_DMA_A(2, la, sa, oob); WGS_DMA_A(3, la, sa, oob);
                 WGS_DMA_B(0, la, sb, oob); WGS_DMA_B(1, la, sb, oob); WGS_DMA_B(2, la, sb, oob); WGS_DMA_B(3, la, sb, oob);
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
                 const int s4 = (K) + WGS_STG;                                                    \
                 const unsigned oob = s4 < k1 ? 0u : WGS_OOB;                                     \
                 const unsigned la = lbase + slot * WGS_STAGE;                                    \
-                const int sa = s4 * 16 * d.ldg * 2, sb = s4 * 16 * d.seg.ld * 2;                 \
+                const int sa = s4 * 16 * d.ldg * 2, sb = s4 * 16 * segld * 2;                    \
                 slot = (slot + 1) & (WGS_STG - 1);                                               \
                 const unsigned char* const rb = wbase + slot * WGS_STAGE;                        \
                 WGS_MM(CA, CB, 0); WGS_MM(CA, CB, 1); NA_[0] = wgs_frag(rb + rdA[0]);          WGS_DMA_A(0, la, sa, oob); if (!PW) b_addr(oob); \
@@ -310,10 +317,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
             const int nl = n0 + 64 * hx + 4 * (lane >> 5);
             // the two 32-column groups of this wave's quarter: tap and channel of a group are wave-uniform (32 | C)
             const int col0 = ctile * 128 + 64 * hy, col1 = col0 + 32;
-            const int tap0 = col0 / d.seg.C, tap1 = col1 / d.seg.C;
+            const int tap0 = col0 / segC, tap1 = col1 / segC;
             const int ntap = d.KH * d.KW;
-            const unsigned voff0 = (unsigned)((nl * p.Ktot + tap0 * d.Ctot + d.coff_k + (col0 - tap0 * d.seg.C) + (lane & 31)) * 4);
-            const unsigned voff1 = (unsigned)((nl * p.Ktot + tap1 * d.Ctot + d.coff_k + (col1 - tap1 * d.seg.C) + (lane & 31)) * 4);
+            const unsigned voff0 = (unsigned)((nl * p.Ktot + tap0 * d.Ctot + coffk + (col0 - tap0 * segC) + (lane & 31)) * 4);
+            const unsigned voff1 = (unsigned)((nl * p.Ktot + tap1 * d.Ctot + coffk + (col1 - tap1 * segC) + (lane & 31)) * 4);
             const unsigned dead0 = tap0 < ntap ? 0u : WGS_OOB, dead1 = tap1 < ntap ? 0u : WGS_OOB;    // columns past the last tap
 #pragma unroll
             for (int xx = 0; xx < 2; ++xx) {
@@ -337,29 +344,40 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
 }
 
 // eligibility of the layer and the launch plan shared by the queries and the launcher
-struct WgsPlan { long M; int nk, ntn, nct, T, G, S, grid; bool pw; };
+struct WgsPlan { long M; int nk, ntn, nct, nct0, T, G, S, grid; bool pw, two; unsigned long xb, xb2; };
+
+bool wgs_seg_ok(const yh_wgrad_desc* d, const yh_seg& sg, int coff, unsigned long* xb)
+{
+    if (sg.C <= 0 || sg.C % 32 != 0 || sg.ld % 8 != 0 || coff % 8 != 0 || coff < 0 || coff + sg.C > d->Ctot) return false;
+    if (sg.ups && (d->Hi % 2 || d->Wi % 2)) return false;
+    const unsigned long npix = (unsigned long)d->B * (d->Hi >> sg.ups) * (d->Wi >> sg.ups);
+    *xb = ((npix - 1) * sg.ld + sg.C) * 2;
+    return *xb < (1ul << 31) - 4096;
+}
 
 bool wgs_plan(const yh_wgrad_desc* d, WgsPlan* pl)
 {
     if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->N < 64 || d->KH <= 0 || d->KW <= 0) return false;
     if (d->KH > 7 || d->KW > 7 || (d->stride != 1 && d->stride != 2) || d->pad < 0) return false;
-    if (d->seg.C <= 0 || d->seg.C % 32 != 0 || d->seg.ld % 8 != 0 || d->ldg % 8 != 0 || d->ldg < (d->N + 7) / 8 * 8) return false;
+    if (d->ldg % 8 != 0 || d->ldg < (d->N + 7) / 8 * 8) return false;
+    pl->two = d->seg2.ptr != nullptr;
+    pl->xb2 = 0;
+    if (!wgs_seg_ok(d, d->seg, d->coff_k, &pl->xb)) return false;
+    if (pl->two && !wgs_seg_ok(d, d->seg2, d->coff_k2, &pl->xb2)) return false;
     if (d->bn_z || d->partial) return false;
     if ((d->Hi + 2 * d->pad - d->KH) / d->stride + 1 != d->Ho || (d->Wi + 2 * d->pad - d->KW) / d->stride + 1 != d->Wo) return false;
-    if (d->seg.ups && (d->Hi % 2 || d->Wi % 2)) return false;
     const long M = (long)d->B * d->Ho * d->Wo;
     if (M % 32 != 0 || M >= (1L << 31) - 256 || d->Ho * d->Wo < 16) return false;
     const unsigned long gyb = ((unsigned long)(M - 1) * d->ldg + (d->N + 7) / 8 * 8) * 2;
-    const unsigned long npix = (unsigned long)d->B * (d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups);
-    const unsigned long xb = ((npix - 1) * d->seg.ld + d->seg.C) * 2;
-    if (gyb >= (1ul << 31) - 4096 || xb >= (1ul << 31) - 4096) return false;
+    if (gyb >= (1ul << 31) - 4096) return false;
     if ((unsigned long)(d->N + 127) * d->KH * d->KW * d->Ctot * 4 >= (1ul << 31)) return false;      // dw is addressed with 32-bit offsets
     pl->M = M;
     pl->nk = (int)(M / 32);
     pl->ntn = (d->N + 127) / 128;
-    pl->nct = (d->KH * d->KW * d->seg.C + 127) / 128;
+    pl->nct0 = (d->KH * d->KW * d->seg.C + 127) / 128;
+    pl->nct = pl->nct0 + (pl->two ? (d->KH * d->KW * d->seg2.C + 127) / 128 : 0);
     pl->T = pl->ntn * pl->nct;
-    pl->pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->seg.ups;
+    pl->pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->seg.ups && !(pl->two && d->seg2.ups);
     int G = d->splits < 1 ? 1 : (d->splits > 4096 ? 4096 : d->splits);
     const long U = (long)pl->T * pl->nk;
     if ((long)G > U) G = (int)U;
@@ -389,22 +407,22 @@ int yh_wgs_run(const yh_wgrad_desc* d, yh_stream stream)
 {
     WgsPlan pl;
     YH_CHECK_ARG(wgs_plan(d, &pl), "yh_conv_wgrad(tile_k 129): layer not eligible");
-    YH_CHECK_ARG(d->gy && yh_aligned16(d->gy) && d->seg.ptr && yh_aligned16(d->seg.ptr) && d->dw, "yh_conv_wgrad(tile_k 129): bad operands");
-    YH_CHECK_ARG(d->coff_k % 8 == 0 && d->coff_k + d->seg.C <= d->Ctot, "yh_conv_wgrad(tile_k 129): bad channel offset");
+    YH_CHECK_ARG(d->gy && yh_aligned16(d->gy) && d->seg.ptr && yh_aligned16(d->seg.ptr) && d->dw && yh_aligned16(d->seg2.ptr),
+                 "yh_conv_wgrad(tile_k 129): bad operands");
     WgsK k;
     k.d = *d;
     k.stamps = g_wgs_stamps;
     k.Ktot = d->KH * d->KW * d->Ctot;
-    k.nk = pl.nk; k.nct = pl.nct; k.T = pl.T; k.G = pl.G; k.S = pl.S;
+    k.nk = pl.nk; k.nct = pl.nct; k.nct0 = pl.nct0; k.T = pl.T; k.G = pl.G; k.S = pl.S;
     k.U = (long)pl.T * pl.nk;
     k.gybytes = (unsigned)(((unsigned long)(pl.M - 1) * d->ldg + (d->N + 7) / 8 * 8) * 2);
-    const unsigned long npix = (unsigned long)d->B * (d->Hi >> d->seg.ups) * (d->Wi >> d->seg.ups);
-    k.xbytes = (unsigned)(((npix - 1) * d->seg.ld + d->seg.C) * 2);
+    k.xbytes = (unsigned)pl.xb;
+    k.xbytes2 = (unsigned)pl.xb2;
     k.dwbytes = (unsigned)((unsigned long)d->N * d->KH * d->KW * d->Ctot * 4);
     // timing-only diagnostics (results wrong): YH_WGS_ABL bit 0: zero-record operand descriptors (every transfer returns zeros without
     // touching memory: the loop's issue-bound time), bit 1: zero-record dw descriptor (the atomics are dropped by the range check)
     static const int abl = [] { const char* e = getenv("YH_WGS_ABL"); return e ? atoi(e) : 0; }();
-    if (abl & 1) k.gybytes = k.xbytes = 0;
+    if (abl & 1) k.gybytes = k.xbytes = k.xbytes2 = 0;
     if (abl & 2) k.dwbytes = 0;
     static bool attr_set = false;
     if (!attr_set) {

@@ -135,6 +135,7 @@ MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct
 # the sigmoid of 210 M elements is hidden behind HBM time in a streaming pass but not between the barriers of a 15-wave-per-CU GEMM;
 # the step gets 1 % slower); 0: never.
 FUSE_STEM_BWD = int(os.environ.get("YH_FUSE_STEM_BWD", "1"))
+WGS_MERGE = os.environ.get("YH_WGS_MERGE", "0") != "0"                  # two-segment layers: one conv_wgs_kernel launch for both segments (measured: v5s step 12.13 -> 12.19 ms, off)
 HEAD_COLSUM_SIDE = os.environ.get("YH_HEAD_COLSUM_SIDE", "1") != "0"    # bias gradients of the head layers on the weight-gradient stream
 SPPF_FUSE = os.environ.get("YH_SPPF_FUSE", "1") != "0"      # FastSPP's three pools in one launch per direction (csrc/sppf.hip)
 WG_WS_BYTES = (256 << 20) if os.environ.get("YH_WGRAD_PARTIAL", "0") == "1" else 0
@@ -155,7 +156,7 @@ _WGRAD_TK64 = {
 # entries of a shipped / cached table are not applied.  Stride-2 data gradients carry their own version (conv_dg2_kernel, algo 7,
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
 KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad10", "wgrad8"
-TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
+TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f", KEY_WGRAD + "m"))
 
 # YH_SKIP_ALGOS=<n>[,<n>]: leave these kernel families (yh_conv_desc.algo) out of the per-layer timing — A/B runs of a new family on
 # one box (use a YH_TUNE_CACHE of its own and YH_TUNE_DEFAULTS=0 for the layers concerned)
@@ -1239,8 +1240,7 @@ class Program:
             on_main = op.kind == 'cba' and fused_stem
             if not on_main:
                 cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
-            coff_k = 0
-            for si, sg in enumerate(op.segs):
+            def wgrad_desc_for(sg, coff_k):
                 wd = WgradDesc()
                 wd.gy = gys.data_ptr() if op.kind == 'cba' else 0
                 wd.ldg, wd.N = gy_ld, gyN
@@ -1257,13 +1257,37 @@ class Program:
                 wd.dw = gdw
                 if self.wg_ws is not None:
                     wd.partial, wd.partial_bytes = self.wg_ws.data_ptr(), self.wg_ws.numel() * 4
-                ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
+                return wd
+            merged = None
+            if len(op.segs) == 2 and WGS_MERGE and not on_main:
+                # a concat input: both segments in ONE launch of conv_wgs_kernel (yh_wgrad_desc.seg2) — gy read once per pixel
+                # split, one set of partial tiles / atomics and one launch instead of two
+                wm = wgrad_desc_for(op.segs[0], 0)
+                wm.seg2 = hipk.make_seg(op.segs[1].sl())
+                wm.coff_k2 = op.segs[0].C
+                wm.tile_k = 129
+                if L.yh_conv_wgrad_wave_tiles(C.byref(wm)) > 0:
+                    merged = wm
+            coff_k = 0
+            for si, sg in enumerate(op.segs):
+                if merged is not None:
+                    if si == 1:
+                        break
+                    wd = merged
+                    ntile = L.yh_conv_wgrad_wave_tiles(C.byref(wd))
+                    kcols = op.k * op.k * op.Ctot
+                    nbytes_x = sum(2.0 * B * (op.Hi >> g.ups) * (op.Wi >> g.ups) * g.C for g in op.segs)
+                else:
+                    wd = wgrad_desc_for(sg, coff_k)
+                    ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
+                    kcols = op.k * op.k * (12 if op.focus else sg.C)
+                    nbytes_x = 2.0 * B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.C
                 wd.splits = self._tune_wgrad_splits(wd, M, ntile, op)
                 self._keep.append(wd)
                 if on_main:
                     self._wgrad_on_main.add(id(wd))
-                cmds.append(('wgrad', op, wd, (self._wgrad_name(L, wd), 2.0 * M * op.N * op.k * op.k * (12 if op.focus else sg.C),
-                                               2.0 * M * gy_ld * (2 if wd.bn_z else 1) + 2.0 * B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.C)))
+                cmds.append(('wgrad', op, wd, (self._wgrad_name(L, wd), 2.0 * M * op.N * kcols,
+                                               2.0 * M * gy_ld * (2 if wd.bn_z else 1) + nbytes_x)))
                 coff_k += sg.C
             if not on_main:
                 cmds.append(('wg_end', (n_cba - 1) % NGZ if op.kind == 'cba' else None, None, ('sync', 0, 0.0)))
@@ -1342,8 +1366,9 @@ class Program:
             return max(1, min((M + 255) // 256, (total + nt - 1) // nt))
         if os.environ.get("YH_WGRAD_TUNE", "1") == "0":
             return splits_for(512)
-        key = f"{KEY_WGRAD_WS if wd.partial else KEY_WGRAD}{'f' if wd.bn_z else ''}:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
-                                                          wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad))
+        two = bool(wd.seg2.ptr)
+        key = f"{KEY_WGRAD_WS if wd.partial else KEY_WGRAD}{'f' if wd.bn_z else ''}{'m' if two else ''}:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
+                                                          wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad) + ((wd.seg2.C, wd.seg2.ld, wd.seg2.ups) if two else ()))
         cache = _tune_cache()
         if key in cache:
             sp, wd.tile_k = (int(v) for v in cache[key])
@@ -1356,13 +1381,15 @@ class Program:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         name = self.L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
         tks = (0, 64) if name in _WGRAD_TK64 else (0,)
+        if two:
+            name, tks = "", ()              # both segments in one launch: only conv_wgs_kernel takes the second segment
         if name.startswith("conv_wgrad_kernel<4, 2, 1, 2, 64"):
             tks = tks + (32, 35)            # the general tiling with 32-pixel k-steps (two blocks per CU): 8 waves of 32 x 64 / 4 of 64 x 64
-        if 128 <= Kseg <= 384 and wd.N > 32 and not wd.bn_z:
+        if 128 <= Kseg <= 384 and wd.N > 32 and not wd.bn_z and not two:
             tks = tks + (128,)              # the general 128-column tiling on a layer that defaults to a wide one
         best, best_ms = None, None
         wd.tile_k = 40
-        if not wd.partial and self.L.yh_conv_wgrad_patch_ok(C.byref(wd)):
+        if not wd.partial and not two and self.L.yh_conv_wgrad_patch_ok(C.byref(wd)):
             tks = tks + (40,)               # patch form (conv_wgp_kernel): the input patch of a pixel region staged once in LDS
         wtiles = 0 if (wd.partial or wd.bn_z or os.environ.get("YH_WGRAD_WAVE", "1") == "0") else self.L.yh_conv_wgrad_wave_tiles(C.byref(wd))
         if wtiles > 0:
@@ -1371,10 +1398,14 @@ class Program:
             wd.tile_k = tk
             if tk == 129:                   # an exact tiles x splits grid where it fills the chip, else 256 workgroups dealt (tile, 32 pixels) units
                 # Workgroups (= CUs: the form holds a whole CU) a weight gradient may take.  Alone on the chip 256 is fastest; in the
-                # two-stream backward the main chain (data gradients, BatchNorm passes) runs beside it and the step is shortest when
-                # the weight gradients leave a quarter of the CUs alone (YOLOv5s 12.20 -> 12.02 ms, YOLOv5l 42.9 -> 42.4 ms: r04
-                # experiments).  Half of that is timed too: on the small layers the atomics (one partial tile per workgroup) dominate.
-                gmax = int(os.environ.get("YH_WGS_G", "192"))
+                # two-stream backward the main chain runs beside it, and its short latency-bound kernels (finalize launches, small
+                # layers) wait for a CU while a weight gradient holds all of them: the YOLOv5s step is shortest when the weight
+                # gradients leave a quarter of the CUs alone (12.00 -> 11.90 ms), the YOLOv5l step — long kernels on both streams —
+                # when its big layers take the whole chip (43.36 -> 42.82 ms): layers under 60 GFLOP get 192, the others 256
+                # (profiles/r04_step_experiments.txt d).  Half of the budget is timed too: on the small layers the atomics (one
+                # partial tile per workgroup) dominate.
+                wflops = 2.0 * M * wd.N * wd.KH * wd.KW * (wd.seg.C + (wd.seg2.C if two else 0))
+                gmax = int(os.environ.get("YH_WGS_G", "256" if wflops >= 60e9 else "192"))
                 sps = set()
                 for g in (gmax, gmax // 2):
                     sps |= {g} | ({wtiles * (g // wtiles)} if wtiles <= g else set())
