@@ -109,7 +109,10 @@ typedef struct yh_conv_desc {
                            * no statistics: 256-pixel x 80-channel tiles on 16x16x32 MFMAs, reduction over the flattened (tap, channel)
                            * index — no padding of N or K);
                            * 10 the pointwise kernel (conv_pw_kernel: 1x1 / s1 / p0 forward with exactly 80, 160 or 320 input channels and
-                           * N % 80 == 0, no statistics: pixel tiles and the weight tile whole in LDS, no k loop over memory) */
+                           * N % 80 == 0, no statistics: pixel tiles and the weight tile whole in LDS, no k loop over memory);
+                           * 11 wave-private tiles (conv_wpf_kernel: 3x3 / s1 / p1 or 1x1 / s1 / p0, one segment of >= 64 channels in a
+                           * multiple of 32, N >= 64: four waves of 128 pixels x 128 channels per CU, shared weight stage, one barrier
+                           * per 32 MFMAs; forward with statistics, data gradient plain / accumulating / with the fused reduction) */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
      * contributions already in out0 are added first and the sums are taken over the rounded total):

@@ -510,6 +510,53 @@ def _expect_family(d, algo):
         assert "conv_p3_kernel" in kn, kn
     if algo == 9:
         assert "conv_h80_kernel" in kn, kn
+    if algo == 11:
+        assert "conv_wpf_kernel" in kn, kn
+
+
+WPF_CASES = [
+    # B, H, W, Cin, Cout, k
+    (2, 20, 20, 128, 128, 3),      # YOLOv5s stage-3 bottleneck class: 800 pixels = two 512-pixel tiles, the second ragged
+    (1, 24, 40, 256, 256, 3),      # two channel tiles, 8 channel blocks per tap
+    (3, 13, 17, 64, 192, 3),       # odd sizes (tile rows wrap image rows and images), ragged channel tile (128 + 64)
+    (2, 16, 16, 128, 248, 3),      # N a multiple of 8 only
+    (2, 16, 16, 256, 128, 1),      # pointwise
+    (1, 8, 8, 512, 64, 1),         # 64 pixels: three of the four waves have no rows
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", WPF_CASES)
+def test_conv_wave_private_tiles_kernel(dev, B, H, W, Cin, Cout, k):
+    """conv_wpf_kernel (algo 11): four waves of 128 pixels x 128 channels per workgroup, private im2col stages, shared weight stage,
+    one barrier per 32 MFMAs — forward with the BatchNorm partial sums, data gradient accumulating / plain / with the fused
+    BatchNorm-backward reduction, against torch"""
+    from yoloseries_amd import hipk
+    p = k // 2
+    x = _nhwc(B, H, W, Cin, dev, 91)
+    g = torch.Generator().manual_seed(92)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    out = torch.full((B, H, W, Cout), 3.0, dtype=torch.bfloat16, device=dev)
+    d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, H, W, H, W, k, 1, p, wp, Cout, hipk.full(out))
+    d.algo = 11
+    assert "conv_wpf_kernel<0>" in _kname(d), _kname(d)
+    hipk.conv_launch(d)                                   # plain store
+    torch.cuda.synchronize()
+    ref = F.conv2d(_nchw(x), w, padding=p).permute(0, 2, 3, 1)
+    _close(out, ref, 8e-3, 2e-2)
+    out.fill_(3.0)
+    stats = torch.full((hipk.conv_stat_blocks(d), 2, wp.shape[0]), float("nan"), device=dev)
+    d.stats = stats.data_ptr()
+    assert "conv_wpf_kernel<1>" in _kname(d) and hipk.conv_stat_blocks(d) == stats.shape[0]
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out, ref, 8e-3, 2e-2)
+    o = out.float().reshape(-1, Cout).double()
+    assert not torch.isnan(stats[:, :, :Cout]).any()
+    assert ((stats[:, 0, :Cout].double().sum(0) - o.sum(0)).abs() <= 1e-3 + 1e-5 * o.abs().sum(0)).all()      # sums of the STORED values
+    assert ((stats[:, 1, :Cout].double().sum(0) - (o ** 2).sum(0)).abs() <= 1e-3 + 1e-5 * (o ** 2).sum(0)).all()
+    if Cout % 32 == 0 and Cout >= 64 and Cin >= 64:       # the data gradient reads gz with Cout channels, writes Cin
+        _dgrad_check(dev, B, H, W, Cin, Cout, k, 1, p, 11)
 
 
 @pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])

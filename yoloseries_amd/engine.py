@@ -599,13 +599,15 @@ class Program:
                 cands.append((1, tk, cap))
         d.tile_k = d.grid_cap = 0
         if os.environ.get("YH_CONV_V3", "1") != "0":
-            for algo in (2, 3, 4, 5, 6, 7, 8, 9, 10):
+            # algo 11 (conv_wpf_kernel: wave-private 128 x 128 tiles) is built and parity-tested but loses to the halo / ring kernels on
+            # every BASELINE layer shape (tile quantisation: tools/bench_wpf.py, profiles/r04_step_experiments.txt k): YH_CONV_WPF=1 times it too
+            for algo in (2, 3, 4, 5, 6, 7, 8, 9, 10) + ((11,) if os.environ.get("YH_CONV_WPF", "0") == "1" else ()):
                 if str(algo) in SKIP_ALGOS:
                     continue
                 d.algo = algo
                 kn = self._kernel_name(d)
                 if ("conv_v3" in kn and algo < 5) or ("conv_halo_kernel" in kn and algo == 5) or ("conv_halo160" in kn and algo == 6) or \
-                        ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8) or ("conv_h80" in kn and algo == 9) or ("conv_pw" in kn and algo == 10):
+                        ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8) or ("conv_h80" in kn and algo == 9) or ("conv_pw" in kn and algo == 10) or ("conv_wpf" in kn and algo == 11):
                     cands.append((algo, 0, 0))
                     if algo < 5 and kn.endswith(", true>") and all(d.seg[i].C % 32 == 0 for i in range(d.nseg)):
                         cands.append((algo, 32, 0))    # ragged last channel block: 32-channel steps instead of 64 + tail
