@@ -29,6 +29,9 @@ YH_BWD_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/se
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/b64 -- python3 bench.py --steps 10 --warmup 3 $NOB > $OUT/b64.log 2>&1
 S=$(find $OUT/serial -name "*kernel_stats.csv" | head -1); cp "$S" profiles/${TAG}_kernel_stats_serial.csv
 S=$(find $OUT/b64 -name "*kernel_stats.csv" | head -1); cp "$S" profiles/${TAG}_kernel_stats_bench_b64.csv
+T=$(find $OUT/b64 -name "*kernel_trace.csv" | head -1)
+python3 tools/step_trace.py "$T" > profiles/${TAG}_step_trace.txt
+python3 tools/step_overlap.py "$T" > profiles/${TAG}_step_overlap.txt
 rm -rf $OUT/serial $OUT/b64
 pmc_passes "" train:small:64:640 3
 python3 bench.py --steps 20 --warmup 5 > profiles/${TAG}_bench_default.json 2> $OUT/bench_default.err
