@@ -50,6 +50,7 @@ struct ConvK {
     unsigned segbytes[2], wbytes;   // addressable bytes from seg[i].ptr / w (hardware range check zero-fills beyond)
     unsigned long segbytes64[2];    // the same, unclamped: conv_v3_kernel re-bases its input descriptors at every tile
     int pointwise; // 1x1 / stride 1 / no upsample: input pixel == output pixel
+    int xgx, xgy;  // conv_v3_kernel launched as ONE row of xgx * xgy workgroups in XCD-major (m-tile slot, n-tile) order (0: 2-D grid)
     int dbg;       // YH_CONV_DBG kernel-selection switches for A/B timing: 16 generic kernel instead of v2, 64 32-channel
                    // k-steps only, 256 no stem kernel (the ablation masks are compile-time: make ablate ABL=mask)
 };
@@ -917,7 +918,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN;
     const int wn = wave % WN;
-    const int n0 = blockIdx.y * BN;
+    // the gy output-channel tiles of an m-tile read the same input rows: as grid rows they are gx workgroups apart (other XCDs, other
+    // times: every one fetches the rows again — PMC on YOLOv5x stage-2 conv, 3x3 / s2, 3 channel tiles: 30 GB fetched for a 4.2 GB
+    // input); launched as one row in XCD-major (slot, channel tile) order they share an XCD's L2 (halo_block_map)
+    int bx = blockIdx.x, by = blockIdx.y, gdx = gridDim.x;
+    if (p.xgx > 0) {
+        const int nb = p.xgx * p.xgy, lin = blockIdx.x, x = lin & 7, q = nb >> 3, r = nb & 7;
+        const int vid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+        bx = vid / p.xgy; by = vid - bx * p.xgy; gdx = p.xgx;
+    }
+    const int n0 = by * BN;
     const int HoWo = d.Ho * d.Wo;
     const int sdmask = (1 << p.sdshift) - 1;
     int ph = 0, pw = 0, zslot = 0, zslots = 1;
@@ -976,7 +986,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
         __syncthreads();
     }
 
-    for (int mt = blockIdx.x + gridDim.x * zslot; mt < mtiles; mt += gridDim.x * zslots) {
+    for (int mt = bx + gdx * zslot; mt < mtiles; mt += gdx * zslots) {
         const int m0 = mt * BMT;
         const int im0 = p.pointwise ? 0 : m0 / (p.cls ? HcWc : HoWo);          // first image of the tile
         const unsigned long off0 = p.pointwise ? (unsigned long)m0 * (unsigned long)(d.seg[0].ld * 2) : (unsigned long)im0 * pimg0;
@@ -1243,8 +1253,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
     }
 
     if (EPI == 1 && t < BN) {
-        put_stat(d, blockIdx.x, 0, n0 + t, run_s);
-        put_stat(d, blockIdx.x, 1, n0 + t, run_q);
+        put_stat(d, bx, 0, n0 + t, run_s);
+        put_stat(d, bx, 1, n0 + t, run_q);
     }
     if (EPI == 3) {
         constexpr int CPR2 = BN / 8;
@@ -1253,7 +1263,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sRed[t * 16 + e] = bs_[e]; sRed[t * 16 + 8 + e] = bq_[e]; }
         __syncthreads();
-        const size_t rowi = (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+        const size_t rowi = (size_t)blockIdx.z * gdx + bx;
         for (int i = t; i < 2 * BN; i += NT) {
             const int which = i / BN, c = i - which * BN;
             float v = 0.f;
@@ -2621,8 +2631,10 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         const bool tl = (k.Ctot % 64) != 0;
         if (name_out) { snprintf(name_out, name_len, tl ? "conv_halo_kernel<%d, %d, true>" : "conv_halo_kernel<%d, %d, false>", bn, epi); return YH_OK; }
         hipStream_t sth = (hipStream_t)stream;
+        // measured (profiles/r04_step_experiments.txt j): +0.5 % on YOLOv5x inference, -1 % on the YOLOv5l train step (forward with
+        // statistics / data gradients) -> the XCD-major order only under the inference epilogue
         static const int rowmajor = [] { const char* e = getenv("YH_HALO_MAP"); return (e && atoi(e) == 0) ? 1 : 0; }();
-        hgeo.gx = gx; hgeo.gy = gy; hgeo.rowmajor = (rowmajor || gy == 1) ? 1 : 0;
+        hgeo.gx = gx; hgeo.gy = gy; hgeo.rowmajor = (rowmajor || gy == 1 || epi != 2) ? 1 : 0;
         const dim3 gridh(gx * gy), blkh(512);              // one row of workgroups: halo_block_map
 #define YH_LAUNCH_HALO(BN_, TL_)                                                                                     \
         do {                                                                                                         \
@@ -2658,6 +2670,12 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
             return YH_OK;
         }
         hipStream_t st3 = (hipStream_t)stream;
+        {
+            // measured: no gain on YOLOv5x inference (707 / 712 -> 691 / 717 img/s), -2 % on the YOLOv5l train step: off (YH_HALO_MAP=2 enables it)
+            static const int rowmajor3 = [] { const char* e = getenv("YH_HALO_MAP"); return (e && atoi(e) == 2) ? 0 : 1; }();
+            k.xgx = k.xgy = 0;
+            if (!k.cls && grid.y > 1 && grid.z == 1 && !rowmajor3) { k.xgx = (int)grid.x; k.xgy = (int)grid.y; grid = dim3(grid.x * grid.y, 1, 1); }
+        }
 #define YH_LAUNCH_V3(BMT_, BN_, WM_, BKT_, STG_, TL_)                                                                \
         do {                                                                                                         \
             const size_t sm = conv3_smem_bytes<BMT_, BN_, WM_, BKT_, STG_>();                                        \
