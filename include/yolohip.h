@@ -458,7 +458,8 @@ size_t yh_decode_filter_ws_bytes(const yh_decode_desc* d);
 /* The same filter applied to an already decoded (B, N, 5+nc) fp32 tensor — the argument of
  * YOLOV5Evaluator.numba_nms (trainer/eval_yolov5.py:261-286); used after TTA merging.  `yolox`: 0 YOLOv5 single label,
  * 1 YOLOX, 2 YOLOv5 multi-label (hyp['mutil_label'], :276-279: one candidate per (prediction, class) with cls*obj >= cls_thr,
- * in (prediction, class) order; ncand may exceed cap — rows past cap are counted, not stored: the caller re-runs with more). */
+ * in (prediction, class) order; ncand may exceed cap — rows past cap are counted, not stored: the caller re-runs with more),
+ * 3 YOLOX multi-label (trainer/eval_yolox.py:218-221: the same among the predictions with obj * max(cls) >= conf_thr). */
 int yh_filter_decoded(const float* dec, int B, int N, int num_class, float conf_thr, float cls_thr, int yolox,
                       float* cand, int32_t* ncand, int cap, yh_stream stream);
 /* Greedy NMS per image on candidate lists, selection order = reference order.

@@ -110,8 +110,10 @@ def candidates_v5(x_img, conf_thr, cls_thr, multi_label=False):
     return out[conf > F32(cls_thr)]
 
 
-def candidates_yolox(x_img, conf_thr, cls_thr):
-    """trainer/eval_yolox.py:206-231: pre-filter obj*max(cls) >= conf ; cls*=obj ; cls_conf >= cls_thr."""
+def candidates_yolox(x_img, conf_thr, cls_thr, multi_label=False):
+    """trainer/eval_yolox.py:206-231: pre-filter obj*max(cls) >= conf ; cls*=obj ; cls_conf >= cls_thr.
+    Multi-label branch (:218-221, hyp['mutil_label']): every (row, class) with cls*obj >= cls_thr is a candidate of its own,
+    in row-major order (np.nonzero)."""
     x = np.asarray(x_img, dtype=F32)
     m = (x[:, 4] * x[:, 5:].max(axis=1)) >= F32(conf_thr)
     x = x[m].copy()
@@ -119,6 +121,9 @@ def candidates_yolox(x_img, conf_thr, cls_thr):
         return np.zeros((0, 6), F32)
     x[:, 5:] *= x[:, 4:5]
     box = xywh2xyxy(x[:, :4])
+    if multi_label:
+        ri, ci = (x[:, 5:] >= F32(cls_thr)).nonzero()
+        return np.concatenate((box[ri], x[ri, ci + 5][:, None], ci[:, None].astype(F32)), axis=1).astype(F32)
     conf = x[:, 5:].max(axis=1)
     cls = x[:, 5:].argmax(axis=1).astype(F32)
     out = np.concatenate((box, conf[:, None], cls[:, None]), axis=1).astype(F32)
@@ -149,6 +154,16 @@ def postprocess_v5(decoded, conf_thr, cls_thr, iou_thr, class_aware=True, max_ke
     outs = []
     for i in range(decoded.shape[0]):
         cand = candidates_v5(decoded[i], conf_thr, cls_thr, multi_label)
+        rows, _ = nms_image(cand, iou_thr, class_aware, max_keep, merge_filter)
+        outs.append(rows if rows is not None else None)
+    return outs
+
+
+def postprocess_yolox(decoded, conf_thr, cls_thr, iou_thr, class_aware=True, max_keep=300, merge_filter=True, multi_label=False):
+    """YOLOXEvaluator.numba_nms (trainer/eval_yolox.py:201-259): list per image of (n,6) or None."""
+    outs = []
+    for i in range(decoded.shape[0]):
+        cand = candidates_yolox(decoded[i], conf_thr, cls_thr, multi_label)
         rows, _ = nms_image(cand, iou_thr, class_aware, max_keep, merge_filter)
         outs.append(rows if rows is not None else None)
     return outs

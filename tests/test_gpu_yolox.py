@@ -92,6 +92,42 @@ def test_yolox_model_and_evaluator(dev):
             np.testing.assert_array_equal(o, g[f"nms_out{i}"])
 
 
+def test_yolox_multi_label_golden(dev):
+    """hyp['mutil_label'] for the YOLOX evaluator (trainer/eval_yolox.py:218-221; round 4): every (prediction, class) with
+    cls*obj >= cls_thr among the predictions with obj * max(cls) >= conf_thr enters NMS as a candidate of its own — rows and pick
+    order of the reference evaluator bit for bit (the candidate table has to grow past one row per prediction), the oracle on fresh
+    inputs, and the head path (decode + multi-label filter) against the decoded path"""
+    from oracle import postproc as opp
+    from yoloseries_amd.trainer import YOLOXEvaluator
+    g = np.load(os.path.join(G, "g13_round4.npz"))
+    dec = g["mlx_dec"]
+    ev = YOLOXEvaluator(None, _hypx(dev, 320, num_class=dec.shape[2] - 5, mutil_label=True))
+    outs = ev.numba_nms(torch.from_numpy(dec).to(dev))
+    assert [(-1 if o is None else len(o)) for o in outs] == list(g["mlx_n"])
+    for i, o in enumerate(outs):
+        if o is not None:
+            np.testing.assert_array_equal(o, g[f"mlx_out{i}"])
+    assert max(ev.last_ncand) > dec.shape[1]
+    r = np.random.RandomState(78)
+    d2 = r.uniform(0, 1, (2, 300, 5 + 8)).astype(np.float32)
+    d2[..., :2] = r.uniform(20, 300, (2, 300, 2)); d2[..., 2:4] = r.uniform(10, 60, (2, 300, 2))
+    ev2 = YOLOXEvaluator(None, _hypx(dev, 320, num_class=8, mutil_label=True, conf_threshold=0.2, cls_threshold=0.1))
+    got = ev2.numba_nms(torch.from_numpy(d2).to(dev))
+    exp = opp.postprocess_yolox(d2, 0.2, 0.1, 0.2, multi_label=True)
+    for a, b in zip(got, exp):
+        np.testing.assert_array_equal(a, b)
+    heads = synth_yolox_heads(2, 64, 4, seed=5, scale=2.0)
+    ev3 = YOLOXEvaluator(None, _hypx(dev, 64, num_class=4, mutil_label=True, conf_threshold=0.05, cls_threshold=0.05))
+    hp = {k: torch.from_numpy(v).to(dev) for k, v in heads.items()}
+    a = ev3._nms_from_heads(hp, 64)
+    b = ev3.numba_nms(ev3.decode(hp, 64))
+    assert any(x is not None for x in a)
+    for x, y in zip(a, b):
+        assert (x is None) == (y is None)
+        if x is not None:
+            np.testing.assert_array_equal(x, y)
+
+
 def test_yolox_train_step(dev):
     from yoloseries_amd import models
     from yoloseries_amd.loss import YOLOXLoss

@@ -273,3 +273,16 @@ def test_g12_multi_label_candidates():
     for i, o in enumerate(outs):
         if o is not None:
             np.testing.assert_array_equal(o, g[f"ml_out{i}"])
+
+
+def test_g13_yolox_multi_label_candidates():
+    """hyp['mutil_label'] of the YOLOX evaluator (trainer/eval_yolox.py:218-221): pre-filter obj * max(cls) >= conf, then one
+    candidate per (prediction, class) — the oracle's rows and pick order equal the reference evaluator's, bit for bit"""
+    g = load("g13_round4.npz")
+    conf, cls, iou = (float(v) for v in g["mlx_thr"])
+    outs = postproc.postprocess_yolox(g["mlx_dec"], conf, cls, iou, class_aware=True, max_keep=300, merge_filter=True, multi_label=True)
+    assert [(-1 if o is None else len(o)) for o in outs] == list(g["mlx_n"])
+    assert max(g["mlx_n"]) > 40 and min(g["mlx_n"]) == -1
+    for i, o in enumerate(outs):
+        if o is not None:
+            np.testing.assert_array_equal(o, g[f"mlx_out{i}"])

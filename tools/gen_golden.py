@@ -86,6 +86,9 @@ def main():
     if sys.argv[1:] == ["--only", "g12"]:
         gen_g12(ref_models, ref_trainer)
         return
+    if sys.argv[1:] == ["--only", "g13"]:
+        gen_g13(ref_trainer)
+        return
     from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_head_outputs, synth_targets
 
     os.makedirs(OUT, exist_ok=True)
@@ -465,6 +468,7 @@ def main():
     gen_g10(ref_utils)
     gen_g11(ref_utils, ref_models)
     gen_g12(ref_models, ref_trainer)
+    gen_g13(ref_trainer)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden written:", sorted(os.listdir(OUT)), f"{total / 1e6:.2f} MB")
 
@@ -695,6 +699,35 @@ def gen_g12(ref_models, ref_trainer):
             g[f"ml_out{i}"] = np.asarray(q, np.float32)
     np.savez_compressed(os.path.join(OUT, "g12_round3.npz"), **g)
     print("g12 written", os.path.getsize(os.path.join(OUT, "g12_round3.npz")) / 1e6, "MB", g["ml_n"])
+
+
+def gen_g13(ref_trainer):
+    """G13 (round 4): YOLOXEvaluator.numba_nms with hyp['mutil_label'] = True (trainer/eval_yolox.py:218-221) — one candidate per
+    (prediction, class) among the predictions with obj * max(cls) >= conf_threshold — on decoded rows with several hot classes."""
+    import torch
+    nc = 6
+    r = np.random.RandomState(1330)
+    B, N = 3, 400
+    dec = np.zeros((B, N, 5 + nc), np.float32)
+    for b in range(B):
+        c = r.uniform(30, 290, (12, 2)); wh = r.uniform(20, 80, (12, 2))
+        for i in range(N):
+            k = r.randint(12)
+            cls = r.uniform(0.0, 0.25, nc)
+            hot = r.choice(nc, size=r.randint(1, 4), replace=False)
+            cls[hot] = r.uniform(0.45, 1.0, len(hot))
+            dec[b, i] = np.concatenate([c[k] + r.uniform(-6, 6, 2), wh[k] * r.uniform(0.85, 1.2, 2), [r.uniform(0.05, 1.0)], cls])
+    dec[1, :, 4] = 0.01                          # an image without candidates
+    h = make_hyp(num_class=nc, img=320, mutil_label=True)
+    e = ref_trainer.YOLOXEvaluator(None, h, compute_metric=False)
+    res = e.numba_nms(torch.from_numpy(dec.copy()))
+    g = {"mlx_dec": dec, "mlx_n": np.array([-1 if q is None else len(q) for q in res]),
+         "mlx_thr": np.array([h["conf_threshold"], h["cls_threshold"], h["iou_threshold"]], np.float64)}
+    for i, q in enumerate(res):
+        if q is not None:
+            g[f"mlx_out{i}"] = np.asarray(q, np.float32)
+    np.savez_compressed(os.path.join(OUT, "g13_round4.npz"), **g)
+    print("g13 written", os.path.getsize(os.path.join(OUT, "g13_round4.npz")) / 1e3, "KB", g["mlx_n"], g["mlx_thr"])
 
 
 def gen_g10(ref_utils):

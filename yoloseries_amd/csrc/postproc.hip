@@ -255,11 +255,12 @@ __global__ __launch_bounds__(1024) void decode_gather_kernel(const float* __rest
     if (t == 0) ncand[b] = base_s;
 }
 
-// Multi-label candidate filter (hyp['mutil_label'], eval_yolov5.py:276-279): every (prediction, class) with cls*obj >= cls_thr
-// among the predictions with obj >= conf_thr is a candidate of its own; rows in (prediction, class) order like np.nonzero.
+// Multi-label candidate filter (hyp['mutil_label'], eval_yolov5.py:276-279 / eval_yolox.py:218-221): every (prediction, class) with
+// cls*obj >= cls_thr among the pre-filtered predictions — YOLOv5: obj >= conf_thr; YOLOX (yolox != 0): obj * max(cls) >= conf_thr —
+// is a candidate of its own; rows in (prediction, class) order like np.nonzero.
 // A thread counts its prediction's classes, a wave / block prefix sum places them.
 __global__ __launch_bounds__(1024) void filter_decoded_multi_kernel(const float* __restrict__ dec, int N, int nc, float conf_thr,
-                                                                    float cls_thr, float* __restrict__ cand, int32_t* __restrict__ ncand, int cap)
+                                                                    float cls_thr, int yolox, float* __restrict__ cand, int32_t* __restrict__ ncand, int cap)
 {
     __shared__ int wave_cnt[16];
     __shared__ int base_s;
@@ -276,7 +277,13 @@ __global__ __launch_bounds__(1024) void filter_decoded_multi_kernel(const float*
         float obj = 0.f;
         if (pi < N) {
             obj = row[4];
-            if (obj >= conf_thr)
+            bool pre = obj >= conf_thr;
+            if (yolox) {                                  // np.max over the classes, then one fp32 product (eval_yolox.py:206-207)
+                float mx = row[5];
+                for (int c = 1; c < nc; ++c) mx = fmaxf(mx, row[5 + c]);
+                pre = obj * mx >= conf_thr;
+            }
+            if (pre)
                 for (int c = 0; c < nc; ++c) cnt += (row[5 + c] * obj >= cls_thr) ? 1 : 0;
         }
         int incl = cnt;                                   // inclusive prefix sum over the wave
@@ -641,9 +648,9 @@ extern "C" int yh_filter_decoded(const float* dec, int B, int N, int num_class, 
                                  float* cand, int32_t* ncand, int cap, yh_stream stream)
 {
     YH_CHECK_ARG(dec && cand && ncand && B > 0 && N > 0 && num_class >= 1 && cap > 0 && cap % 4 == 0, "yh_filter_decoded: bad args");
-    YH_CHECK_ARG(yolox >= 0 && yolox <= 2, "yh_filter_decoded: mode must be 0 (YOLOv5), 1 (YOLOX) or 2 (YOLOv5 multi-label)");
-    if (yolox == 2)
-        hipLaunchKernelGGL(filter_decoded_multi_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, dec, N, num_class, conf_thr, cls_thr, cand, ncand, cap);
+    YH_CHECK_ARG(yolox >= 0 && yolox <= 3, "yh_filter_decoded: mode must be 0 (YOLOv5), 1 (YOLOX), 2 (YOLOv5 multi-label) or 3 (YOLOX multi-label)");
+    if (yolox >= 2)
+        hipLaunchKernelGGL(filter_decoded_multi_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, dec, N, num_class, conf_thr, cls_thr, yolox == 3 ? 1 : 0, cand, ncand, cap);
     else
         hipLaunchKernelGGL(filter_decoded_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, dec, N, num_class, conf_thr, cls_thr, yolox, cand, ncand, cap);
     YH_CHECK_LAUNCH("yh_filter_decoded");

@@ -87,8 +87,8 @@ class YOLOXEvaluator(YOLOV5Evaluator):
         return [torch.from_numpy(x) if x is not None else None for x in outs]
 
     def _nms_from_heads(self, stage_preds, img_h=None):
-        if self.hyp.get('mutil_label', False):
-            raise NotImplementedError("mutil_label=True (trainer/eval_yolox.py:218-221) is not implemented for YOLOX on the HIP path (false in every shipped config; the YOLOv5 evaluator has it)")
+        if self.hyp.get('mutil_label', False):          # one candidate per (prediction, class): through the decoded tensor (eval_yolox.py:218-221)
+            return self.numba_nms(self.decode(stage_preds, img_h))
         sp = self._stage_list(stage_preds)
         d, canon, ptrs = self._desc(sp)
         self._set_strides(d, img_h if img_h is not None else self.inp_h)
@@ -105,15 +105,19 @@ class YOLOXEvaluator(YOLOV5Evaluator):
     def numba_nms(self, preds_out):
         """decoded (bs, N, 5+nc) -> list of np.ndarray (n,6) or None (eval_yolox.py:201-259): pre-filter on
         obj*max(cls) >= conf, class confidence >= cls threshold (inclusive, unlike the v5 evaluator)"""
-        if self.hyp.get('mutil_label', False):
-            raise NotImplementedError("mutil_label=True (trainer/eval_yolox.py:218-221) is not implemented for YOLOX on the HIP path (false in every shipped config; the YOLOv5 evaluator has it)")
         p = preds_out.detach().to(torch.float32).contiguous()
         if not p.is_cuda:
             p = p.to(self.device if str(self.device).startswith("cuda") else "cuda:0")
         B, n, E = p.shape
         cap = ((n + 3) // 4) * 4
-        cand = torch.empty(B, cap, 6, dtype=torch.float32, device=p.device)
-        ncand = torch.zeros(B, dtype=torch.int32, device=p.device)
-        check(lib().yh_filter_decoded(p.data_ptr(), B, n, self.num_class, float(self.conf_threshold), float(self.cls_threshold), 1,
-                                      cand.data_ptr(), ncand.data_ptr(), cap, _lib.stream_ptr()), "yh_filter_decoded")
+        mode = 3 if self.hyp.get('mutil_label', False) else 1      # 3: one candidate per (prediction, class) (:218-221)
+        while True:
+            cand = torch.empty(B, cap, 6, dtype=torch.float32, device=p.device)
+            ncand = torch.zeros(B, dtype=torch.int32, device=p.device)
+            check(lib().yh_filter_decoded(p.data_ptr(), B, n, self.num_class, float(self.conf_threshold), float(self.cls_threshold), mode,
+                                          cand.data_ptr(), ncand.data_ptr(), cap, _lib.stream_ptr()), "yh_filter_decoded")
+            most = int(ncand.max().item()) if mode == 3 else 0     # multi-label: up to num_class candidates per prediction
+            if most <= cap:
+                break
+            cap = ((most + 3) // 4) * 4
         return self._run_nms(cand, ncand, B, cap)
