@@ -41,7 +41,8 @@ struct WgsK {
     int nk;            // 32-pixel work units of the layer (M / 32); a unit is two 16-pixel steps
     int nct, T;        // column tiles (128 im2col columns of a segment: column = tap * C + c) per n-tile, tiles
     int nct0;          // ... of them in the first segment (the rest belong to d.seg2)
-    int G, S;          // virtual workgroups; S > 0: exact T x S grid (XCD-aware block map)
+    int G;             // virtual workgroups
+    int mg, mGp, minv; // XCD-aware block map (mg = gcd(T, G), mGp = G / mg, minv = (T / mg)^-1 mod mGp); mg 0: identity
     long U;            // T * nk work units
     unsigned gybytes, xbytes, xbytes2, dwbytes;
 };
@@ -77,16 +78,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char* const wbase = smem + wave * WGS_WAVE_LDS;
 
-    // virtual workgroup.  Workgroups are dealt round-robin to the 8 XCDs by linear id, ONE per CU: XCD x (ids x, x + 8, ...) takes
-    // a contiguous range of the split-major order (split s, tile t) of an exact T x S grid, so the T tiles of a pixel split
-    // (which read the same gy / X rows) run on one XCD at the same time and share its L2, and no XCD gets more workgroups than
-    // CUs.  Stream-K grids keep the identity map (workgroups 16 apart cover the same pixels of tiles that share an operand).
+    // virtual workgroup.  Virtual workgroup v covers units [v U / G, (v + 1) U / G) of the tile-major order, so it STARTS at the
+    // fraction frac(v T / G) of a tile's pixel range: workgroups with the same start fraction ("phase") walk the same pixels of
+    // different tiles at the same time and read the same gy / X rows.  Hardware workgroups are dealt round-robin to the 8 XCDs by
+    // linear id, ONE per CU; XCD x (ids x, x + 8, ...) takes a contiguous range of the phase-sorted order, so equal and
+    // neighbouring phases share one L2 and no XCD gets more workgroups than CUs.  With g = gcd(T, G), G' = G / g: phase index
+    // ph = (v T / g) mod G' and the g workgroups of a phase are v0 + k G', v0 = ph (T / g)^-1 mod G'.  An exact T x S grid is the
+    // case g = T, G' = S (split-major order: the T tiles of a pixel split on one XCD).
     int v = blockIdx.x;
-    if (p.S > 0) {
+    if (p.mg > 0) {
         const int b = blockIdx.x, x = b & 7, q = p.G >> 3, r = p.G & 7;
-        const int vsm = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-        const int s = vsm / p.T;
-        v = (vsm - s * p.T) * p.S + s;
+        const int pos = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        const int ph = pos / p.mg;
+        v = (ph * p.minv) % p.mGp + (pos - ph * p.mg) * p.mGp;
     }
     const long u0 = p.U * v / p.G, u1 = p.U * (v + 1) / p.G;
 
@@ -413,7 +417,16 @@ int yh_wgs_run(const yh_wgrad_desc* d, yh_stream stream)
     k.d = *d;
     k.stamps = g_wgs_stamps;
     k.Ktot = d->KH * d->KW * d->Ctot;
-    k.nk = pl.nk; k.nct = pl.nct; k.nct0 = pl.nct0; k.T = pl.T; k.G = pl.G; k.S = pl.S;
+    k.nk = pl.nk; k.nct = pl.nct; k.nct0 = pl.nct0; k.T = pl.T; k.G = pl.G;
+    {   // phase-sorted block map: see the kernel.  YH_WGS_SKMAP=0 keeps the identity map on stream-K grids (A/B)
+        static const int skm = getenv("YH_WGS_SKMAP") ? atoi(getenv("YH_WGS_SKMAP")) : 1;
+        int a = pl.T, b = pl.G;
+        while (b) { const int t = a % b; a = b; b = t; }
+        k.mg = a; k.mGp = pl.G / a; k.minv = 0;
+        const int tp = (pl.T / a) % k.mGp;
+        for (int i = 1; i < k.mGp; ++i) if ((long)tp * i % k.mGp == 1) { k.minv = i; break; }
+        if (pl.S == 0 && !skm) k.mg = 0;
+    }
     k.U = (long)pl.T * pl.nk;
     k.gybytes = (unsigned)(((unsigned long)(pl.M - 1) * d->ldg + (d->N + 7) / 8 * 8) * 2);
     k.xbytes = (unsigned)pl.xb;
