@@ -20,12 +20,16 @@ __device__ __forceinline__ uint4 ld_nt(const uint16_t* p) {
 // ---------------------------------------------------------------- BN finalize
 // Deterministic column sums of a [nblk][nwhich][ld] partial slab.  These kernels sit on the layer chain's critical path
 // (conv -> finalize -> apply) and move little data, so they are built for latency: one block = FIN_CPB channels
-// (a quarter wave reads 64 contiguous bytes of a slab row), 32 row groups (8 waves x 4 quarter waves) with 8 independent
+// (a quarter wave reads 64 contiguous bytes of a slab row), 32 row groups (8 waves x 4 quarter waves) with FIN_U independent
 // row loads in flight per lane, fixed-order combine through LDS in fp64.  C / 16 blocks spread the slab over the CUs
 // (the 64-channel, 4-in-flight version took 7-24 us per launch, 114 launches per train step).
 constexpr int FIN_CPB = 16;
 constexpr int FIN_RG = 32;             // 512 threads: measured against 1024 / 256 / 128 threads and 8 / 32 channels per block on the train step
 constexpr int FIN_NT = FIN_CPB * FIN_RG;
+#ifndef YH_FIN_U
+#define YH_FIN_U 8
+#endif
+constexpr int FIN_U = YH_FIN_U;          // independent row loads in flight per lane
 
 template <int NW>
 __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int nblk, int ld, int C, int c, double* out /*NW*/)
@@ -36,27 +40,22 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
 #pragma unroll
     for (int w = 0; w < NW; ++w) acc[w] = 0.0;
     if (c < C) {
-        int b = rg;
-        for (; b + 7 * FIN_RG < nblk; b += 8 * FIN_RG) {
-            float v[8][NW];
+        // branch-free batches (rows past the end are clamped and masked): a predicated load per row makes the compiler wait for
+        // each one before the next is issued, which was most of the 6 us these launches took
+        for (int b = rg; b < nblk; b += FIN_U * FIN_RG) {
+            float v[FIN_U][NW];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < FIN_U; ++u) {
+                const int r = b + FIN_RG * u;
+                const size_t rc = (size_t)(r < nblk ? r : nblk - 1);
 #pragma unroll
-                for (int w = 0; w < NW; ++w) v[u][w] = slab[((size_t)(b + FIN_RG * u) * NW + w) * ld + c];
+                for (int w = 0; w < NW; ++w) v[u][w] = slab[(rc * NW + w) * ld + c];
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < FIN_U; ++u)
 #pragma unroll
-                for (int w = 0; w < NW; ++w) acc[w] += (double)v[u][w];
+                for (int w = 0; w < NW; ++w) acc[w] += (b + FIN_RG * u < nblk) ? (double)v[u][w] : 0.0;
         }
-        float t[8][NW];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int w = 0; w < NW; ++w) t[u][w] = (b + FIN_RG * u < nblk) ? slab[((size_t)(b + FIN_RG * u) * NW + w) * ld + c] : 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int w = 0; w < NW; ++w) acc[w] += (double)t[u][w];
     }
 #pragma unroll
     for (int w = 0; w < NW; ++w) sred[rg][w][lc] = acc[w];
@@ -77,16 +76,24 @@ __device__ __forceinline__ void bn_finalize_body(int cb, const float* __restrict
                                                  float eps, float momentum, float* ws)
 {
     const int c = cb * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
+    // the per-channel parameters are fetched BEFORE the column sums, so their latency hides under the slab's
+    const bool fin = threadIdx.x < FIN_CPB && c < C;
+    float g = 0.f, bt = 0.f, rm = 0.f, rv = 0.f;
+    if (fin) {
+        g = gamma[c]; bt = beta[c];
+        if (running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+    }
+    int64_t nb = 0;
+    if (fin && c == 0 && num_batches) nb = *num_batches;
     double sq[2];
     slab_colsum<2>(stats, nblk, ldstat, C, c, sq);
     if (threadIdx.x >= FIN_CPB) return;
-    if (c == 0 && num_batches) *num_batches += 1;
+    if (c == 0 && num_batches) *num_batches = nb + 1;
     if (c >= C) return;
     double mean = sq[0] / count;
     double var = sq[1] / count - mean * mean;
     if (var < 0.0) var = 0.0;
     float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    float g = gamma[c], bt = beta[c];
     float scale = g * invstd;
     ws[c] = scale;
     ws[C + c] = bt - (float)mean * scale;
@@ -94,8 +101,8 @@ __device__ __forceinline__ void bn_finalize_body(int cb, const float* __restrict
     ws[3 * C + c] = invstd;
     if (running_mean) {
         double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        running_mean[c] = (1.f - momentum) * rm + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * rv + momentum * (float)unbiased;
     }
 }
 
@@ -412,10 +419,12 @@ __device__ __forceinline__ void bn_bwd_finalize_body(int cb, const float* __rest
                                                      const float* __restrict__ ws, float* dgamma, float* dbeta, float* coef)
 {
     const int c = cb * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
+    float mu = 0.f, is = 0.f;           // fetched before the column sums (latency hidden under the slab's)
+    if (threadIdx.x < FIN_CPB && c < C) { mu = ws[2 * C + c]; is = ws[3 * C + c]; }
     double s[2];
     slab_colsum<2>(part, nblk, C, C, c, s);
     if (threadIdx.x >= FIN_CPB || c >= C) return;
-    s[1] = (double)ws[3 * C + c] * (s[1] - (double)ws[2 * C + c] * s[0]);      // sum(dz*y) -> sum(dz*xhat)
+    s[1] = (double)is * (s[1] - (double)mu * s[0]);      // sum(dz*y) -> sum(dz*xhat)
     if (dbeta) dbeta[c] = (float)s[0];
     if (dgamma) dgamma[c] = (float)s[1];
     if (coef) { coef[c] = (float)(s[0] / M); coef[C + c] = (float)(s[1] / M); }
