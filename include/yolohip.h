@@ -112,7 +112,10 @@ typedef struct yh_conv_desc {
                            * N % 80 == 0, no statistics: pixel tiles and the weight tile whole in LDS, no k loop over memory);
                            * 11 wave-private tiles (conv_wpf_kernel: 3x3 / s1 / p1 or 1x1 / s1 / p0, one segment of >= 64 channels in a
                            * multiple of 32, N >= 64: four waves of 128 pixels x 128 channels per CU, shared weight stage, one barrier
-                           * per 32 MFMAs; forward with statistics, data gradient plain / accumulating / with the fused reduction) */
+                           * per 32 MFMAs; forward with statistics, data gradient plain / accumulating / with the fused reduction);
+                           * 12 the 80 -> 160 channel tap kernel (conv_c80_kernel: 3x3 / s1 or s2 / p1 forward with exactly 80 input and 160
+                           * output channels, inference epilogue into one destination, no residual: 256 pixels x 160 channels per
+                           * workgroup, one tap per stage — no padding of N or K; YOLOv5x's stage-1 downsampling layer) */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
      * contributions already in out0 are added first and the sums are taken over the rounded total):

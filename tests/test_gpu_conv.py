@@ -512,6 +512,8 @@ def _expect_family(d, algo):
         assert "conv_h80_kernel" in kn, kn
     if algo == 11:
         assert "conv_wpf_kernel" in kn, kn
+    if algo == 12:
+        assert "conv_c80_kernel" in kn, kn
 
 
 WPF_CASES = [
@@ -748,6 +750,65 @@ def test_conv_halo80_kernel(dev, B, H, W, Cout):
         hipk.conv_launch(d4)
         torch.cuda.synchronize()
         _close(gx, gref.permute(0, 2, 3, 1), 1e-2, 4e-2)
+
+
+C80_CASES = [
+    # B, H, W, stride: ConvBnAct(80, 160, 3, stride, 1) on an H x W map (YOLOv5x stage-1 downsampling: 80 -> 160, stride 2, 640 x 640)
+    (2, 32, 32, 2),             # 16 x 16 outputs: one whole 256-pixel tile per image
+    (1, 40, 24, 2),             # 240 outputs: a ragged tile
+    (3, 19, 23, 2),             # odd input sizes (the last tap row / column inside the image, no bottom / right padding)
+    (1, 64, 48, 2),             # three tiles per image, tiles that start in the middle of an output row
+    (2, 16, 16, 1),             # stride 1
+    (1, 20, 28, 1),             # stride 1, three tiles, the last ragged
+]
+
+
+@pytest.mark.parametrize("B,H,W,stride", C80_CASES)
+def test_conv_c80_tap_kernel(dev, B, H, W, stride):
+    """conv_c80_kernel (algo 12): 3x3 layers with 80 input and 160 output channels, one tap per stage, no padding of either GEMM
+    side — plain store, and folded BatchNorm + bias + SiLU into a channel slice of a wider buffer — against torch"""
+    from yoloseries_amd import hipk
+    Cin, Cout = 80, 160
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = _nhwc(B, H, W, Cin, dev, 191)
+    g = torch.Generator().manual_seed(192)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    ref = F.conv2d(_nchw(x), w, None, stride=stride, padding=1).permute(0, 2, 3, 1)
+    # the input as a channel slice of a wider buffer (ld > C); NaN around it must never be read into a result
+    xbuf = torch.full((B, H, W, Cin + 16), float("nan"), dtype=torch.bfloat16, device=dev)
+    xbuf[..., 8:8 + Cin] = x
+    xin = hipk.Slice(xbuf, 8, Cin)
+    out = torch.full((B, Ho, Wo, Cout), 7.0, dtype=torch.bfloat16, device=dev)
+    d = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, Ho, Wo, H, W, 3, stride, 1, wp, Cout, hipk.full(out))
+    d.algo = 12
+    assert "conv_c80_kernel" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out, ref, 8e-3, 2e-2)
+    # a grid smaller than the tile count: persistent workgroups walk several tiles (stage buffers alternate across tiles)
+    out.fill_(7.0)
+    d.grid_cap = 1
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out, ref, 8e-3, 2e-2)
+    # folded BatchNorm + bias + SiLU, written into a slice of a wider buffer
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=g).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    cat = torch.full((B, Ho, Wo, Cout + 32), 5.0, dtype=torch.bfloat16, device=dev)
+    d2 = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, Ho, Wo, H, W, 3, stride, 1, wp, Cout, hipk.Slice(cat, 16, Cout),
+                        bias=bias, scale=scale, shift=shift, act=hipk.YH_ACT_SILU)
+    d2.algo = 12
+    assert "conv_c80_kernel" in _kname(d2), _kname(d2)
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    _close(cat[..., 16:16 + Cout], F.silu((ref + bias) * scale + shift), 1e-2, 3e-2)
+    assert (cat[..., :16] == 5.0).all() and (cat[..., 16 + Cout:] == 5.0).all()
+    # not eligible: a residual, statistics, other channel counts -> the library default runs instead
+    d3 = hipk.conv_desc([xin], hipk.YH_CONV_FWD, B, Ho, Wo, H, W, 3, stride, 1, wp, Cout, hipk.full(out), accumulate=1)
+    d3.algo = 12
+    assert "conv_c80_kernel" not in _kname(d3)
 
 
 PW_CASES = [

@@ -98,6 +98,8 @@ int yh_h80_rows(const yh_conv_desc* d);                 // grid rows; 0 = not el
 int yh_h80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
 
 // conv_pw.hip: the pointwise (1x1) kernel for the 80- / 160-channel layers of YOLOv5x (inference epilogues) behind yh_conv_igemm (algo 10)
+int yh_c80_rows(const yh_conv_desc* d);                 // grid size; 0 = not eligible (conv_c80.hip)
+int yh_c80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
 int yh_pw_rows(const yh_conv_desc* d);                  // grid rows; 0 = not eligible
 int yh_pw_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
 

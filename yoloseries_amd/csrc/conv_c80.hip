@@ -1,0 +1,324 @@
+// 3x3 convolution of an 80-channel input to 160 output channels, stride 1 or 2 — YOLOv5x's stage-1 downsampling layer
+// (ConvBnAct(80, 160, 3, 2) at 640 x 640 -> 320 x 320 for a 1280 x 1280 input: models/normal/yolov5x.py, utils/layer_tools.py:97-114),
+// inference epilogue.  On the general kernels that layer pads both sides of the GEMM: 160 output channels on 128-wide tiles
+// (256 computed) and 80 input channels per tap on 64-wide reduction blocks (128 computed) — 0.39 of the MFMAs are useful and the
+// layer, the largest of the network at 1280^2 (3.0 TFLOP per batch of 128), ran at 300 TFLOP/s.  Here neither side is padded:
+//
+//   * tile: 256 output pixels (consecutive in the image's row-major order; ragged at the end of an image) x all 160 channels per
+//     workgroup of 4 waves; a wave owns 64 pixels x 160 channels = 2 x 5 accumulators of v_mfma_f32_32x32x16_bf16 (operands
+//     swapped, D = W X^T: a lane holds one pixel and groups of four consecutive channels);
+//   * reduction: one TAP per stage — 80 channels = five MFMA steps of 16, no step straddles a tap.  A stage is the im2col rows of
+//     the tap (256 pixels x 160 B, gathered by LDS-DMA with a per-lane source address: stride and padding cost nothing extra) and
+//     the tap's weight slice (160 rows x 160 B), both in rows of 11 chunks of 16 bytes (176 B: an odd pitch, conflict-free b128
+//     fragment reads without a swizzle; the 11th chunk is never read).  Two stage buffers of 72 KiB alternate over the continuous
+//     stream of stages (9 per tile, the next tile's first stage is requested during the current tile's last): one barrier per
+//     stage = per 50 MFMAs of a wave;
+//   * epilogue: bias / folded BatchNorm / SiLU in registers, 32 pixels x 160 channels of a wave at a time through a wave-private
+//     corner of the stage buffer that has just been consumed, stored as whole 320-byte rows.
+//
+// The transfers are issued as inline assembly and waited for with hand-counted vmcnt (see conv_wgs.hip: through the builtin the
+// compiler waits for every transfer in flight before any LDS read).  Chosen per layer by the engine's timing (yh_conv_desc.algo 12).
+#include "common.h"
+#include <stdlib.h>
+#ifndef YH_C80_ABL
+#define YH_C80_ABL 0      // timing builds (results wrong): 1 no transfers after the prologue, 2 no fragment reads in the k loop, 4 no epilogue, 8 no scheduling fences
+#endif
+
+namespace {
+
+struct C80K {
+    const uint16_t* x; int ldx;
+    const uint16_t* w;
+    uint16_t* out; int ldo;
+    const float* bias; const float* scale; const float* shift;
+    int act;
+    int B, Hi, Wi, Ho, Wo, stride, pad;
+    int ntiles, tiles_per_img;
+    unsigned imgbytes, wbytes;
+    unsigned long long* stamps;            // diagnostics (yh_c80_set_stamps): [workgroup][wave][16] shader-clock stamps of the workgroup's third tile
+};
+
+constexpr int C80_CIN = 80, C80_TN = 160;
+constexpr int C80_PCH = 11, C80_PITCH = C80_PCH * 16;            // 176-byte LDS rows
+constexpr int C80_A_INST = 256 * C80_PCH / 64;                   // 44 transfers: the tap's rows of 256 pixels
+constexpr int C80_B_INST = (C80_TN * C80_PCH + 63) / 64;         // 28 transfers: the tap's weight rows
+constexpr int C80_A_BYTES = C80_A_INST * 1024;
+constexpr int C80_B_BYTES = C80_B_INST * 1024;
+constexpr int C80_STAGE = C80_A_BYTES + C80_B_BYTES;             // 72 KiB
+constexpr int C80_CONST_OFF = 2 * C80_STAGE;
+constexpr int C80_SMEM = C80_CONST_OFF + 3 * C80_TN * 4;
+constexpr int C80_NA = C80_A_INST / 4, C80_NB = C80_B_INST / 4;  // transfers per wave and stage
+constexpr int C80_SP = (C80_TN + 8) * 2;                         // staging pitch of the epilogue (bytes)
+constexpr unsigned C80_OOB = 0x80000000u;
+static_assert(256 * C80_PCH % 64 == 0 && C80_A_INST % 4 == 0 && C80_B_INST % 4 == 0, "whole transfers per wave");
+static_assert(4 * 32 * C80_SP <= C80_STAGE, "epilogue staging fits a stage buffer");
+static_assert(C80_SMEM <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ void c80_dma(unsigned lds, unsigned voff, const __amdgpu_buffer_rsrc_t rs) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ bf16x8_t c80_lds16(const unsigned char* p) {
+    return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));
+}
+
+// per-tile source geometry of this lane's NA im2col slots: byte offset of the (kh, kw) = (0, 0) tap inside the image and which
+// taps fall inside it (bit kh: row valid, bit 3 + kw: column valid; 0: a pad chunk or a pixel past the image)
+struct C80Geom { int base[C80_NA]; int mask[C80_NA]; };
+
+__global__ __launch_bounds__(256, 1) void conv_c80_kernel(const C80K p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sConst = reinterpret_cast<float*>(smem + C80_CONST_OFF);                 // [3][160]: bias | scale | shift
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, kh2 = lane >> 5;
+    const int HoWo = p.Ho * p.Wo;
+    const int ldx2 = p.ldx * 2;
+    const size_t img_elems = (size_t)p.Hi * p.Wi * p.ldx;
+    const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+    int tcount = 0;
+#define C80_STAMP(I) do { if (p.stamps && tcount == 2 && lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 16 + (I)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+    // transfer slot g = inst * 64 + lane -> (row, chunk) of an 11-chunk row; inst = 4 k + wave
+    int arow[C80_NA], ac16[C80_NA];
+    unsigned boff[C80_NB];
+#pragma unroll
+    for (int k = 0; k < C80_NA; ++k) {
+        const int g = (4 * k + wave) * 64 + lane;
+        arow[k] = g / C80_PCH;
+        const int c = g - arow[k] * C80_PCH;
+        ac16[k] = c < C80_PCH - 1 ? c * 16 : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < C80_NB; ++k) {
+        const int g = (4 * k + wave) * 64 + lane;
+        const int n = g / C80_PCH, c = g - n * C80_PCH;
+        boff[k] = (n < C80_TN && c < C80_PCH - 1) ? (unsigned)(n * (9 * C80_CIN * 2) + c * 16) : C80_OOB;
+    }
+    for (int i = t; i < 3 * C80_TN; i += 256) {
+        const int which = i / C80_TN, c = i - which * C80_TN;
+        const float* src = which == 0 ? p.bias : (which == 1 ? p.scale : p.shift);
+        sConst[i] = src ? src[c] : (which == 1 ? 1.f : 0.f);
+    }
+
+    // slot k of the tile at (img, pix0): one division by Wo through a float reciprocal (exact: pix < 2^22 and (pix + 0.5) / Wo is
+    // at least 0.5 / Wo away from an integer), rows / columns of the three taps that fall inside the image as a 6-bit mask
+    const float rWo = 1.0f / (float)p.Wo;
+    auto geom_slot = [&](int pix0, C80Geom& gm, int k) {
+        const int pix = pix0 + arow[k];
+        const int oy = (int)(((float)pix + 0.5f) * rWo), ox = pix - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        gm.base[k] = (iy0 * p.Wi + ix0) * ldx2 + ac16[k];
+        const int m = (iy0 >= 0 ? 1 : 0) | (iy0 + 1 < p.Hi ? 2 : 0) | (iy0 + 2 < p.Hi ? 4 : 0) |
+                      (ix0 >= 0 ? 8 : 0) | (ix0 + 1 < p.Wi ? 16 : 0) | (ix0 + 2 < p.Wi ? 32 : 0);
+        gm.mask[k] = (ac16[k] >= 0 && pix < HoWo) ? m : 0;
+    };
+    auto geom = [&](int tile, C80Geom& gm) {
+        const int img = tile / p.tiles_per_img;
+        const int pix0 = (tile - img * p.tiles_per_img) * 256;
+#pragma unroll
+        for (int k = 0; k < C80_NA; ++k) geom_slot(pix0, gm, k);
+    };
+    // transfer q (0 .. 10: im2col rows, 11 .. 17: weight rows) of this wave for tap `tap` of the tile described by gm into stage
+    // buffer `buf`; the image descriptor rsx is built once per stage
+    auto issue_q = [&](const C80Geom& gm, const __amdgpu_buffer_rsrc_t rsx, int tap, int buf, int q) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const unsigned la = lbase + buf * C80_STAGE + wave * 1024;
+        if (q < C80_NA) {
+            const int toff = (kh * p.Wi + kw) * ldx2;
+            const int need = (1 << kh) | (8 << kw);
+            c80_dma(la + q * 4096, (gm.mask[q] & need) == need ? (unsigned)(gm.base[q] + toff) : C80_OOB, rsx);
+        } else {
+            const int k = q - C80_NA;
+            c80_dma(la + C80_A_BYTES + k * 4096, boff[k] == C80_OOB ? C80_OOB : boff[k] + tap * (C80_CIN * 2), rsw);
+        }
+    };
+    auto image_rsrc = [&](int img) {               // img: wave-uniform
+        const unsigned long a = (unsigned long)(p.x + (size_t)img * img_elems);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long)hi << 32) | lo), 0, p.imgbytes, 0x00020000);
+    };
+    auto issue = [&](const C80Geom& gm, int img, int tap, int buf) {
+        const __amdgpu_buffer_rsrc_t rsx = image_rsrc(img);
+#pragma unroll
+        for (int q = 0; q < C80_NA + C80_NB; ++q) issue_q(gm, rsx, tap, buf, q);
+    };
+
+    int tile = blockIdx.x;
+    int buf = 0;
+    C80Geom gc, gn;
+    int img_c = tile < p.ntiles ? tile / p.tiles_per_img : 0;
+    if (tile < p.ntiles) {
+        geom(tile, gc);
+        issue(gc, img_c, 0, 0);
+    }
+    __syncthreads();                                   // sConst
+
+    const int arow0 = (wave * 64 + l31) * C80_PITCH + kh2 * 16;      // this lane's fragment rows: pixels / channels l31, k half kh2
+    const int brow0 = C80_A_BYTES + l31 * C80_PITCH + kh2 * 16;
+
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        const int tnext = tile + (int)gridDim.x;
+        const bool has_next = tnext < p.ntiles;
+
+        f32x16_t acc[2][5];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // past the last tile the "next tile" is a dummy whose pixels are all past the image: its transfers return zeros into the
+        // free stage buffer, and nothing in the stage loop is conditional
+        const int img_n = has_next ? tnext / p.tiles_per_img : 0;
+        const int pix0_n = has_next ? (tnext - img_n * p.tiles_per_img) * 256 : HoWo;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            if (s == 0) C80_STAMP(0);
+            if (s == 1) C80_STAMP(3);
+            YH_VMCNT(0);                               // this wave's transfers of stage s (and the previous tile's stores) are done
+            if (s == 0) C80_STAMP(1);
+            if (s == 1) C80_STAMP(4);
+            __builtin_amdgcn_s_barrier();
+            if (s == 0) C80_STAMP(2);
+            if (s == 1) C80_STAMP(5);
+            if (s == 8) C80_STAMP(6);              // ... everyone's are; everyone is out of stage s - 1 and of the epilogue staging
+            // the stage after this one: tap s + 1 of this tile, or tap 0 of the next
+            const __amdgpu_buffer_rsrc_t rsx = image_rsrc(s < 8 ? img_c : img_n);
+            const unsigned char* sb = smem + buf * C80_STAGE;
+            // The stage is ONE basic block of 50 groups {MFMA, at most one fragment read of the next k-step, at most one transfer
+            // of the next stage} pinned by scheduling fences: fragment latency and transfer issue hide under the MFMAs instead
+            // of standing in front of them (one wave per SIMD: nobody else would fill the gap).
+            bf16x8_t fr[2][7];                         // [k-step parity][x0 x1 w0 .. w4]
+#pragma unroll
+            for (int f = 0; f < 7; ++f)
+                fr[0][f] = c80_lds16(sb + (f < 2 ? arow0 + f * 32 * C80_PITCH : brow0 + (f - 2) * 32 * C80_PITCH));
+            if (s < 8) {                               // the next tile's slot arithmetic, a slot or two per stage
+                geom_slot(pix0_n, gn, s);
+                if (s + 8 < C80_NA) geom_slot(pix0_n, gn, s + 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) {
+                const int cu = ks & 1, nx = cu ^ 1;
+#pragma unroll
+                for (int m = 0; m < 10; ++m) {
+                    const int i = m / 5, j = m - i * 5;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[cu][2 + j], fr[cu][i], acc[i][j], 0, 0, 0);
+                    if (ks < 4 && m < 7 && !(YH_C80_ABL & 2))
+                        fr[nx][m] = c80_lds16(sb + (m < 2 ? arow0 + m * 32 * C80_PITCH : brow0 + (m - 2) * 32 * C80_PITCH) + (ks + 1) * 32);
+                    const int g = ks * 10 + m;
+                    if (g < C80_NA + C80_NB && !(YH_C80_ABL & 1)) {      // one transfer per group, all in the first 18: the most time to land
+                        if (s < 8) issue_q(gc, rsx, s + 1, buf ^ 1, g);
+                        else       issue_q(gn, rsx, 0, buf ^ 1, g);
+                    }
+                    if (!(YH_C80_ABL & 8)) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            buf ^= 1;
+        }
+
+        // ---- epilogue through the stage buffer of tap 8 (the other one is receiving the next tile's first stage)
+        C80_STAMP(7);
+        YH_LDS_BARRIER();                              // every wave has read its last fragments
+        C80_STAMP(8);
+        unsigned char* sW = smem + (buf ^ 1) * C80_STAGE + wave * (32 * C80_SP);
+        const int img = img_c;
+        const int pixw = (tile - img * p.tiles_per_img) * 256 + wave * 64;
+#pragma unroll
+        for (int i = 0; i < ((YH_C80_ABL & 4) ? 0 : 2); ++i) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = j * 32 + 8 * q + 4 * kh2;
+                    const float4 cb = *reinterpret_cast<const float4*>(sConst + ch);
+                    const float4 cs = *reinterpret_cast<const float4*>(sConst + C80_TN + ch);
+                    const float4 ct = *reinterpret_cast<const float4*>(sConst + 2 * C80_TN + ch);
+                    float v0 = (acc[i][j][4 * q + 0] + cb.x) * cs.x + ct.x, v1 = (acc[i][j][4 * q + 1] + cb.y) * cs.y + ct.y;
+                    float v2 = (acc[i][j][4 * q + 2] + cb.z) * cs.z + ct.z, v3 = (acc[i][j][4 * q + 3] + cb.w) * cs.w + ct.w;
+                    if (p.act == YH_ACT_SILU) { v0 = silu_fast(v0); v1 = silu_fast(v1); v2 = silu_fast(v2); v3 = silu_fast(v3); }
+                    *reinterpret_cast<uint2*>(sW + l31 * C80_SP + ch * 2) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's rows are complete (LDS executes a wave's accesses in order)
+#pragma unroll
+            for (int tt = 0; tt < 10; ++tt) {
+                const int id = lane + 64 * tt;
+                const int row = id / 20, cc = id - row * 20;
+                const int pix = pixw + i * 32 + row;
+                const uint4 v = *reinterpret_cast<const uint4*>(sW + row * C80_SP + cc * 16);
+                if (pix < HoWo)
+                    *reinterpret_cast<uint4*>(p.out + ((size_t)img * HoWo + pix) * p.ldo + cc * 8) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // rows read before the second half overwrites them
+        }
+        if (YH_C80_ABL & 4) { for (int i = 0; i < 2; ++i) for (int j = 0; j < 5; ++j) asm volatile("" :: "a"(acc[i][j])); }
+        C80_STAMP(9);
+        ++tcount;
+#pragma unroll
+        for (int k = 0; k < C80_NA; ++k) { gc.base[k] = gn.base[k]; gc.mask[k] = gn.mask[k]; }
+        img_c = img_n;
+    }
+    YH_VMCNT(0);                                       // the dummy stage's transfers must not outlive the workgroup's LDS
+}
+
+static unsigned long long* g_c80_stamps = nullptr;
+struct C80Plan { int grid; C80K k; };
+
+bool c80_plan(const yh_conv_desc* d, C80Plan* pl)
+{
+    if (d->mode != YH_CONV_FWD || d->nseg != 1 || d->seg[0].ups) return false;
+    if (d->KH != 3 || d->KW != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2)) return false;
+    if (d->stats || d->bnr_part || d->acc_rows || d->res || d->accumulate || d->nsplit < d->N) return false;     // inference epilogue, one destination
+    if (d->seg[0].C != C80_CIN || d->N != C80_TN) return false;
+    const unsigned long ib = (unsigned long)d->Hi * d->Wi * d->seg[0].ld * 2;       // one image: what an im2col descriptor addresses
+    const unsigned long wb = (unsigned long)d->Npad * 9 * C80_CIN * 2;
+    if (ib >= (1ul << 31) || wb >= (1ul << 31)) return false;
+    C80K& k = pl->k;
+    k.x = d->seg[0].ptr; k.ldx = d->seg[0].ld;
+    k.w = d->w;
+    k.out = d->out0; k.ldo = d->ld0;
+    k.bias = d->bias; k.scale = d->scale; k.shift = d->shift;
+    k.act = d->act;
+    k.B = d->B; k.Hi = d->Hi; k.Wi = d->Wi; k.Ho = d->Ho; k.Wo = d->Wo; k.stride = d->stride; k.pad = d->pad;
+    k.tiles_per_img = (d->Ho * d->Wo + 255) / 256;
+    const long nt = (long)d->B * k.tiles_per_img;
+    if (nt >= (1l << 30)) return false;
+    k.ntiles = (int)nt;
+    k.imgbytes = (unsigned)ib; k.wbytes = (unsigned)wb;
+    k.stamps = g_c80_stamps;
+    int cap = d->grid_cap > 0 ? d->grid_cap : 256;
+    pl->grid = k.ntiles < cap ? k.ntiles : cap;
+    return true;
+}
+
+}  // namespace
+
+/* diagnostics: a device buffer of grid x 4 x 16 uint64 that receives shader-clock stamps of every wave's third tile (NULL: off) */
+extern "C" void yh_c80_set_stamps(void* p) { g_c80_stamps = (unsigned long long*)p; }
+
+int yh_c80_rows(const yh_conv_desc* d)
+{
+    C80Plan pl;
+    return c80_plan(d, &pl) ? pl.grid : 0;
+}
+
+int yh_c80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len)
+{
+    C80Plan pl;
+    YH_CHECK_ARG(c80_plan(d, &pl), "yh_conv_igemm: algo 12 (80 -> 160 channel tap kernel) is not eligible for this descriptor");
+    if (name_out) { snprintf(name_out, name_len, "conv_c80_kernel"); return YH_OK; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_c80_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C80_SMEM);
+        attr_set = true;
+    }
+    conv_c80_kernel<<<dim3(pl.grid), dim3(256), C80_SMEM, (hipStream_t)stream>>>(pl.k);
+    YH_CHECK_LAUNCH("yh_conv_igemm(c80)");
+    return YH_OK;
+}

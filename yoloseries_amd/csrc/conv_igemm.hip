@@ -2506,13 +2506,14 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     }
     long M = (long)d->B * d->Ho * d->Wo;
     YH_CHECK_ARG(M < (1L << 31) - BM, "yh_conv_igemm: too many output pixels");
-    if (d->algo >= 7 && d->algo <= 11) {      // stride-2 data-gradient kernel (conv_dg2.hip) / 3x3 patch kernel (conv_p3.hip) / 80-channel halo kernel (conv_h80.hip) /
+    if (d->algo >= 7 && d->algo <= 12) {      // stride-2 data-gradient kernel (conv_dg2.hip) / 3x3 patch kernel (conv_p3.hip) / 80-channel halo kernel (conv_h80.hip) /
                                               // pointwise kernel (conv_pw.hip) where eligible, else the library default
         if (d->algo == 7 && yh_dg2_rows(d) > 0) return yh_dg2_run(d, stream, name_out, name_len);
         if (d->algo == 8 && yh_p3_rows(d) > 0) return yh_p3_run(d, stream, name_out, name_len);
         if (d->algo == 9 && yh_h80_rows(d) > 0) return yh_h80_run(d, stream, name_out, name_len);
         if (d->algo == 10 && yh_pw_rows(d) > 0) return yh_pw_run(d, stream, name_out, name_len);
         if (d->algo == 11 && yh_wpf_rows(d) > 0) return yh_wpf_run(d, stream, name_out, name_len);
+        if (d->algo == 12 && yh_c80_rows(d) > 0) return yh_c80_run(d, stream, name_out, name_len);
         yh_conv_desc d0 = *d;
         d0.algo = 0;
         return conv_run(&d0, stream, name_out, name_len);
