@@ -39,9 +39,12 @@ struct C80K {
 };
 
 constexpr int C80_CIN = 80, C80_TN = 160;
-constexpr int C80_PCH = 11, C80_PITCH = C80_PCH * 16;            // 176-byte LDS rows
+#ifndef YH_C80_PCH
+#define YH_C80_PCH 11
+#endif
+constexpr int C80_PCH = YH_C80_PCH, C80_PITCH = C80_PCH * 16;    // 176-byte LDS rows (10: unpadded rows, 10 % fewer transfers, two-way conflicts on 16-lane groups)
 constexpr int C80_A_INST = 256 * C80_PCH / 64;                   // 44 transfers: the tap's rows of 256 pixels
-constexpr int C80_B_INST = (C80_TN * C80_PCH + 63) / 64;         // 28 transfers: the tap's weight rows
+constexpr int C80_B_INST = ((C80_TN * C80_PCH + 63) / 64 + 3) / 4 * 4;   // 28 transfers: the tap's weight rows (whole transfers per wave)
 constexpr int C80_A_BYTES = C80_A_INST * 1024;
 constexpr int C80_B_BYTES = C80_B_INST * 1024;
 constexpr int C80_STAGE = C80_A_BYTES + C80_B_BYTES;             // 72 KiB
@@ -91,13 +94,13 @@ __global__ __launch_bounds__(256, 1) void conv_c80_kernel(const C80K p)
         const int g = (4 * k + wave) * 64 + lane;
         arow[k] = g / C80_PCH;
         const int c = g - arow[k] * C80_PCH;
-        ac16[k] = c < C80_PCH - 1 ? c * 16 : -1;
+        ac16[k] = c < C80_CIN / 8 ? c * 16 : -1;
     }
 #pragma unroll
     for (int k = 0; k < C80_NB; ++k) {
         const int g = (4 * k + wave) * 64 + lane;
         const int n = g / C80_PCH, c = g - n * C80_PCH;
-        boff[k] = (n < C80_TN && c < C80_PCH - 1) ? (unsigned)(n * (9 * C80_CIN * 2) + c * 16) : C80_OOB;
+        boff[k] = (n < C80_TN && c < C80_CIN / 8) ? (unsigned)(n * (9 * C80_CIN * 2) + c * 16) : C80_OOB;
     }
     for (int i = t; i < 3 * C80_TN; i += 256) {
         const int which = i / C80_TN, c = i - which * C80_TN;
