@@ -281,6 +281,14 @@ typedef struct yh_bn_part {
 int yh_bn_finalize_parts(const yh_bn_part* parts, int nparts, int64_t count, yh_stream stream);
 int yh_bn_bwd_finalize_parts(const yh_bn_part* parts, int nparts, int64_t M, yh_stream stream);
 int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts, yh_stream stream);
+/* yh_bn_finalize_parts + yh_bn_silu_apply_parts (or, with one part, yh_bn_finalize + yh_bn_silu_apply incl. the residual) as ONE
+ * launch: the first workgroups of the grid finalize 16 channels each and publish ws, the others wait for them before their first
+ * row is scaled (in-order workgroup dispatch: see the kernel).  Same results bit for bit (same summation order).  `sync`:
+ * YH_BN_FIN_SYNC_WORDS int32 of device memory owned by this (layer, pass), zero when first used and never touched by anything
+ * else — the launches keep their own books in it.  Reference: one nn.BatchNorm2d forward in training mode, utils/layer_tools.py:39-53. */
+#define YH_BN_FIN_SYNC_WORDS (128 * 32 + 2)
+int yh_bn_silu_apply_fin(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts,
+                         const yh_bf16* res, int ldr, int32_t* sync, yh_stream stream);
 int yh_bn_silu_bwd_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts,
                                yh_bf16* gy, int ldgy, yh_stream stream);
 /* column sums of a bf16 matrix (bias gradient of Detect): out[c] += sum_m g[m][c] */

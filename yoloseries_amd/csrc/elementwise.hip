@@ -31,10 +31,10 @@ constexpr int FIN_NT = FIN_CPB * FIN_RG;
 #endif
 constexpr int FIN_U = YH_FIN_U;          // independent row loads in flight per lane
 
-template <int NW>
+template <int NW, int RG = FIN_RG>
 __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int nblk, int ld, int C, int c, double* out /*NW*/)
 {
-    __shared__ double sred[FIN_RG][NW][FIN_CPB];
+    __shared__ double sred[RG][NW][FIN_CPB];
     const int lc = threadIdx.x & (FIN_CPB - 1), rg = threadIdx.x / FIN_CPB;
     double acc[NW];
 #pragma unroll
@@ -42,11 +42,11 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
     if (c < C) {
         // branch-free batches (rows past the end are clamped and masked): a predicated load per row makes the compiler wait for
         // each one before the next is issued, which was most of the 6 us these launches took
-        for (int b = rg; b < nblk; b += FIN_U * FIN_RG) {
+        for (int b = rg; b < nblk; b += FIN_U * RG) {
             float v[FIN_U][NW];
 #pragma unroll
             for (int u = 0; u < FIN_U; ++u) {
-                const int r = b + FIN_RG * u;
+                const int r = b + RG * u;
                 const size_t rc = (size_t)(r < nblk ? r : nblk - 1);
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v[u][w] = slab[(rc * NW + w) * ld + c];
@@ -54,7 +54,7 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
 #pragma unroll
             for (int u = 0; u < FIN_U; ++u)
 #pragma unroll
-                for (int w = 0; w < NW; ++w) acc[w] += (b + FIN_RG * u < nblk) ? (double)v[u][w] : 0.0;
+                for (int w = 0; w < NW; ++w) acc[w] += (b + RG * u < nblk) ? (double)v[u][w] : 0.0;
         }
     }
 #pragma unroll
@@ -64,12 +64,13 @@ __device__ __forceinline__ void slab_colsum(const float* __restrict__ slab, int 
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             double s = 0.0;
-            for (int i = 0; i < FIN_RG; ++i) s += sred[i][w][lc];
+            for (int i = 0; i < RG; ++i) s += sred[i][w][lc];
             out[w] = s;
         }
     }
 }
 
+template <int RG = FIN_RG>
 __device__ __forceinline__ void bn_finalize_body(int cb, const float* __restrict__ stats, int nblk, int ldstat, int C, double count,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float* running_mean, float* running_var, int64_t* num_batches,
@@ -86,7 +87,7 @@ __device__ __forceinline__ void bn_finalize_body(int cb, const float* __restrict
     int64_t nb = 0;
     if (fin && c == 0 && num_batches) nb = *num_batches;
     double sq[2];
-    slab_colsum<2>(stats, nblk, ldstat, C, c, sq);
+    slab_colsum<2, RG>(stats, nblk, ldstat, C, c, sq);
     if (threadIdx.x >= FIN_CPB) return;
     if (c == 0 && num_batches) *num_batches = nb + 1;
     if (c >= C) return;
@@ -242,6 +243,93 @@ __global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int l
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e] * sc[e] + sh[e]);
         *reinterpret_cast<uint4*>(out + m * ldo) = pack8(f);
+    }
+}
+
+// bn_silu_apply(_parts) with the yh_bn_finalize(_parts) launch folded in (yh_bn_silu_apply_fin): the first `nfin` workgroups of the
+// grid finalize 16 channels each (column sums of the slab -> ws, running statistics), publish that with a release + counter, and
+// exit; the others request their first row, wait for the counter, and run the pass.  Workgroups are dispatched in index order, so
+// the finalize workgroups are resident before any waiter can occupy the chip (the forward-progress assumption of every stream-K
+// fix-up).  sync = { 64 copies of: finalize workgroups done (cumulative over launches) | 64 first-level exit tickets | their count | launches completed }: the
+// last workgroup to leave bumps `launches`, which a later launch reads to know the count it has to wait for — no reset launch.
+constexpr int FINF_RG = EW_THREADS / FIN_CPB;      // the finalize workgroups run with the pass's block size
+constexpr int FINF_COPIES = 64;                    // copies of the finalize counter, one per 128-byte line (YH_BN_FIN_SYNC_WORDS = 128 * 32 + 2)
+__global__ __launch_bounds__(EW_THREADS) void bn_silu_apply_fin_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M, double count,
+                                                                       const uint16_t* __restrict__ res, int ldr, int* sync, int nfin)
+{
+    if ((int)blockIdx.x < nfin) {
+        int cb;
+        const yh_bn_part& q = P.p[fin_part_of(P, blockIdx.x, cb)];
+        bn_finalize_body<FINF_RG>(cb, q.slab, q.nblk, q.ldslab, q.C, count, q.gamma, q.beta, q.running_mean, q.running_var, q.num_batches,
+                                  q.eps, q.momentum, q.ws);
+        __syncthreads();
+        __threadfence();                                           // ws (and the running statistics) before the counters
+        if (threadIdx.x < FINF_COPIES)                             // one counter copy per 128-byte line: the waiters spread over them
+            __hip_atomic_fetch_add(&sync[threadIdx.x * 32], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        const long T = (long)(gridDim.x - nfin) * blockDim.x;
+        const long rstep = T / cpr;
+        const long gid = (long)(blockIdx.x - nfin) * blockDim.x + threadIdx.x;
+        const bool live = gid < rstep * cpr;
+        long m = live ? gid / cpr : 0;
+        const int c = live ? (int)(gid - m * cpr) * 8 : 0;
+        int cp;
+        const int k = part_of(P, c, cp);
+        const float* __restrict__ ws = P.p[k].ws;
+        const int Cp = P.p[k].C;
+        uint16_t* __restrict__ out = P.p[k].out + cp;
+        const int ldo = P.p[k].ldo;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (live && m < M) v = *reinterpret_cast<const uint4*>(y + m * ldy + c);     // in flight while the constants are made
+        if (threadIdx.x == 0) {
+            const int want = (__hip_atomic_load(&sync[2 * FINF_COPIES * 32 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1) * nfin;
+            const int* flag = sync + (blockIdx.x % FINF_COPIES) * 32;
+            int spins = 0;
+            // relaxed polls: an acquire per poll would invalidate the XCD's L2 every time (measured: 170 us per launch).  ws is read
+            // below with plain loads: no cache of this XCD can hold a line of it (caches are clean at kernel start and nobody
+            // reads ws before the counter says it is written; device-coherent loads of ws from every thread cost 40 us per launch)
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0 && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(16);
+        }
+        __syncthreads();
+        if (live) {
+            float sc[8], sh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sc[e] = ws[cp + e];
+                sh[e] = ws[Cp + cp + e];
+            }
+            for (; m < M; m += rstep) {
+                float f[8];
+                unpack8(v, f);
+                const long mn = m + rstep;
+                if (mn < M) v = *reinterpret_cast<const uint4*>(y + mn * ldy + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e] * sc[e] + sh[e]);
+                if (res) {
+                    uint4 rv = *reinterpret_cast<const uint4*>(res + m * ldr + c);
+                    float g[8];
+                    unpack8(rv, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = bf_round(f[e]) + g[e];
+                }
+                *reinterpret_cast<uint4*>(out + m * ldo) = pack8(f);
+            }
+        }
+    }
+    // the last workgroup out closes the launch — found through 64 first-level tickets (2 000 increments of ONE word cost 40 us)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int G = (int)gridDim.x, i = (int)blockIdx.x % FINF_COPIES;
+        int* tick = sync + (FINF_COPIES + i) * 32;
+        int* top = sync + 2 * FINF_COPIES * 32;
+        if (__hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (G - i + FINF_COPIES - 1) / FINF_COPIES - 1) {
+            __hip_atomic_store(tick, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (G < FINF_COPIES ? G : FINF_COPIES) - 1) {
+                __hip_atomic_store(top, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(top + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -1039,6 +1127,28 @@ extern "C" int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, cons
     const int cpr = C / 8;
     hipLaunchKernelGGL(bn_silu_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, ldy, P, cpr, (long)M);
     YH_CHECK_LAUNCH("yh_bn_silu_apply_parts");
+    return YH_OK;
+}
+
+extern "C" int yh_bn_silu_apply_fin(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts,
+                                    const yh_bf16* res, int ldr, int32_t* sync, yh_stream stream)
+{
+    PartsK P;
+    int C = 0;
+    int rc = parts_pack("yh_bn_silu_apply_fin", parts, nparts, 2, &P, &C);
+    if (rc == YH_OK) rc = parts_pack("yh_bn_silu_apply_fin", parts, nparts, 0, &P, &C);
+    if (rc != YH_OK) return rc;
+    YH_CHECK_ARG(M > 0 && sync, "yh_bn_silu_apply_fin: bad M / sync");
+    YH_CHECK_SLICE("yh_bn_silu_apply_fin", y, ldy, C);
+    if (res) {
+        YH_CHECK_ARG(nparts == 1, "yh_bn_silu_apply_fin: a residual needs a single part");
+        YH_CHECK_SLICE("yh_bn_silu_apply_fin", res, ldr, C);
+    }
+    const int cpr = C / 8;
+    const int nfin = P.bend[nparts - 1];
+    hipLaunchKernelGGL(bn_silu_apply_fin_kernel, dim3(nfin + ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       y, ldy, P, cpr, (long)M, (double)M, res, ldr, sync, nfin);
+    YH_CHECK_LAUNCH("yh_bn_silu_apply_fin");
     return YH_OK;
 }
 

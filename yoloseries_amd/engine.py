@@ -122,6 +122,11 @@ def tuning_source():
 BN_ACC = os.environ.get("YH_BN_ACC", "0") == "1"
 TUNE_ITERS = max(1, int(os.environ.get("YH_TUNE_ITERS", "3")))   # launches timed per candidate (tools/make_tune_defaults.sh: 12)
 ACC_ROWS = int(os.environ.get("YH_ACC_ROWS", "8"))
+# YH_BN_FIN_FUSE=1: the forward BatchNorm finalize launch of a layer rides in its BN+SiLU pass (yh_bn_silu_apply_fin: the grid's first
+# workgroups finalize, the others wait for them) — one launch and one kernel boundary less per layer.  Measured on the YOLOv5s step it
+# is 1 % SLOWER (12.29 vs 12.14 ms): finalize + publish + wake-up inside the pass cost ~7 us against 4.7 us for the launch plus
+# 1.5 us for the boundary it replaces (profiles/r04_step_experiments.txt, q) — off by default.
+BN_FIN_FUSE = os.environ.get("YH_BN_FIN_FUSE", "0") == "1"
 MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct layers: one BN+SiLU pass for all parts
 # YH_WGRAD_PARTIAL=1: the weight gradients' split-M partial tiles go to a workspace with plain stores and are summed in split
 # order by a second kernel (yh_wgrad_desc.partial) instead of fp32 atomics: BIT-REPRODUCIBLE gradients.  Measured on the YOLOv5s
@@ -860,6 +865,10 @@ class Program:
                 self.cmd_train.append((L.yh_bn_silu_apply_parts, (op.y.t.data_ptr(), op.y.C, M, parts_arr, len(op.parts)), op.name,
                                        ('yh_bn_silu_apply_parts', 0, 4.0 * M * op.N)))
 
+        self.cmd_train_src = self.cmd_train          # finalize launches spelled out: what the frozen-BatchNorm program is derived from
+        if BN_FIN_FUSE and not BN_ACC:
+            self.cmd_train = self._fuse_finalize(self.cmd_train)
+
         if BN_ACC:
             self.acc_fwd = torch.zeros(max(self._acc_fwd_elems, 2), dtype=torch.int64, device=self.dev)
             cmds = [('fill', self.acc_fwd, None, ('yh_fill_u32', 0, 8.0 * self.acc_fwd.numel()))]
@@ -879,6 +888,40 @@ class Program:
                     st = self.op_state[op.name]
                     st['desc_train'].stats = self.acc_fwd.data_ptr() + 8 * st['acc_off']
             self.cmd_train = cmds
+
+    def _fuse_finalize(self, cmds):
+        """(yh_bn_finalize, yh_bn_silu_apply) and (yh_bn_finalize_parts, yh_bn_silu_apply_parts) pairs of the forward program as
+        one yh_bn_silu_apply_fin launch each"""
+        L, out, i = self.L, [], 0
+        self._fin_sync = []
+        while i < len(cmds):
+            cmd = cmds[i]
+            nxt = cmds[i + 1] if i + 1 < len(cmds) else None
+            if nxt is not None and cmd[0] is L.yh_bn_finalize and nxt[0] is L.yh_bn_silu_apply and nxt[1][2] == cmd[1][12]:
+                stats, nblk, ldstat, n, M, gamma, beta, rm, rv, nbt, eps, mom, ws = cmd[1]
+                y, ldy, _ws, _n, _M, dst, ldo, res, ldr = nxt[1]
+                pa = (BnPart * 1)()
+                q = pa[0]
+                q.ws, q.C, q.out, q.ldo = ws, n, dst, ldo
+                q.slab, q.nblk, q.ldslab = stats, nblk, ldstat
+                q.gamma, q.beta, q.eps, q.momentum = gamma, beta, eps, mom
+                q.running_mean, q.running_var, q.num_batches = rm, rv, nbt
+                args = (y, ldy, M, pa, 1, res, ldr)
+            elif nxt is not None and cmd[0] is L.yh_bn_finalize_parts and nxt[0] is L.yh_bn_silu_apply_parts and nxt[1][3] is cmd[1][0]:
+                pa, nparts, M = cmd[1]
+                y, ldy, _M, _pa, _np = nxt[1]
+                args = (y, ldy, M, pa, nparts, None, 0)
+            else:
+                out.append(cmd)
+                i += 1
+                continue
+            sync = torch.zeros(128 * 32 + 2, dtype=torch.int32, device=self.dev)       # YH_BN_FIN_SYNC_WORDS
+            self._fin_sync.append(sync)
+            self._keep.append(pa)
+            fam, _, nbytes = nxt[3]
+            out.append((L.yh_bn_silu_apply_fin, args + (sync.data_ptr(),), nxt[2], ('yh_bn_silu_apply_fin', 0, nbytes + cmd[3][2])))
+            i += 2
+        return out
 
     # -- forward ---------------------------------------------------------------------------
     def _kernel_name(self, d):
@@ -980,7 +1023,7 @@ class Program:
         batch statistics -> constants, running-statistics update — give way to yh_bn_frozen (constants from the running
         statistics); the conv kernels still emit their partial sums, nobody reads them"""
         L, out = self.L, []
-        for cmd in self.cmd_train:
+        for cmd in getattr(self, "cmd_train_src", self.cmd_train):
             fn, args = cmd[0], cmd[1]
             if fn is L.yh_bn_finalize:
                 _stats, _nblk, _ld, n, _M, gamma, beta, rm, rv, _nbt, eps, _mom, ws = args
