@@ -299,9 +299,13 @@ def worker(args):
         ema = ExponentialMovingAverageModel(model)
         dp = DataParallelGrads(model) if (world > 1 or force_dp) else None
 
+        prefetch = hasattr(lossf, "prefetch_assign") and os.environ.get("YH_LOSS_PREFETCH", "0") == "1"    # measured slower: r04_step_experiments.txt (r)
+
         def step():
             # YOLOXLoss converts the target boxes to xywh IN PLACE like the reference (loss/yolox_loss.py:70-75): every step
             # gets a fresh copy, as a data loader would deliver
+            if prefetch:
+                lossf.prefetch_assign(t)            # the target assignment on a side stream beside the forward pass
             out = lossf(model(x), t.clone() if args.workload == "yolox" else t)
             out["tot_loss"].backward()
             opt.clip_grad_norm_(10.0)

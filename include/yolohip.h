@@ -405,6 +405,11 @@ int yh_v5_assign(const yh_v5loss_desc* d, const float* targets,
  * result (fp32[8]): tot, iou, cof, cls, tar_nums, 0,0,0  (iou/cof/cls already x B)
  * saved: opaque per-call state for the backward, yh_v5loss_saved_bytes()         */
 size_t yh_v5loss_saved_bytes(const yh_v5loss_desc* d);
+/* The assignment step of the forward loss alone (it depends on the targets only: loss/yolov5_loss.py:142-214 is called per stage with
+ * `targets` before any prediction is touched), written into `saved`; a following yh_v5_loss_fwd with targets = NULL and the same
+ * geometry (B, maxbox, anchors, H, W) skips its own assignment and reads this one.  Lets a training loop run the assignment on
+ * another stream beside the network's forward pass; ordering the two streams is the caller's business. */
+int yh_v5_loss_assign(const yh_v5loss_desc* d, const float* targets, void* saved, yh_stream stream);
 int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds, const float* targets,
                    double* balances, float* result, void* saved, void* ws, yh_stream stream);
 /* Backward: gpreds[s] same geometry/dtype as preds[s], fully overwritten.

@@ -184,6 +184,10 @@ class Training:
                 boundary = (i + 1) % self.accumulate == 0
                 ctx = self.dp.no_sync() if (self.dp is not None and not boundary) else _Null()
                 with ctx:
+                    if hyp.get('prefetch_assign', False):
+                        # the target assignment on a side stream beside the forward pass (it needs the targets only); measured on the
+                        # YOLOv5s step it does not pay (profiles/r04_step_experiments.txt, r): off unless the configuration asks for it
+                        self.loss_fcn.prefetch_assign(x['ann'])
                     stage_preds = self.model(x['img'])
                     loss_dict = self.loss_fcn(stage_preds, x['ann'])
                     loss_dict['tot_loss'].backward()

@@ -183,6 +183,7 @@ _SIGS = {
     "yh_v5loss_saved_bytes": (_sz, [C.POINTER(V5LossDesc)]),
     "yh_v5_assign": (_i32, [C.POINTER(V5LossDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "yh_v5_loss_fwd": (_i32, [C.POINTER(V5LossDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "yh_v5_loss_assign": (_i32, [C.POINTER(V5LossDesc), _vp, _vp, _vp]),
     "yh_v5_loss_bwd": (_i32, [C.POINTER(V5LossDesc), C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), _vp, _vp]),
     "yh_yolox_saved_bytes": (_sz, [C.POINTER(YoloxDesc)]),
     "yh_yolox_ws_bytes": (_sz, [C.POINTER(YoloxDesc)]),

@@ -615,12 +615,30 @@ extern "C" int yh_v5_assign(const yh_v5loss_desc* d, const float* targets, int32
     return YH_OK;
 }
 
+/* the assignment step of yh_v5_loss_fwd alone, into the `saved` state of a later yh_v5_loss_fwd(targets = NULL) call with the same
+ * geometry: it depends on the targets only, so a training loop can run it on another stream beside the network's forward pass */
+extern "C" int yh_v5_loss_assign(const yh_v5loss_desc* d, const float* targets, void* saved, yh_stream stream)
+{
+    int rc = check_desc(d, "yh_v5_loss_assign");
+    if (rc) return rc;
+    YH_CHECK_ARG(targets && saved, "yh_v5_loss_assign: null pointer");
+    LossK k; k.d = *d; k.L = make_layout(*d);
+    char* sv = (char*)saved;
+    int32_t* head = (int32_t*)(sv + k.L.head);
+    rc = yh_fill_u32(head, 0xffffffffu, (int64_t)((k.L.total - k.L.head) / 4), stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(v5_assign_kernel, dim3(d->num_stage), dim3(1024), 0, (hipStream_t)stream, k, targets,
+                       (int32_t*)(sv + k.L.count), (float*)(sv + k.L.tbox), (int32_t*)(sv + k.L.tidx));
+    YH_CHECK_LAUNCH("yh_v5_loss_assign");
+    return YH_OK;
+}
+
 extern "C" int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds, const float* targets,
                               double* balances, float* result, void* saved, void* ws, yh_stream stream)
 {
     int rc = check_desc(d, "yh_v5_loss_fwd");
     if (rc) return rc;
-    YH_CHECK_ARG(preds && targets && balances && result && saved && ws, "yh_v5_loss_fwd: null pointer");
+    YH_CHECK_ARG(preds && balances && result && saved && ws, "yh_v5_loss_fwd: null pointer");
     for (int s = 0; s < d->num_stage; ++s) YH_CHECK_ARG(preds[s] && yh_aligned16(preds[s]), "yh_v5_loss_fwd: preds[%d] null/unaligned", s);
     hipStream_t st = (hipStream_t)stream;
     LossK k; k.d = *d; k.L = make_layout(*d);
@@ -633,10 +651,10 @@ extern "C" int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds,
     int32_t* next = (int32_t*)(sv + k.L.next);
     int32_t* head = (int32_t*)(sv + k.L.head);
     double* part = (double*)ws;
-    size_t head_elems = (k.L.total - k.L.head) / 4;
-    rc = yh_fill_u32(head, 0xffffffffu, (int64_t)head_elems, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(v5_assign_kernel, dim3(d->num_stage), dim3(1024), 0, st, k, targets, count, tbox, tidx);
+    if (targets) {                      // NULL: yh_v5_loss_assign has filled `saved` for this geometry (the caller orders the streams)
+        rc = yh_v5_loss_assign(d, targets, saved, stream);
+        if (rc) return rc;
+    }
     int nb_pos = (k.L.cap + 15) / 16;
     if (nb_pos > PART_BLOCKS) nb_pos = PART_BLOCKS;
     int nb_obj = PART_BLOCKS;
