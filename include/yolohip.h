@@ -281,6 +281,11 @@ typedef struct yh_bn_part {
 int yh_bn_finalize_parts(const yh_bn_part* parts, int nparts, int64_t count, yh_stream stream);
 int yh_bn_bwd_finalize_parts(const yh_bn_part* parts, int nparts, int64_t M, yh_stream stream);
 int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts, yh_stream stream);
+/* yh_bn_bwd_finalize_parts for slabs with thousands of rows: the rows are summed in up to 16 slices by as many workgroups per 16
+ * channels, the last one to arrive adds the slices in order (deterministic; sums associate differently from the unsplit launch, in
+ * fp64).  scratch: yh_bn_fin_split_scratch_bytes() of device memory, zero before the first use, not shared between streams. */
+size_t yh_bn_fin_split_scratch_bytes(void);
+int yh_bn_bwd_finalize_parts_split(const yh_bn_part* parts, int nparts, int64_t M, void* scratch, yh_stream stream);
 /* yh_bn_finalize_parts + yh_bn_silu_apply_parts (or, with one part, yh_bn_finalize + yh_bn_silu_apply incl. the residual) as ONE
  * launch: the first workgroups of the grid finalize 16 channels each and publish ws, the others wait for them before their first
  * row is scaled (in-order workgroup dispatch: see the kernel).  Same results bit for bit (same summation order).  `sync`:

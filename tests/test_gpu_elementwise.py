@@ -403,3 +403,38 @@ def test_engine_with_the_finalize_folded_into_the_pass(dev):
             assert (a - b).abs().max() <= 2e-3 * b.abs().max() + 1e-6
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k
+
+
+@pytest.mark.parametrize("Cs,nblk", [((64,), 12800), ((32, 32), 3200), ((128, 40), 1111), ((16,), 100)])
+def test_bn_bwd_finalize_in_row_slices(dev, Cs, nblk):
+    """yh_bn_bwd_finalize_parts_split (rows of the slab summed in slices by several workgroups per 16 channels, the last to arrive
+    adds the slices and finalizes) against yh_bn_bwd_finalize_parts: fp64 sums that associate differently; twice on the same
+    scratch (the launches leave it clean)"""
+    import ctypes as C
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import lib
+    g = torch.Generator().manual_seed(41)
+    M = 100000
+    scratch = torch.zeros(int(lib().yh_bn_fin_split_scratch_bytes()), dtype=torch.uint8, device=dev)
+    ref, new = [], []
+    for C_ in Cs:
+        slab = torch.randn(nblk, 2, C_, generator=g).to(dev)
+        ws = torch.cat([torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g), torch.randn(C_, generator=g), torch.rand(C_, generator=g) + 0.5]).to(dev)
+        def outs():
+            return dict(dgamma=torch.zeros(C_, device=dev), dbeta=torch.zeros(C_, device=dev), coef=torch.zeros(2 * C_, device=dev))
+        a, b = outs(), outs()
+        ref.append(dict(ws=ws, C=C_, slab=slab.data_ptr(), nblk=nblk, _t=slab, **a))
+        new.append(dict(ws=ws, C=C_, slab=slab.data_ptr(), nblk=nblk, _t=slab, **b))
+    strip = lambda ps: [{k: v for k, v in q.items() if k != "_t"} for q in ps]
+    hipk.bn_bwd_finalize_parts(strip(ref), M)
+    for _ in range(2):
+        for q in new:
+            for k in ("dgamma", "dbeta", "coef"):
+                q[k].zero_()
+        arr = hipk._bn_parts(strip(new))
+        hipk.check(lib().yh_bn_bwd_finalize_parts_split(arr, len(new), M, scratch.data_ptr(), hipk._st()), "yh_bn_bwd_finalize_parts_split")
+        torch.cuda.synchronize()
+        for qa, qb in zip(ref, new):
+            for k in ("dgamma", "dbeta", "coef"):
+                torch.testing.assert_close(qb[k], qa[k], rtol=1e-5, atol=1e-5 * qa[k].abs().max().item())
+        assert int(scratch[:4096].view(torch.int32).abs().sum()) == 0

@@ -158,6 +158,8 @@ _SIGS = {
     "yh_bn_finalize_parts": (_i32, [_vp, _i32, _i64, _vp]),
     "yh_bn_bwd_finalize_parts": (_i32, [_vp, _i32, _i64, _vp]),
     "yh_bn_silu_apply_parts": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp]),
+    "yh_bn_fin_split_scratch_bytes": (_sz, []),
+    "yh_bn_bwd_finalize_parts_split": (_i32, [_vp, _i32, _i64, _vp, _vp]),
     "yh_bn_silu_apply_fin": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
     "yh_bn_silu_bwd_apply_parts": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
     "yh_bn_silu_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _vp]),

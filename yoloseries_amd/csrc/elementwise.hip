@@ -531,6 +531,50 @@ __global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_parts_kernel(const Par
     bn_bwd_finalize_body(cb, q.slab, q.nblk, q.C, M, q.ws, q.dgamma, q.dbeta, q.coef);
 }
 
+// Backward finalize of slabs with thousands of rows (the 160 x 160 layers' data gradients leave 12 800 of them): the rows are cut
+// into Z slices, one workgroup per (16 channels, slice); a slice's sums go to a scratch row, and the LAST workgroup of a channel
+// group to arrive (a ticket per group: no waiting) adds the Z rows in slice order — deterministic — and finalizes.  One launch,
+// C / 16 x Z workgroups instead of C / 16 walking 50 batches of rows each (20 - 30 us per launch on an otherwise idle GPU).
+constexpr int FINZ_MAX = 16;                       // slices
+constexpr int FINZ_GROUPS = 2048 / FIN_CPB;        // channel groups a launch may have
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_split_kernel(const PartsK P, double M, int Z, int* tickets, double* partial)
+{
+    __shared__ int s_last;
+    int cb;
+    const yh_bn_part& q = P.p[fin_part_of(P, blockIdx.x, cb)];
+    const int g = blockIdx.x, z = blockIdx.y, lc = threadIdx.x & (FIN_CPB - 1);
+    const int c = cb * FIN_CPB + lc;
+    const long r0 = (long)q.nblk * z / Z, r1 = (long)q.nblk * (z + 1) / Z;
+    float mu = 0.f, is = 0.f;
+    if (threadIdx.x < FIN_CPB && c < q.C) { mu = q.ws[2 * q.C + c]; is = q.ws[3 * q.C + c]; }
+    double s[2];
+    slab_colsum<2>(q.slab + (size_t)r0 * 2 * q.C, (int)(r1 - r0), q.C, q.C, c, s);
+    double* mine = partial + ((size_t)g * FINZ_MAX + z) * 2 * FIN_CPB;
+    if (threadIdx.x < FIN_CPB) {
+        mine[lc] = s[0];
+        mine[FIN_CPB + lc] = s[1];
+        __threadfence();                           // the slice's sums before the ticket
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(&tickets[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == Z - 1;
+        if (s_last) __hip_atomic_store(&tickets[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= FIN_CPB || c >= q.C) return;
+    double t0 = 0.0, t1 = 0.0;
+    for (int i = 0; i < Z; ++i) {                  // device-coherent loads: the rows were written by other workgroups of this launch
+        const double* row = partial + ((size_t)g * FINZ_MAX + i) * 2 * FIN_CPB;
+        t0 += __hip_atomic_load(row + lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t1 += __hip_atomic_load(row + FIN_CPB + lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    t1 = (double)is * (t1 - (double)mu * t0);      // sum(dz*y) -> sum(dz*xhat)
+    if (q.dbeta) q.dbeta[c] = (float)t0;
+    if (q.dgamma) q.dgamma[c] = (float)t1;
+    if (q.coef) { q.coef[c] = (float)(t0 / M); q.coef[q.C + c] = (float)(t1 / M); }
+}
+
 __global__ __launch_bounds__(FIN_NT) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out)
 {
     const int c = blockIdx.x * FIN_CPB + (threadIdx.x & (FIN_CPB - 1));
@@ -1113,6 +1157,28 @@ extern "C" int yh_bn_bwd_finalize_parts(const yh_bn_part* parts, int nparts, int
     YH_CHECK_ARG(M > 0, "yh_bn_bwd_finalize_parts: bad M");
     hipLaunchKernelGGL(bn_bwd_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(FIN_NT), 0, (hipStream_t)stream, P, (double)M);
     YH_CHECK_LAUNCH("yh_bn_bwd_finalize_parts");
+    return YH_OK;
+}
+
+/* bytes of the scratch yh_bn_bwd_finalize_parts_split needs (zero before the first use; the launches leave it clean) */
+extern "C" size_t yh_bn_fin_split_scratch_bytes(void) { return 4096 + (size_t)FINZ_GROUPS * FINZ_MAX * 2 * FIN_CPB * sizeof(double); }
+
+extern "C" int yh_bn_bwd_finalize_parts_split(const yh_bn_part* parts, int nparts, int64_t M, void* scratch, yh_stream stream)
+{
+    PartsK P;
+    int C = 0;
+    const int rc = parts_pack("yh_bn_bwd_finalize_parts_split", parts, nparts, 3, &P, &C);
+    if (rc != YH_OK) return rc;
+    YH_CHECK_ARG(M > 0 && scratch && yh_aligned16(scratch), "yh_bn_bwd_finalize_parts_split: bad M / scratch");
+    int nmax = 0;
+    for (int i = 0; i < nparts; ++i) nmax = parts[i].nblk > nmax ? parts[i].nblk : nmax;
+    int Z = nmax / (FIN_U * FIN_RG);               // a slice keeps at least one full batch of rows
+    Z = Z < 1 ? 1 : (Z > FINZ_MAX ? FINZ_MAX : Z);
+    const int groups = P.bend[nparts - 1];
+    YH_CHECK_ARG(groups <= FINZ_GROUPS, "yh_bn_bwd_finalize_parts_split: more than %d channel groups", FINZ_GROUPS);
+    hipLaunchKernelGGL(bn_bwd_finalize_split_kernel, dim3(groups, Z), dim3(FIN_NT), 0, (hipStream_t)stream, P, (double)M, Z,
+                       (int*)scratch, (double*)((char*)scratch + 4096));
+    YH_CHECK_LAUNCH("yh_bn_bwd_finalize_parts_split");
     return YH_OK;
 }
 

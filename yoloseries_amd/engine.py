@@ -127,6 +127,11 @@ ACC_ROWS = int(os.environ.get("YH_ACC_ROWS", "8"))
 # is 1 % SLOWER (12.29 vs 12.14 ms): finalize + publish + wake-up inside the pass cost ~7 us against 4.7 us for the launch plus
 # 1.5 us for the boundary it replaces (profiles/r04_step_experiments.txt, q) — off by default.
 BN_FIN_FUSE = os.environ.get("YH_BN_FIN_FUSE", "0") == "1"
+# YH_FIN_SPLIT_MIN=<rows>: backward finalize launches whose slab has at least this many rows are cut into row slices
+# (yh_bn_bwd_finalize_parts_split); 0 (default): never — the two launches per YOLOv5s step it applies to take 15 us either way, and the
+# long finalize launches of the trace (20 - 30 us) are short slabs waiting behind a weight gradient's transfers on the same CUs
+# (profiles/r04_step_experiments.txt, s)
+FIN_SPLIT_MIN = int(os.environ.get("YH_FIN_SPLIT_MIN", "0"))
 MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct layers: one BN+SiLU pass for all parts
 # YH_WGRAD_PARTIAL=1: the weight gradients' split-M partial tiles go to a workspace with plain stores and are summed in split
 # order by a second kernel (yh_wgrad_desc.partial) instead of fp32 atomics: BIT-REPRODUCIBLE gradients.  Measured on the YOLOv5s
@@ -889,6 +894,12 @@ class Program:
                     st['desc_train'].stats = self.acc_fwd.data_ptr() + 8 * st['acc_off']
             self.cmd_train = cmds
 
+    def _fin_split_scratch(self):
+        """scratch of the split backward finalize launches (main stream only: one buffer for all layers)"""
+        if getattr(self, "_fin_scratch", None) is None:
+            self._fin_scratch = torch.zeros(int(self.L.yh_bn_fin_split_scratch_bytes()), dtype=torch.uint8, device=self.dev)
+        return self._fin_scratch.data_ptr()
+
     def _fuse_finalize(self, cmds):
         """(yh_bn_finalize, yh_bn_silu_apply) and (yh_bn_finalize_parts, yh_bn_silu_apply_parts) pairs of the forward program as
         one yh_bn_silu_apply_fin launch each"""
@@ -1254,9 +1265,17 @@ class Program:
                         pa.slab, pa.nblk = part_ptr, nblk
                         pa.dgamma, pa.dbeta = pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff
                     else:
-                        cmds.append((L.yh_bn_bwd_finalize, (part_ptr, nblk, n, M, ws.data_ptr(),
-                                                            pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
-                                                            coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0, 8.0 * nblk * n)))
+                        if FIN_SPLIT_MIN and nblk >= FIN_SPLIT_MIN:
+                            one = (BnPart * 1)()
+                            one[0].slab, one[0].nblk, one[0].C, one[0].ws, one[0].coef = part_ptr, nblk, n, ws.data_ptr(), coef.data_ptr()
+                            one[0].dgamma, one[0].dbeta = pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff
+                            self._keep.append(one)
+                            cmds.append((L.yh_bn_bwd_finalize_parts_split, (one, 1, M, self._fin_split_scratch()), op.name,
+                                         ('yh_bn_bwd_finalize', 0, 8.0 * nblk * n)))
+                        else:
+                            cmds.append((L.yh_bn_bwd_finalize, (part_ptr, nblk, n, M, ws.data_ptr(),
+                                                                pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
+                                                                coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0, 8.0 * nblk * n)))
                     gres_ptr, gres_ld, gres_acc = None, 0, 0
                     if op.res is not None and pi == 0 and op.res.buf.needs_grad:
                         gres_acc = claim(op.res)
@@ -1276,8 +1295,12 @@ class Program:
                     c0 += n
                 if bwd_parts is not None:          # the parts' reductions are done: one finalize, one pass writes gz of the whole stacked layer
                     self._keep.append(bwd_parts)
-                    cmds.append((L.yh_bn_bwd_finalize_parts, (bwd_parts, len(op.parts), M), op.name,
-                                 ('yh_bn_bwd_finalize', 0, 8.0 * sum(int(q.nblk) * int(q.C) for q in bwd_parts))))
+                    if FIN_SPLIT_MIN and max(int(q.nblk) for q in bwd_parts) >= FIN_SPLIT_MIN:
+                        cmds.append((L.yh_bn_bwd_finalize_parts_split, (bwd_parts, len(op.parts), M, self._fin_split_scratch()), op.name,
+                                     ('yh_bn_bwd_finalize', 0, 8.0 * sum(int(q.nblk) * int(q.C) for q in bwd_parts))))
+                    else:
+                        cmds.append((L.yh_bn_bwd_finalize_parts, (bwd_parts, len(op.parts), M), op.name,
+                                     ('yh_bn_bwd_finalize', 0, 8.0 * sum(int(q.nblk) * int(q.C) for q in bwd_parts))))
                     cmds.append((L.yh_bn_silu_bwd_apply_parts, (op.y.t.data_ptr(), op.y.C, M, bwd_parts, len(op.parts), gys.data_ptr(), op.N),
                                  op.name, ('yh_bn_silu_bwd_apply_parts', 0, 6.0 * M * op.N)))
                 gy_ld, gyN = op.N, op.N
@@ -1519,8 +1542,8 @@ class Program:
             if fn is L.yh_bn_bwd_finalize:
                 coef_ptr = cmd[1][7]
                 out.append(('pair', [cmd, (L.yh_fill_u32, (coef_ptr, 0, 2 * cmd[1][2]), cmd[2], ('yh_fill_u32', 0, 0.0))], cmd[2], ('sync', 0, 0.0)))
-            elif fn is L.yh_bn_bwd_finalize_parts:
-                parts, nparts, _M = cmd[1]
+            elif fn is L.yh_bn_bwd_finalize_parts or fn is L.yh_bn_bwd_finalize_parts_split:
+                parts, nparts = cmd[1][0], cmd[1][1]
                 fills = [(L.yh_fill_u32, (parts[i].coef, 0, 2 * int(parts[i].C)), cmd[2], ('yh_fill_u32', 0, 0.0)) for i in range(nparts)]
                 out.append(('pair', [cmd] + fills, cmd[2], ('sync', 0, 0.0)))
             else:
