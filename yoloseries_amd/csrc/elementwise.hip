@@ -944,6 +944,10 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// YH_FIN_LDS_PAD=<bytes>: dynamic LDS the finalize launches ask for without using it, so that their workgroups do not fit on a CU beside a
+// weight-gradient workgroup (128 KiB of the 160) and go to the CUs it leaves free (experiment: profiles/r04_step_experiments.txt, t)
+inline unsigned fin_lds_pad() { static const unsigned v = [] { const char* e = getenv("YH_FIN_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }(); return v; }
+
 inline int ew_grid(long nthreads) {
     long g = (nthreads + EW_THREADS - 1) / EW_THREADS;
     if (g > 256 * 8) g = 256 * 8;          // 8 blocks of 256 threads per CU: measured against 4 / 6 / 10 / 16 / 32 and 128- / 512-thread blocks on the train step
@@ -965,7 +969,7 @@ extern "C" int yh_bn_finalize(const float* stats, int nblk, int ldstat, int C, i
                               int64_t* num_batches, float eps, float momentum, float* ws, yh_stream stream)
 {
     YH_CHECK_ARG(stats && gamma && beta && ws && nblk > 0 && C > 0 && count > 0 && ldstat >= C, "yh_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(FIN_NT), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(FIN_NT), fin_lds_pad(), (hipStream_t)stream,
                        stats, nblk, ldstat, C, (double)count, gamma, beta, running_mean, running_var, num_batches, eps, momentum, ws);
     YH_CHECK_LAUNCH("yh_bn_finalize");
     return YH_OK;
@@ -1081,7 +1085,7 @@ extern "C" int yh_bn_bwd_finalize(const float* part, int nblk, int C, int64_t M,
                                   float* dgamma, float* dbeta, float* coef, yh_stream stream)
 {
     YH_CHECK_ARG(part && ws && nblk > 0 && C > 0 && M > 0, "yh_bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(FIN_NT), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(FIN_NT), fin_lds_pad(), (hipStream_t)stream,
                        part, nblk, C, (double)M, ws, dgamma, dbeta, coef);
     YH_CHECK_LAUNCH("yh_bn_bwd_finalize");
     return YH_OK;
@@ -1143,7 +1147,7 @@ extern "C" int yh_bn_finalize_parts(const yh_bn_part* parts, int nparts, int64_t
     const int rc = parts_pack("yh_bn_finalize_parts", parts, nparts, 2, &P, &C);
     if (rc != YH_OK) return rc;
     YH_CHECK_ARG(count > 0, "yh_bn_finalize_parts: bad count");
-    hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(FIN_NT), 0, (hipStream_t)stream, P, (double)count);
+    hipLaunchKernelGGL(bn_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(FIN_NT), fin_lds_pad(), (hipStream_t)stream, P, (double)count);
     YH_CHECK_LAUNCH("yh_bn_finalize_parts");
     return YH_OK;
 }
@@ -1155,7 +1159,7 @@ extern "C" int yh_bn_bwd_finalize_parts(const yh_bn_part* parts, int nparts, int
     const int rc = parts_pack("yh_bn_bwd_finalize_parts", parts, nparts, 3, &P, &C);
     if (rc != YH_OK) return rc;
     YH_CHECK_ARG(M > 0, "yh_bn_bwd_finalize_parts: bad M");
-    hipLaunchKernelGGL(bn_bwd_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(FIN_NT), 0, (hipStream_t)stream, P, (double)M);
+    hipLaunchKernelGGL(bn_bwd_finalize_parts_kernel, dim3(P.bend[nparts - 1]), dim3(FIN_NT), fin_lds_pad(), (hipStream_t)stream, P, (double)M);
     YH_CHECK_LAUNCH("yh_bn_bwd_finalize_parts");
     return YH_OK;
 }
