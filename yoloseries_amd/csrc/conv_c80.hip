@@ -108,12 +108,13 @@ __global__ __launch_bounds__(256, 1) void conv_c80_kernel(const C80K p)
         sConst[i] = src ? src[c] : (which == 1 ? 1.f : 0.f);
     }
 
-    // slot k of the tile at (img, pix0): one division by Wo through a float reciprocal (exact: pix < 2^22 and (pix + 0.5) / Wo is
-    // at least 0.5 / Wo away from an integer), rows / columns of the three taps that fall inside the image as a 6-bit mask
+    // slot k of the tile at (img, pix0): one division by Wo through a float reciprocal with a one-row correction, rows / columns of
+    // the three taps that fall inside the image as a 6-bit mask
     const float rWo = 1.0f / (float)p.Wo;
     auto geom_slot = [&](int pix0, C80Geom& gm, int k) {
         const int pix = pix0 + arow[k];
-        const int oy = (int)(((float)pix + 0.5f) * rWo), ox = pix - oy * p.Wo;
+        int oy = (int)(((float)pix + 0.5f) * rWo), ox = pix - oy * p.Wo;
+        if (ox < 0) { oy -= 1; ox += p.Wo; } else if (ox >= p.Wo) { oy += 1; ox -= p.Wo; }      // the estimate is off by at most one row
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         gm.base[k] = (iy0 * p.Wi + ix0) * ldx2 + ac16[k];
         const int m = (iy0 >= 0 ? 1 : 0) | (iy0 + 1 < p.Hi ? 2 : 0) | (iy0 + 2 < p.Hi ? 4 : 0) |
