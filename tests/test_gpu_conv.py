@@ -1004,12 +1004,15 @@ def test_conv_two_segments_ragged_first_segment(dev, C0, C1, Cout, k):
     assert ((stats[:, 0, :Cout].double().sum(0) - o.sum(0)).abs() <= 1e-2 + 4 * 2.0 ** -9 * (o ** 2).sum(0).sqrt()).all()
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 24, 64),         # 48 image rows: strips dealt to the waves in order
+                                   (4, 32, 64),         # 128 rows = whole bands of 8 rows per XCD: the XCD-aware strip order
+                                   (16, 64, 128)])      # ... with two strips per wave (4 096 strips on 512 workgroups)
 @pytest.mark.parametrize("Cout", [32, 48, 64, 80])
-def test_conv_stem_kernel(dev, Cout):
+def test_conv_stem_kernel(dev, Cout, B, H, W):
     """the strip kernel of the stem (3x3 on the 16-channel space-to-depth image, 1..3 output tiles of 32 channels: v5s 32, v5m 48,
     v5l 64, v5x 80): plain store + BatchNorm partial sums, and folded BatchNorm + SiLU (inference)"""
     from yoloseries_amd import hipk
-    B, H, W, Cin = 2, 24, 64, 16
+    Cin = 16
     x = _nhwc(B, H, W, Cin, dev, 41)
     g = torch.Generator().manual_seed(42)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).to(torch.bfloat16).float().to(dev)

@@ -2081,6 +2081,7 @@ constexpr size_t conv3_smem_bytes() {
 // chunks.  BatchNorm statistics are per-lane running sums over all strips of the wave, reduced once at the end.
 // The layer moves 630 MB for 0.6 GFLOP/MB: it is HBM bound.
 struct StemTag {};
+constexpr int STEM_BAND = 8;          // image rows per XCD band of the XCD-aware strip order
 
 // NTL = output-channel tiles of 32 (v5s 32 -> 1; v5m 48 / v5l 64 -> 2; v5x 80 -> 3, inference only: the running sums of
 // three tiles do not fit the register file): the nine fragments of every tile stay in registers, a strip's nine input
@@ -2199,15 +2200,27 @@ __global__ __launch_bounds__(256, NTL == 3 ? 1 : 2) void conv_stem_kernel(const 
         }
     };
 
-    int s = blockIdx.x * 4 + wave;
-    if (s < nstrip) issue(s, 0);
-    for (; s < nstrip; s += 2 * wstride) {
-        const int s1 = s + wstride, s2 = s + 2 * wstride;
-        if (s1 < nstrip) issue(s1, 1);
-        compute(s, 0);
-        if (s1 < nstrip) {
-            if (s2 < nstrip) issue(s2, 0);
-            compute(s1, 1);
+    // Strip order.  Workgroups are dealt round-robin to the 8 XCDs by id, and a strip needs the input rows above and below its
+    // own: with strips simply dealt to waves in order, vertically adjacent strips land on different XCDs and every XCD fetches
+    // every input row (PMC: 3.2 - 4.2x the input).  With p.xgx set (whole bands of STEM_BAND rows per XCD: host check) XCD x works
+    // through the bands x, x + 8, ... — its waves walk a band row by row together, so the halo rows are L2 hits.
+    auto strip_of = [&](int u) __attribute__((always_inline)) {      // u: position in this wave's XCD-local (or global) order
+        if (!p.xgx) return u;
+        const int per_band = STEM_BAND * spr;
+        const int bl = u / per_band, within = u - bl * per_band;
+        return ((bl << 3) + ((int)blockIdx.x & 7)) * per_band + within;
+    };
+    const int ustride = p.xgx ? (int)(gridDim.x >> 3) * 4 : wstride;
+    const int ulim = p.xgx ? nstrip >> 3 : nstrip;
+    int u = p.xgx ? (int)(blockIdx.x >> 3) * 4 + wave : (int)blockIdx.x * 4 + wave;
+    if (u < ulim) issue(strip_of(u), 0);
+    for (; u < ulim; u += 2 * ustride) {
+        const int u1 = u + ustride, u2 = u + 2 * ustride;
+        if (u1 < ulim) issue(strip_of(u1), 1);
+        compute(strip_of(u), 0);
+        if (u1 < ulim) {
+            if (u2 < ulim) issue(strip_of(u2), 0);
+            compute(strip_of(u1), 1);
         }
     }
 
@@ -2582,6 +2595,11 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         if (name_out) { snprintf(name_out, name_len, "conv_stem_kernel<%d, %d>", epi, ntl); return YH_OK; }
         hipStream_t sst = (hipStream_t)stream;
         const dim3 sg(gx), sb(256);
+        {   // XCD-aware strip order (see the kernel): whole bands per XCD and whole workgroup octets; YH_STEM_MAP=0: strips in order
+            static const int smap = getenv("YH_STEM_MAP") ? atoi(getenv("YH_STEM_MAP")) : 1;
+            const long rows = (long)d->B * d->Ho;
+            k.xgx = (smap && gx % 8 == 0 && rows % (8 * STEM_BAND) == 0) ? 1 : 0;
+        }
 #define YH_LAUNCH_STEM(NTL_)                                                            \
         do {                                                                            \
             if (epi == 2)      conv_stem_kernel<2, NTL_><<<sg, sb, 0, sst>>>(k);        \
