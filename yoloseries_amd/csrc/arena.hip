@@ -15,16 +15,40 @@ inline int grid_for(long n) {
     return (int)g;
 }
 
+// eight elements per thread: two 16-byte index loads, eight gathered floats in flight, ONE 16-byte store (a 2-byte store per lane
+// wrote 128 bytes per wave instruction: 77 us per step for the 18 MB of YOLOv5s' packed weights); the tail and unaligned
+// destinations take the scalar path
 __global__ void pack_bf16_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, long n, uint16_t* __restrict__ dst)
 {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long n8 = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(idx)) & 15) ? 0 : n >> 3;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (long)gridDim.x * blockDim.x) {
+        const int4 j0 = *reinterpret_cast<const int4*>(idx + c * 8), j1 = *reinterpret_cast<const int4*>(idx + c * 8 + 4);
+        const int j[8] = {j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w};
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = j[e] >= 0 ? src[j[e]] : 0.f;
+        uint4 v;
+        v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+        v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+        v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+        v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+        *reinterpret_cast<uint4*>(dst + c * 8) = v;
+    }
+    for (long i = n8 * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         int32_t j = idx[i];
         dst[i] = j >= 0 ? f2bf(src[j]) : (uint16_t)0;
     }
 }
 __global__ void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, long n, float* __restrict__ dst)
 {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long n4 = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(idx)) & 15) ? 0 : n >> 2;      // four per thread: 16-byte stores
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < n4; c += (long)gridDim.x * blockDim.x) {
+        const int4 j = *reinterpret_cast<const int4*>(idx + c * 4);
+        float4 v;
+        v.x = j.x >= 0 ? src[j.x] : 0.f; v.y = j.y >= 0 ? src[j.y] : 0.f; v.z = j.z >= 0 ? src[j.z] : 0.f; v.w = j.w >= 0 ? src[j.w] : 0.f;
+        *reinterpret_cast<float4*>(dst + c * 4) = v;
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         int32_t j = idx[i];
         dst[i] = j >= 0 ? src[j] : 0.f;
     }

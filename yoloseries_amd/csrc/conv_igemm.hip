@@ -2077,8 +2077,8 @@ constexpr size_t conv3_smem_bytes() {
 // of 32 consecutive output pixels of one image row: 9 coalesced 1-KB loads (one per tap, fragments straight from
 // global memory in MFMA layout, hardware zero fill at the borders), 9 MFMAs, no LDS staging, no barriers.
 // The MFMA runs with swapped operands (D = W x X^T): a lane then holds 4 consecutive CHANNELS of one pixel per
-// accumulator group, lanes l and l+32 exchange halves with v_permlane32_swap, and every lane stores two 16-byte
-// chunks.  BatchNorm statistics are per-lane running sums over all strips of the wave, reduced once at the end.
+// accumulator group, lanes l and l+32 exchange halves with v_permlane32_swap into 16-byte chunks, and the strip leaves
+// through a wave-private LDS strip in memory order (1 KiB of consecutive chunks per store instruction).  BatchNorm statistics are per-lane running sums over all strips of the wave, reduced once at the end.
 // The layer moves 630 MB for 0.6 GFLOP/MB: it is HBM bound.
 struct StemTag {};
 constexpr int STEM_BAND = 8;          // image rows per XCD band of the XCD-aware strip order
@@ -2093,6 +2093,8 @@ __global__ __launch_bounds__(256, NTL == 3 ? 1 : 2) void conv_stem_kernel(const 
     static_assert(EPI != 1 || NTL <= 2, "statistics: at most two channel tiles");
     __shared__ float sRed[EPI == 1 ? 4 : 1][2][32 * NTL];
     __shared__ __attribute__((aligned(16))) float sConst[2][32 * NTL];           // EPI 2: scale | shift
+    constexpr int STEM_SP = 32 * NTL + 8;                                        // pitch (elements) of a staged output row
+    __shared__ __attribute__((aligned(16))) uint16_t sOut[4 * 32 * STEM_SP];      // [wave][32 pixels][STEM_SP]
     const yh_conv_desc& d = p.d;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -2148,7 +2150,6 @@ __global__ __launch_bounds__(256, NTL == 3 ? 1 : 2) void conv_stem_kernel(const 
         }
     };
     auto compute = [&](int s, int set) __attribute__((always_inline)) {
-        const size_t m = (size_t)s * 32 + r;
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
             f32x16_t acc;
@@ -2194,10 +2195,24 @@ __global__ __launch_bounds__(256, NTL == 3 ? 1 : 2) void conv_stem_kernel(const 
                 c01 = make_uint4(a0[0], a1[0], a0[1], a1[1]);
                 c23 = make_uint4(b0[0], b1[0], b0[1], b1[1]);
             }
-            uint16_t* dst = d.out0 + m * d.ld0 + nt * 32 + 8 * h;
-            *reinterpret_cast<uint4*>(dst) = c01;                                  // channels 32nt +  0..7  (h = 0) /  8..15 (h = 1)
-            if (nt * 32 + 16 < d.N) *reinterpret_cast<uint4*>(dst + 16) = c23;     // channels 32nt + 16..23 (h = 0) / 24..31 (h = 1)
+            // through a wave-private LDS strip [32 pixels][N channels]: stored from the registers, an instruction writes 32 bytes of
+            // every pixel row (2.3 TB/s of writes measured: the layer is all writes); read back in memory order, an instruction
+            // writes 1 KiB of consecutive 16-byte chunks
+            uint16_t* srow = sOut + (wave * 32 + r) * STEM_SP + nt * 32 + 8 * h;
+            *reinterpret_cast<uint4*>(srow) = c01;                                 // channels 32nt +  0..7  (h = 0) /  8..15 (h = 1)
+            *reinterpret_cast<uint4*>(srow + 16) = c23;                            // channels 32nt + 16..23 (h = 0) / 24..31 (h = 1)
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // LDS executes a wave's accesses in order
+        const int cpp = d.N >> 3;                                                  // 16-byte chunks per pixel
+        const size_t m0 = (size_t)s * 32;
+#pragma unroll
+        for (int it = 0; it < (32 * 32 * NTL / 8 + 63) / 64; ++it) {
+            const int q = it * 64 + lane;
+            const int px = q / cpp, ck = q - px * cpp;
+            if (px < 32)
+                *reinterpret_cast<uint4*>(d.out0 + (m0 + px) * d.ld0 + ck * 8) = *reinterpret_cast<const uint4*>(sOut + (wave * 32 + px) * STEM_SP + ck * 8);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // read before the next strip overwrites it
     };
 
     // Strip order.  Workgroups are dealt round-robin to the 8 XCDs by id, and a strip needs the input rows above and below its
