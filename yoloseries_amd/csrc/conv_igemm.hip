@@ -2093,8 +2093,10 @@ __global__ __launch_bounds__(256, NTL == 3 ? 1 : 2) void conv_stem_kernel(const 
     static_assert(EPI != 1 || NTL <= 2, "statistics: at most two channel tiles");
     __shared__ float sRed[EPI == 1 ? 4 : 1][2][32 * NTL];
     __shared__ __attribute__((aligned(16))) float sConst[2][32 * NTL];           // EPI 2: scale | shift
+    // the two-tile training form (64 channels: whole 128-byte rows, 254 registers) keeps its direct stores: staged it spills and gains nothing
+    constexpr bool STAGED = !(EPI == 1 && NTL == 2);
     constexpr int STEM_SP = 32 * NTL + 8;                                        // pitch (elements) of a staged output row
-    __shared__ __attribute__((aligned(16))) uint16_t sOut[4 * 32 * STEM_SP];      // [wave][32 pixels][STEM_SP]
+    __shared__ __attribute__((aligned(16))) uint16_t sOut[STAGED ? 4 * 32 * STEM_SP : 8];      // [wave][32 pixels][STEM_SP]
     const yh_conv_desc& d = p.d;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -2198,10 +2200,17 @@ __global__ __launch_bounds__(256, NTL == 3 ? 1 : 2) void conv_stem_kernel(const 
             // through a wave-private LDS strip [32 pixels][N channels]: stored from the registers, an instruction writes 32 bytes of
             // every pixel row (2.3 TB/s of writes measured: the layer is all writes); read back in memory order, an instruction
             // writes 1 KiB of consecutive 16-byte chunks
-            uint16_t* srow = sOut + (wave * 32 + r) * STEM_SP + nt * 32 + 8 * h;
-            *reinterpret_cast<uint4*>(srow) = c01;                                 // channels 32nt +  0..7  (h = 0) /  8..15 (h = 1)
-            *reinterpret_cast<uint4*>(srow + 16) = c23;                            // channels 32nt + 16..23 (h = 0) / 24..31 (h = 1)
+            if constexpr (STAGED) {
+                uint16_t* srow = sOut + (wave * 32 + r) * STEM_SP + nt * 32 + 8 * h;
+                *reinterpret_cast<uint4*>(srow) = c01;                             // channels 32nt +  0..7  (h = 0) /  8..15 (h = 1)
+                *reinterpret_cast<uint4*>(srow + 16) = c23;                        // channels 32nt + 16..23 (h = 0) / 24..31 (h = 1)
+            } else {
+                uint16_t* dst = d.out0 + ((size_t)s * 32 + r) * d.ld0 + nt * 32 + 8 * h;
+                *reinterpret_cast<uint4*>(dst) = c01;
+                if (nt * 32 + 16 < d.N) *reinterpret_cast<uint4*>(dst + 16) = c23;
+            }
         }
+        if constexpr (!STAGED) return;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // LDS executes a wave's accesses in order
         const int cpp = d.N >> 3;                                                  // 16-byte chunks per pixel
         const size_t m0 = (size_t)s * 32;
