@@ -299,13 +299,9 @@ def worker(args):
         ema = ExponentialMovingAverageModel(model)
         dp = DataParallelGrads(model) if (world > 1 or force_dp) else None
 
-        prefetch = hasattr(lossf, "prefetch_assign") and os.environ.get("YH_LOSS_PREFETCH", "0") == "1"    # measured slower: r04_step_experiments.txt (r)
-
         def step():
             # YOLOXLoss converts the target boxes to xywh IN PLACE like the reference (loss/yolox_loss.py:70-75): every step
             # gets a fresh copy, as a data loader would deliver
-            if prefetch:
-                lossf.prefetch_assign(t)            # the target assignment on a side stream beside the forward pass
             out = lossf(model(x), t.clone() if args.workload == "yolox" else t)
             out["tot_loss"].backward()
             opt.clip_grad_norm_(10.0)
@@ -576,6 +572,41 @@ def _groups(fam, nsteps, pmc):
     return res
 
 
+def _foreign_launches(step, nsteps=2):
+    """kernels of a steady-state step that are NOT this library's (torch fills / copies / elementwise kernels, runtime copy kernels):
+    launches and device time per step from a torch.profiler (roctracer) trace of `nsteps` extra steps.  Every kernel of
+    libyolohip.so lives in an anonymous namespace, which is how the two are told apart (tools/foreign_launches.py does the same on a
+    rocprofv3 trace).  None when the profiler is unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(nsteps):
+                step()
+            torch.cuda.synchronize()
+        ours = n_all = 0
+        foreign = {}
+        for ev in prof.events():
+            if str(getattr(ev, "device_type", "")).endswith("CUDA") is False:
+                continue
+            name = ev.name
+            n_all += 1
+            if "(anonymous namespace)::" in name:
+                ours += 1
+                continue
+            f = foreign.setdefault(name.split("(")[0][:80], [0, 0.0])
+            f[0] += 1
+            f[1] += float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0) or 0.0)
+        if ours == 0:
+            return None
+        return {"launches_per_step": round(sum(v[0] for v in foreign.values()) / nsteps, 1),
+                "ms_per_step": round(sum(v[1] for v in foreign.values()) / nsteps / 1000.0, 4),
+                "library_launches_per_step": round(ours / nsteps, 1),
+                "kernels": {k: round(v[0] / nsteps, 1) for k, v in sorted(foreign.items(), key=lambda kv: -kv[1][1])[:6]}}
+    except Exception as e:       # diagnostics only: never fail the measurement
+        return {"error": repr(e)[:200]}
+
+
 def measure_roofline(model, step, B, nsteps=3):
     """Roofline of the dominant kernel family (template instantiation, profiler spelling: the one with the largest total time),
     plus the same entry for the conv family with the largest time among the MFMA-bound ones (`conv`), per-family times, and the
@@ -629,6 +660,8 @@ def measure_roofline(model, step, B, nsteps=3):
     roof["mfma_util_step"] = pmc_mfma.get("mfma_util_all_kernels") if pmc_mfma else None
     roof["family_ms_per_step"] = {k: round(v["ms"] / nsteps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
     roof["groups"] = _groups(fam, nsteps, pmc)
+    if os.environ.get("YH_BENCH_FOREIGN", "1") != "0":
+        roof["groups"]["foreign"] = _foreign_launches(step)
     roof["engine_kernel_ms_per_step"] = round(total_ms, 3)
     return roof
 

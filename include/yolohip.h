@@ -110,9 +110,8 @@ typedef struct yh_conv_desc {
                            * index — no padding of N or K);
                            * 10 the pointwise kernel (conv_pw_kernel: 1x1 / s1 / p0 forward with exactly 80, 160 or 320 input channels and
                            * N % 80 == 0, no statistics: pixel tiles and the weight tile whole in LDS, no k loop over memory);
-                           * 11 wave-private tiles (conv_wpf_kernel: 3x3 / s1 / p1 or 1x1 / s1 / p0, one segment of >= 64 channels in a
-                           * multiple of 32, N >= 64: four waves of 128 pixels x 128 channels per CU, shared weight stage, one barrier
-                           * per 32 MFMAs; forward with statistics, data gradient plain / accumulating / with the fused reduction);
+                           * (11: retired in round 5 — the wave-private forward kernel lost to tile quantisation on every BASELINE shape,
+                           * profiles/r04_step_experiments.txt k);
                            * 12 the 80 -> 160 channel tap kernel (conv_c80_kernel: 3x3 / s1 or s2 / p1 forward with exactly 80 input and 160
                            * output channels, inference epilogue into one destination, no residual: 256 pixels x 160 channels per
                            * workgroup, one tap per stage — no padding of N or K; YOLOv5x's stage-1 downsampling layer) */
@@ -125,20 +124,7 @@ typedef struct yh_conv_desc {
     const yh_bf16* bnr_z; int32_t bnr_ldz; int32_t bnr_C;
     const float* bnr_ws;
     float*   bnr_part;
-    /* acc_rows > 0: `stats` / `bnr_part` are not fp32 slabs but int64 fixed-point ACCUMULATORS, [acc_rows][2][Npad] resp.
-     * [acc_rows][2][N] (zeroed by the caller before the launch): every block adds its partial sums, scaled by 2^YH_STAT_SHIFT_FWD
-     * resp. 2^YH_STAT_SHIFT_BWD and rounded, to row (block index % acc_rows) with 64-bit integer atomics — associative, so the
-     * totals do not depend on the arrival order.  The consumer passes (yh_bn_silu_apply_acc, yh_bn_silu_bwd_apply_acc) reduce the
-     * few rows in their prologue: no finalize launch.  32 adders per address run at the full atomic rate (16 rows, 512 blocks). */
-    int32_t  acc_rows;
-    int32_t  reserved1;
 } yh_conv_desc;
-#define YH_ACC_ROWS 16           /* most accumulator rows a consumer pass reduces (acc_rows <= YH_ACC_ROWS) */
-#define YH_STAT_SHIFT_FWD 24     /* sums of z, z*z over up to 2^23 pixels: resolution 6e-8, range +-5e11 */
-#define YH_STAT_SHIFT_BWD 40     /* sums of dz, dz*z: resolution 9e-13, range +-8e6 */
-#define YH_STAT_SCALE_FWD 16777216.0f
-#define YH_STAT_SCALE_BWD 1099511627776.0f
-
 /* number of partial-sum rows the conv kernel writes for this shape */
 int yh_conv_stat_blocks(const yh_conv_desc* d);
 int yh_conv_igemm(const yh_conv_desc* d, yh_stream stream);
@@ -184,13 +170,6 @@ typedef struct yh_wgrad_desc {
      * conv_wgrad.hip (wide tilings of up to 256 im2col columns); others return YH_EINVAL.                                      */
     const yh_bf16* bn_z; int32_t bn_ldz; int32_t reserved0;
     const float* bn_ws; const float* bn_gamma; const float* bn_coef;
-    /* tile_k 129 only: an optional SECOND input segment of the same layer (seg2.ptr != NULL; a concat input:
-     * utils/layer_tools.py:106-114, models/normal/yolov5s.py head) whose weight-gradient columns start at channel coff_k2 of every
-     * tap — both segments in ONE launch: gy is read once per pixel split, one set of partial tiles / atomics instead of two.  The
-     * other forms ignore it (callers launch once per segment). */
-    yh_seg   seg2;
-    int32_t  coff_k2;
-    int32_t  reserved1;
 } yh_wgrad_desc;
 int yh_conv_wgrad(const yh_wgrad_desc* d, yh_stream stream);
 size_t yh_conv_wgrad_ws_bytes(const yh_wgrad_desc* d);
@@ -281,19 +260,6 @@ typedef struct yh_bn_part {
 int yh_bn_finalize_parts(const yh_bn_part* parts, int nparts, int64_t count, yh_stream stream);
 int yh_bn_bwd_finalize_parts(const yh_bn_part* parts, int nparts, int64_t M, yh_stream stream);
 int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts, yh_stream stream);
-/* yh_bn_bwd_finalize_parts for slabs with thousands of rows: the rows are summed in up to 16 slices by as many workgroups per 16
- * channels, the last one to arrive adds the slices in order (deterministic; sums associate differently from the unsplit launch, in
- * fp64).  scratch: yh_bn_fin_split_scratch_bytes() of device memory, zero before the first use, not shared between streams. */
-size_t yh_bn_fin_split_scratch_bytes(void);
-int yh_bn_bwd_finalize_parts_split(const yh_bn_part* parts, int nparts, int64_t M, void* scratch, yh_stream stream);
-/* yh_bn_finalize_parts + yh_bn_silu_apply_parts (or, with one part, yh_bn_finalize + yh_bn_silu_apply incl. the residual) as ONE
- * launch: the first workgroups of the grid finalize 16 channels each and publish ws, the others wait for them before their first
- * row is scaled (in-order workgroup dispatch: see the kernel).  Same results bit for bit (same summation order).  `sync`:
- * YH_BN_FIN_SYNC_WORDS int32 of device memory owned by this (layer, pass), zero when first used and never touched by anything
- * else — the launches keep their own books in it.  Reference: one nn.BatchNorm2d forward in training mode, utils/layer_tools.py:39-53. */
-#define YH_BN_FIN_SYNC_WORDS (128 * 32 + 2)
-int yh_bn_silu_apply_fin(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts,
-                         const yh_bf16* res, int ldr, int32_t* sync, yh_stream stream);
 int yh_bn_silu_bwd_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts,
                                yh_bf16* gy, int ldgy, yh_stream stream);
 /* column sums of a bf16 matrix (bias gradient of Detect): out[c] += sum_m g[m][c] */
@@ -359,24 +325,6 @@ int yh_clip_scale(const float* sumsq, float max_norm, float* out, yh_stream stre
 /* EMA: e = d*e + (1-d)*p over a flat arena (trainer/ema_model.py:20-28)         */
 int yh_ema_update(float* ema, const float* p, int64_t n, float decay, yh_stream stream);
 
-/* ---- BatchNorm passes fed by the int64 accumulators (yh_conv_desc.acc_rows): the finalize step is the prologue of the pass ----
- * acc: [rows][2][ldacc] int64 (sum | sum of squares, scaled 2^YH_STAT_SHIFT_FWD), channel c of this BatchNorm at acc[..][c].
- * Every block reduces the rows for all C channels (rows*2*C 8-byte loads from L2), derives scale / shift; block 0 also writes
- * ws = scale | shift | mean | invstd (4*C floats, read by the backward) and updates the running statistics (momentum, unbiased
- * variance, utils/layer_tools.py:87-91 in training mode).  Then out = silu(y*scale+shift) (+res) like yh_bn_silu_apply. */
-int yh_bn_silu_apply_acc(const yh_bf16* y, int ldy, const int64_t* acc, int rows, int ldacc, int C, int64_t M,
-                         const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
-                         float eps, float momentum, float* ws, yh_bf16* out, int ldo, const yh_bf16* res, int ldr, yh_stream stream);
-/* column reduction of the BatchNorm+SiLU backward (sum dz | sum dz*z, dz = g*silu'(y*scale+shift)) added into acc [rows][2][C]
- * int64, scaled 2^YH_STAT_SHIFT_BWD (same role as yh_bn_silu_bwd_reduce; used where no data gradient fuses the reduction) */
-int yh_bn_silu_bwd_reduce_acc(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy, const float* ws, int C, int64_t M,
-                              int64_t* acc, int rows, yh_stream stream);
-/* BatchNorm+SiLU backward apply with the finalize in its prologue: sums from acc [rows][2][C] (yh_conv_desc.bnr_part in accumulator
- * mode, or yh_bn_silu_bwd_reduce_acc), dgamma / dbeta written by block 0, then gy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) */
-int yh_bn_silu_bwd_apply_acc(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy, const float* ws, const float* gamma,
-                             const int64_t* acc, int rows, int C, int64_t M, float* dgamma, float* dbeta,
-                             yh_bf16* gy, int ldgy, yh_bf16* gres, int ldgres, int gres_acc, yh_stream stream);
-
 /* ------------------------------------------------------------------------ *
  * YOLOv5 loss (loss/yolov5_loss.py:30-235)
  * ------------------------------------------------------------------------ */
@@ -410,11 +358,6 @@ int yh_v5_assign(const yh_v5loss_desc* d, const float* targets,
  * result (fp32[8]): tot, iou, cof, cls, tar_nums, 0,0,0  (iou/cof/cls already x B)
  * saved: opaque per-call state for the backward, yh_v5loss_saved_bytes()         */
 size_t yh_v5loss_saved_bytes(const yh_v5loss_desc* d);
-/* The assignment step of the forward loss alone (it depends on the targets only: loss/yolov5_loss.py:142-214 is called per stage with
- * `targets` before any prediction is touched), written into `saved`; a following yh_v5_loss_fwd with targets = NULL and the same
- * geometry (B, maxbox, anchors, H, W) skips its own assignment and reads this one.  Lets a training loop run the assignment on
- * another stream beside the network's forward pass; ordering the two streams is the caller's business. */
-int yh_v5_loss_assign(const yh_v5loss_desc* d, const float* targets, void* saved, yh_stream stream);
 int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds, const float* targets,
                    double* balances, float* result, void* saved, void* ws, yh_stream stream);
 /* Backward: gpreds[s] same geometry/dtype as preds[s], fully overwritten.
@@ -448,7 +391,9 @@ int yh_yolox_loss_fwd(const yh_yolox_desc* d, const void* const* preds, const fl
 int yh_yolox_loss_bwd(const yh_yolox_desc* d, const void* const* preds, const float* targets_xywh, const float* gout,
                       const void* saved, void* const* gpreds, yh_stream stream);
 
-/* Box utilities (utils/bbox_tools.py:164-339) fp32 */
+/* Box utilities (utils/bbox_tools.py:164-339) fp32.  yh_iou_matrix: (n1, n2) IoU of xyxy boxes; eps_clamp > 0: union clamped from
+ * below (gpu_iou, utils/bbox_tools.py:164-190), 0: no clamp on the union (numba_iou :12-35: 0 / 0 = NaN), < 0: no clamp on the
+ * intersection sides either (the evaluators' bbox_iou, trainer/eval_yolov5.py:237-258, trainer/eval_yolox.py) */
 int yh_iou_matrix(const float* b1, int n1, const float* b2, int n2, float eps_clamp, float* out, yh_stream stream);
 /* kind: 0 giou 1 diou 2 ciou ; pairwise (N,) ; grad (optional) d out/d b1 [N][4] */
 int yh_iou_pairwise(int kind, const float* b1, const float* b2, int n, float* out, float* grad_b1, yh_stream stream);

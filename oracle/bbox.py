@@ -30,6 +30,25 @@ def numba_iou(bbox1, bbox2):
         return (inter / (a1[:, None] + a2 - inter)).astype(F32)
 
 
+def evaluator_bbox_iou(bbox1, bbox2):
+    """trainer/eval_yolov5.py:237-258 == trainer/eval_yolox.py:177-199 — the evaluators' static `bbox_iou`: (N,M) IoU with NO clamp
+    on the intersection sides (boxes apart on both axes get the positive product of two negative sides) and none on the union
+    (0/0 -> NaN).  Pinned by tests/golden/g14_round5.npz (iou_v5, iou_yolox)."""
+    b1 = np.asarray(bbox1, dtype=F32)
+    b2 = np.asarray(bbox2, dtype=F32)
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    xmin = np.maximum(b1[:, 0][:, None], b2[:, 0])
+    xmax = np.minimum(b1[:, 2][:, None], b2[:, 2])
+    ymin = np.maximum(b1[:, 1][:, None], b2[:, 1])
+    ymax = np.minimum(b1[:, 3][:, None], b2[:, 3])
+    h = ymax - ymin
+    w = xmax - xmin
+    inter = w * h
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (inter / (a1[:, None] + a2 - inter)).astype(F32)
+
+
 def gpu_iou(bbox1, bbox2):
     """utils/bbox_tools.py:164-190 — (N,M) IoU, union clamped at 1e-9."""
     b1 = np.asarray(bbox1, dtype=F32)

@@ -10,7 +10,7 @@ Pinned by tests/golden/g4_decode.npz, g5_nms.npz (generated from the reference).
 """
 import numpy as np
 
-from .bbox import F32, gpu_iou, numba_iou, xywh2xyxy
+from .bbox import F32, evaluator_bbox_iou, gpu_iou, numba_iou, xywh2xyxy
 
 
 def numba_nms(boxes, scores, iou_threshold):
@@ -147,6 +147,29 @@ def nms_image(cand, iou_thr, class_aware, max_keep, merge_filter, inclusive=True
         mask = iou > F32(iou_thr)
         keep = list(np.asarray(keep)[mask.astype(F32).sum(axis=1) > 1])
     return x[keep], [int(k) for k in keep]
+
+
+def do_nms_v5(decoded, conf_thr, cls_thr, iou_thr, class_aware=True, max_keep=300, merge_filter=True, multi_label=False, yolox=False):
+    """YOLOV5Evaluator.do_nms (trainer/eval_yolov5.py:94-150) with iou_type 'iou': candidates as numba_nms, greedy NMS by
+    utils.gpu_nms (exclusive threshold, clamped gpu_iou) on the class-offset boxes, cap, then the survivors that MORE than one
+    candidate overlaps by > threshold under the evaluator's unclamped bbox_iou (:138-146; the merged boxes of :143 go to a
+    temporary that is never returned).  The reference raises IndexError for any image with a candidate (utils/nms.py:62-63 —
+    tests/golden/g14_round5.npz `donms_status`): this is the loop its gpu_nms spells, as the product implements it."""
+    outs = []
+    for i in range(decoded.shape[0]):
+        x = (candidates_yolox if yolox else candidates_v5)(decoded[i], conf_thr, cls_thr, multi_label)
+        M = x.shape[0]
+        if M == 0:
+            outs.append(None)
+            continue
+        off = x[:, 5] * F32(4096) if class_aware else x[:, 5] * F32(0)
+        boxes = (x[:, :4] + off[:, None]).astype(F32)
+        keep = gpu_nms(boxes, x[:, 4], iou_thr)[:max_keep]
+        if merge_filter and 1 < M < 3000:
+            iou = evaluator_bbox_iou(boxes[keep], boxes) if keep else np.zeros((0, M), F32)
+            keep = list(np.asarray(keep, dtype=np.int64)[(iou > F32(iou_thr)).astype(F32).sum(axis=1) > 1])
+        outs.append(x[keep])
+    return outs
 
 
 def postprocess_v5(decoded, conf_thr, cls_thr, iou_thr, class_aware=True, max_keep=300, merge_filter=True, multi_label=False):

@@ -416,42 +416,6 @@ def test_conv_wgrad_wave_private_tiles(dev, B, H, W, Cin, Cout, k, s, coff, Ctot
     assert (got[..., mask] == 0.5).all()                           # the other segments' columns are untouched
 
 
-@pytest.mark.parametrize("k,C0,C1,ups0,Cout,groups", [(1, 128, 64, 1, 128, 5), (1, 64, 64, 0, 256, 96), (3, 64, 64, 0, 128, 7), (3, 128, 32, 0, 64, 20), (1, 256, 256, 1, 255, 256)])
-def test_conv_wgrad_wave_private_tiles_two_segments(dev, k, C0, C1, ups0, Cout, groups):
-    """both segments of a concat input in ONE launch of conv_wgs_kernel (yh_wgrad_desc.seg2): the column tiles of segment 0, then
-    those of segment 1 (its own buffer, pitch, upsample flag and channel offset); gy is read once"""
-    import ctypes as C
-    from yoloseries_amd import hipk
-    from yoloseries_amd._lib import lib
-    B, H, W = 2, 16, 16
-    p = k // 2
-    ldg = ((Cout + 7) // 8) * 8
-    gy = torch.zeros(B, H, W, ldg, dtype=torch.bfloat16, device=dev)
-    gy[..., :Cout] = _nhwc(B, H, W, Cout, dev, 30)
-    s0 = _nhwc(B, H >> ups0, W >> ups0, C0, dev, 31)
-    s1w = torch.full((B, H, W, C1 + 32), float("nan"), dtype=torch.bfloat16, device=dev)
-    s1w[..., 32:] = _nhwc(B, H, W, C1, dev, 32)
-    Ctot = C0 + C1
-    dw = torch.zeros(Cout, k * k * Ctot, device=dev)
-    d = hipk.wgrad_desc(hipk.full(gy) if ldg == Cout else hipk.Slice(gy, 0, ldg), Cout, hipk.Slice(s0, 0, C0, ups=ups0), 0, Ctot, B, H, W, H, W, k, 1, p, dw, groups)
-    d.seg2 = hipk.make_seg(hipk.Slice(s1w, 32, C1))
-    d.coff_k2 = C0
-    d.tile_k = 129
-    T = lib().yh_conv_wgrad_wave_tiles(C.byref(d))
-    assert T == ((Cout + 127) // 128) * ((k * k * C0 + 127) // 128 + (k * k * C1 + 127) // 128)
-    hipk.wgrad_launch(d)
-    torch.cuda.synchronize()
-    x0 = _nchw(s0)
-    if ups0:
-        x0 = F.interpolate(x0, scale_factor=2, mode="nearest")
-    xin = torch.cat([x0, _nchw(s1w[..., 32:])], 1)
-    w = torch.zeros(Cout, Ctot, k, k, device=dev, requires_grad=True)
-    (ref,) = torch.autograd.grad(F.conv2d(xin, w, padding=p), w, _nchw(gy[..., :Cout]))
-    ref = ref.permute(0, 2, 3, 1).reshape(Cout, -1)
-    assert not torch.isnan(dw).any()
-    _close(dw, ref, 2e-3, 2e-3 * ref.abs().max().item())
-
-
 def test_conv_wgrad_wave_private_tiles_eligibility(dev):
     """layers the form does not cover fall through to the im2col forms (yh_conv_wgrad_wave_tiles == 0, tile_k 129 ignored)"""
     import ctypes as C
@@ -510,55 +474,8 @@ def _expect_family(d, algo):
         assert "conv_p3_kernel" in kn, kn
     if algo == 9:
         assert "conv_h80_kernel" in kn, kn
-    if algo == 11:
-        assert "conv_wpf_kernel" in kn, kn
     if algo == 12:
         assert "conv_c80_kernel" in kn, kn
-
-
-WPF_CASES = [
-    # B, H, W, Cin, Cout, k
-    (2, 20, 20, 128, 128, 3),      # YOLOv5s stage-3 bottleneck class: 800 pixels = two 512-pixel tiles, the second ragged
-    (1, 24, 40, 256, 256, 3),      # two channel tiles, 8 channel blocks per tap
-    (3, 13, 17, 64, 192, 3),       # odd sizes (tile rows wrap image rows and images), ragged channel tile (128 + 64)
-    (2, 16, 16, 128, 248, 3),      # N a multiple of 8 only
-    (2, 16, 16, 256, 128, 1),      # pointwise
-    (1, 8, 8, 512, 64, 1),         # 64 pixels: three of the four waves have no rows
-]
-
-
-@pytest.mark.parametrize("B,H,W,Cin,Cout,k", WPF_CASES)
-def test_conv_wave_private_tiles_kernel(dev, B, H, W, Cin, Cout, k):
-    """conv_wpf_kernel (algo 11): four waves of 128 pixels x 128 channels per workgroup, private im2col stages, shared weight stage,
-    one barrier per 32 MFMAs — forward with the BatchNorm partial sums, data gradient accumulating / plain / with the fused
-    BatchNorm-backward reduction, against torch"""
-    from yoloseries_amd import hipk
-    p = k // 2
-    x = _nhwc(B, H, W, Cin, dev, 91)
-    g = torch.Generator().manual_seed(92)
-    w = (torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5).to(torch.bfloat16).float().to(dev)
-    wp = hipk.pack_weight_fwd(w)
-    out = torch.full((B, H, W, Cout), 3.0, dtype=torch.bfloat16, device=dev)
-    d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, H, W, H, W, k, 1, p, wp, Cout, hipk.full(out))
-    d.algo = 11
-    assert "conv_wpf_kernel<0>" in _kname(d), _kname(d)
-    hipk.conv_launch(d)                                   # plain store
-    torch.cuda.synchronize()
-    ref = F.conv2d(_nchw(x), w, padding=p).permute(0, 2, 3, 1)
-    _close(out, ref, 8e-3, 2e-2)
-    out.fill_(3.0)
-    stats = torch.full((hipk.conv_stat_blocks(d), 2, wp.shape[0]), float("nan"), device=dev)
-    d.stats = stats.data_ptr()
-    assert "conv_wpf_kernel<1>" in _kname(d) and hipk.conv_stat_blocks(d) == stats.shape[0]
-    hipk.conv_launch(d)
-    torch.cuda.synchronize()
-    _close(out, ref, 8e-3, 2e-2)
-    o = out.float().reshape(-1, Cout).double()
-    assert not torch.isnan(stats[:, :, :Cout]).any()
-    assert ((stats[:, 0, :Cout].double().sum(0) - o.sum(0)).abs() <= 1e-3 + 1e-5 * o.abs().sum(0)).all()      # sums of the STORED values
-    assert ((stats[:, 1, :Cout].double().sum(0) - (o ** 2).sum(0)).abs() <= 1e-3 + 1e-5 * (o ** 2).sum(0)).all()
-    if Cout % 32 == 0 and Cout >= 64 and Cin >= 64:       # the data gradient reads gz with Cout channels, writes Cin
-        _dgrad_check(dev, B, H, W, Cin, Cout, k, 1, p, 11)
 
 
 @pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])

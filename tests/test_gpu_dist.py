@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, size="small"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     B, img = 2, 128
-    model = models.YOLOV5Small(3, 80).to(dev).train()
+    model = {"small": models.YOLOV5Small, "large": models.YOLOV5Large}[size](3, 80).to(dev).train()
     lossf = YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), bench.make_hyp(dev, img, B))
     opt = FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=0.0, nesterov=True)
     dp = DataParallelGrads(model)
@@ -98,14 +98,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_overlapped_bucket_allreduce_two_ranks(dev):
+@pytest.mark.parametrize("size", ["small", "large"])
+def test_overlapped_bucket_allreduce_two_ranks(dev, size):
+    """`large`: BASELINE config #4's model (YOLOv5l, models/normal/yolov5l.py:16-44: 177 MiB of fp32 gradients in the packed arena,
+    cut into the same four buckets) through the same data-parallel step"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, size)) for r in range(2)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=300) for _ in range(2)]
+    out = [q.get(timeout=600) for _ in range(2)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

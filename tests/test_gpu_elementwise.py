@@ -291,150 +291,3 @@ def test_arena_kernels(dev):
     e = torch.randn(n, device=dev); e0 = e.clone()
     hipk.ema_update(e, src, 0.99)
     assert torch.allclose(e, 0.99 * e0 + 0.01 * src, rtol=1e-5, atol=1e-6)
-
-
-def test_bn_accumulator_path_matches_slab_path(dev):
-    """YH_BN_ACC=1 (int64 fixed-point accumulator rows filled by the conv kernels with 64-bit atomics, reduced in the prologue of
-    the BN+SiLU passes: yh_conv_desc.acc_rows, yh_bn_silu_apply_acc, yh_bn_silu_bwd_reduce_acc, yh_bn_silu_bwd_apply_acc) gives the
-    same forward, running statistics and gradients as the default slab + finalize path on a C3 block"""
-    import importlib
-    import os
-    import numpy as np
-    from yoloseries_amd import engine
-    from yoloseries_amd import utils as U
-    res = {}
-    for acc in (False, True):
-        old = engine.BN_ACC
-        engine.BN_ACC = acc
-        try:
-            torch.manual_seed(0)
-            mod = U.C3BottleneckCSP(64, 64, shortcut=True, num_block=2).to(dev).train()
-            x = torch.from_numpy(np.random.RandomState(5).randn(4, 64, 32, 32).astype(np.float32)).to(dev).requires_grad_(True)
-            y = mod(x)
-            go = torch.from_numpy(np.random.RandomState(6).randn(*y.shape).astype(np.float32)).to(dev)
-            grads = torch.autograd.grad(y, [x] + list(mod.parameters()), go)
-            res[acc] = (y.detach().float().cpu(), [g.detach().float().cpu() for g in grads],
-                        {k: v.detach().float().cpu() for k, v in mod.state_dict().items() if "running" in k})
-        finally:
-            engine.BN_ACC = old
-    y0, g0, b0 = res[False]
-    y1, g1, b1 = res[True]
-    # statistics differ only by the fixed-point rounding of the per-block partial sums (2^-24 / 2^-40 absolute)
-    assert (y0 - y1).abs().max() <= 2e-2 * y0.abs().max()
-    for k in b0:
-        torch.testing.assert_close(b1[k], b0[k], rtol=1e-4, atol=1e-5)
-    for a, b in zip(g1, g0):
-        assert (a - b).abs().max() <= 3e-2 * b.abs().max() + 1e-6
-
-
-@pytest.mark.parametrize("Cs,M,nblk", [((32,), 4096 + 17, 33), ((64, 40, 24), 1000, 8), ((128, 128), 777, 700), ((256,), 20000, 157), ((8, 16, 8, 32), 333, 1)])
-def test_bn_finalize_rides_in_the_apply_launch(dev, Cs, M, nblk):
-    """yh_bn_silu_apply_fin (the finalize workgroups at the front of the pass's grid, the others waiting for them) is bit-identical
-    to yh_bn_finalize(_parts) followed by yh_bn_silu_apply(_parts) — constants, running statistics, step counter, activations,
-    residual — and keeps its books across launches (three launches on the same sync words)"""
-    from yoloseries_amd import hipk
-    Ct = sum(Cs)
-    ybuf = _rand_bf16((M, Ct + 16), dev, 31, 2.0)
-    y = hipk.Slice(ybuf, 8, Ct)
-    g = torch.Generator().manual_seed(32)
-    slab = (torch.randn(nblk, 2, Ct + 8, generator=g) * 3).to(dev)             # any numbers do: both paths sum the same slab
-    slab[:, 1] = slab[:, 1].abs() * 50 + 5.0
-    res = _rand_bf16((M, Ct), dev, 33) if len(Cs) == 1 else None
-    sync = torch.zeros(128 * 32 + 2, dtype=torch.int32, device=dev)            # YH_BN_FIN_SYNC_WORDS
-    ref, new, c0 = [], [], 0
-    for i, C in enumerate(Cs):
-        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
-        def state():
-            return dict(ws=torch.zeros(4 * C, device=dev), rm=torch.zeros(C, device=dev), rv=torch.ones(C, device=dev),
-                        nbt=torch.zeros(1, dtype=torch.int64, device=dev), out=torch.full((M, C + 8 * (i + 1)), 5.0, dtype=torch.bfloat16, device=dev))
-        a, b = state(), state()
-        common = dict(C=C, slab=slab.data_ptr() + 4 * c0, nblk=nblk, ldslab=Ct + 8, gamma=gamma, beta=beta, eps=1e-3, momentum=0.03)
-        ref.append(dict(common, ws=a["ws"], running_mean=a["rm"], running_var=a["rv"], num_batches=a["nbt"], out=hipk.Slice(a["out"], 8, C), _s=a))
-        new.append(dict(common, ws=b["ws"], running_mean=b["rm"], running_var=b["rv"], num_batches=b["nbt"], out=hipk.Slice(b["out"], 8, C), _s=b))
-        c0 += C
-    strip = lambda ps: [{k: v for k, v in q.items() if k != "_s"} for q in ps]
-    for launch in range(3):
-        hipk.bn_finalize_parts(strip(ref), M)
-        if res is None:
-            hipk.bn_silu_apply_parts(y, M, strip(ref))
-        else:
-            hipk.bn_silu_apply(y, ref[0]["ws"], M, ref[0]["out"], res=hipk.full(res))
-        hipk.bn_silu_apply_fin(y, M, strip(new), sync, res=hipk.full(res) if res is not None else None)
-        torch.cuda.synchronize()
-        for qa, qb in zip(ref, new):
-            a, b = qa["_s"], qb["_s"]
-            assert torch.equal(a["ws"], b["ws"]) and torch.equal(a["rm"], b["rm"]) and torch.equal(a["rv"], b["rv"])
-            assert a["nbt"].item() == b["nbt"].item() == launch + 1
-            assert torch.equal(a["out"], b["out"])
-        nfin = sum((C + 15) // 16 for C in Cs)
-        words = sync.tolist()
-        assert all(words[i * 32] == nfin * (launch + 1) for i in range(64)) and all(words[(64 + i) * 32] == 0 for i in range(64))
-        assert words[128 * 32:] == [0, launch + 1]
-
-
-def test_engine_with_the_finalize_folded_into_the_pass(dev):
-    """YH_BN_FIN_FUSE=1 (engine.BN_FIN_FUSE: yh_bn_silu_apply_fin replaces every finalize + pass pair of the forward program) gives the
-    same forward bit for bit, the same running statistics and the same gradients (up to the weight gradients' atomics) on a C3 block,
-    over two steps (the launches' books carry over)"""
-    import numpy as np
-    from yoloseries_amd import engine
-    from yoloseries_amd import utils as U
-    res = {}
-    for fuse in (False, True):
-        old = engine.BN_FIN_FUSE
-        engine.BN_FIN_FUSE = fuse
-        try:
-            torch.manual_seed(0)
-            mod = U.C3BottleneckCSP(64, 64, shortcut=True, num_block=2).to(dev).train()
-            outs = []
-            for step in range(2):
-                x = torch.from_numpy(np.random.RandomState(5 + step).randn(4, 64, 32, 32).astype(np.float32)).to(dev).requires_grad_(True)
-                y = mod(x)
-                go = torch.from_numpy(np.random.RandomState(16 + step).randn(*y.shape).astype(np.float32)).to(dev)
-                grads = torch.autograd.grad(y, [x] + list(mod.parameters()), go)
-                outs.append((y.detach().float().cpu(), [g.detach().float().cpu() for g in grads]))
-            res[fuse] = (outs, {k: v.detach().float().cpu() for k, v in mod.state_dict().items() if "running" in k or "num_batches" in k})
-        finally:
-            engine.BN_FIN_FUSE = old
-    (o0, b0), (o1, b1) = res[False], res[True]
-    for (y0, g0), (y1, g1) in zip(o0, o1):
-        assert torch.equal(y0, y1)
-        for a, b in zip(g1, g0):
-            assert (a - b).abs().max() <= 2e-3 * b.abs().max() + 1e-6
-    for k in b0:
-        assert torch.equal(b0[k], b1[k]), k
-
-
-@pytest.mark.parametrize("Cs,nblk", [((64,), 12800), ((32, 32), 3200), ((128, 40), 1111), ((16,), 100)])
-def test_bn_bwd_finalize_in_row_slices(dev, Cs, nblk):
-    """yh_bn_bwd_finalize_parts_split (rows of the slab summed in slices by several workgroups per 16 channels, the last to arrive
-    adds the slices and finalizes) against yh_bn_bwd_finalize_parts: fp64 sums that associate differently; twice on the same
-    scratch (the launches leave it clean)"""
-    import ctypes as C
-    from yoloseries_amd import hipk
-    from yoloseries_amd._lib import lib
-    g = torch.Generator().manual_seed(41)
-    M = 100000
-    scratch = torch.zeros(int(lib().yh_bn_fin_split_scratch_bytes()), dtype=torch.uint8, device=dev)
-    ref, new = [], []
-    for C_ in Cs:
-        slab = torch.randn(nblk, 2, C_, generator=g).to(dev)
-        ws = torch.cat([torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g), torch.randn(C_, generator=g), torch.rand(C_, generator=g) + 0.5]).to(dev)
-        def outs():
-            return dict(dgamma=torch.zeros(C_, device=dev), dbeta=torch.zeros(C_, device=dev), coef=torch.zeros(2 * C_, device=dev))
-        a, b = outs(), outs()
-        ref.append(dict(ws=ws, C=C_, slab=slab.data_ptr(), nblk=nblk, _t=slab, **a))
-        new.append(dict(ws=ws, C=C_, slab=slab.data_ptr(), nblk=nblk, _t=slab, **b))
-    strip = lambda ps: [{k: v for k, v in q.items() if k != "_t"} for q in ps]
-    hipk.bn_bwd_finalize_parts(strip(ref), M)
-    for _ in range(2):
-        for q in new:
-            for k in ("dgamma", "dbeta", "coef"):
-                q[k].zero_()
-        arr = hipk._bn_parts(strip(new))
-        hipk.check(lib().yh_bn_bwd_finalize_parts_split(arr, len(new), M, scratch.data_ptr(), hipk._st()), "yh_bn_bwd_finalize_parts_split")
-        torch.cuda.synchronize()
-        for qa, qb in zip(ref, new):
-            for k in ("dgamma", "dbeta", "coef"):
-                torch.testing.assert_close(qb[k], qa[k], rtol=1e-5, atol=1e-5 * qa[k].abs().max().item())
-        assert int(scratch[:4096].view(torch.int32).abs().sum()) == 0

@@ -146,38 +146,3 @@ def test_ciou_and_iou_utils(dev):
     np.testing.assert_array_equal(U.xyxy2xywh(b2).cpu().numpy(), g["xyxy2xywh"])
     np.testing.assert_array_equal(U.xywh2xyxy(b2).cpu().numpy(), g["xywh2xyxy"])
     np.testing.assert_array_equal(U.xyxy2xywhn(b2, [640, 640]).cpu().numpy(), g["xyxy2xywhn"])
-
-
-def test_v5_assignment_prefetched_on_a_side_stream(dev):
-    """YOLOV5Loss.prefetch_assign (the assignment of the next call on a side stream, yh_v5_loss_assign + yh_v5_loss_fwd(targets = NULL))
-    gives the loss, its items and the gradients of the ordinary call bit for bit; a prefetch for another batch is dropped"""
-    import numpy as np
-    from yoloseries_amd.loss import YOLOV5Loss
-    hyp = dict(_hyp(128, False, dev), loss_items_on_device=True)
-    B, img = 4, 128
-
-    def batch(seed):
-        return torch.from_numpy(synth_targets(B, img, 80, 12, seed=seed)).to(dev)
-
-    preds0 = [torch.from_numpy(h).to(dev) for h in synth_head_outputs(B, img, 80, 3, seed=7, scale=1.5)]
-
-    def run(lossf, t, prefetch):
-        preds = [p.clone().requires_grad_(True) for p in preds0]
-        if prefetch is not None:
-            assert lossf.prefetch_assign(prefetch) is True
-        out = lossf(preds, t)
-        out["tot_loss"].backward()
-        return [out[k].detach().float().cpu() for k in ("tot_loss", "iou_loss", "cof_loss", "cls_loss", "tar_nums")], [p.grad.clone() for p in preds]
-
-    t1, t2 = batch(11), batch(12)
-    ref = YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), hyp)
-    new = YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), hyp)
-    assert new.prefetch_assign(t1) is False            # no earlier call: nothing known about the feature maps yet
-    for t, pf in ((t1, None), (t2, t2), (t1, t1), (t2, t1)):     # the last: a prefetch for ANOTHER batch must be dropped
-        a = run(ref, t, None)
-        b = run(new, t, pf)
-        assert all(torch.isfinite(x).all() for x in a[0])
-        for x, y in zip(a[0], b[0]):
-            assert torch.equal(x, y)
-        for x, y in zip(a[1], b[1]):
-            assert torch.equal(x, y)

@@ -275,10 +275,10 @@ def test_model_mlx_forward_golden(dev, name):
         _close(o.float().cpu().numpy(), ref, 3e-2, f"v5{name} eval out{i}", outlier_frac=0.002)
 
 
-def _backward_check(dev, key, make, x_np, outs_of):
+def _backward_check(dev, key, make, x_np, outs_of, fixture="g11_round2.npz"):
     """gradients of every parameter and of the input from a fixed output gradient, under both backward schedules
     (weight gradients on the side stream / everything on one stream)"""
-    g = np.load(os.path.join(G, "g11_round2.npz"))
+    g = np.load(os.path.join(G, fixture))
     torch.manual_seed(0)
     model = make().to(dev).train()
     names = [n for n, _ in model.named_parameters()]
@@ -305,7 +305,14 @@ def _backward_check(dev, key, make, x_np, outs_of):
     # (a) the two schedules compute the same thing: identical up to the fp32 atomics of the weight-gradient reduction
     for a, b2 in zip(results[1], results[0]):
         assert np.abs(a - b2).max() <= 2e-3 * (np.abs(a).max() + 1e-30)
-    # (b) against the fp32 reference, with the reference's own bf16 deviation as the bar (see the note above)
+    # (b) against the fp32 reference, with the reference's own bf16 deviation as the bar (see the note above).  A fixture with
+    # `_pcorr` (g14: YOLOv5l) is one where the reference's OWN bf16-autocast backward decorrelates from its fp32 run (training-mode
+    # BatchNorm through ~100 layers from a random init: sampled rel. rms 1.3, correlation 0.1) and a parameter's deviation is a
+    # random draw that changes from run to run with the order of the fp32 atomics (one bn.bias: 0.22 in one run, 0.44 in the next):
+    # there the bars are on the DISTRIBUTION over the 499 parameters — median, 95th percentile and maximum of the gradient-norm
+    # deviation against the same statistics of the reference's bf16 run — plus a gross-error bound per parameter; the
+    # well-conditioned per-parameter check of the same model is test_full_graph_gradients_eval_mode_bn[v5l_frozen]
+    distributional = f"{key}_pcorr" in g.files
     gr = [None] + results[1]
     dev_norm, dev_samp, corr = [], [], []
     for pi, n in enumerate(names):
@@ -320,20 +327,40 @@ def _backward_check(dev, key, make, x_np, outs_of):
             corr.append(float(np.corrcoef(gf[si], samp[pi])[0, 1]))
         assert np.isfinite(gf).all(), n
         # no parameter is grossly wrong (a dropped / doubled contribution shows as O(1) here)
+        if distributional:
+            assert dn <= 0.75, f"{key} grad-norm {n}: {dn:.3f} (calibration {cal[pi, 0]:.3f})"
+            continue
         assert dn <= max(3.0 * cal[pi, 0], 0.0) + 0.25, f"{key} grad-norm {n}: {dn:.3f} (calibration {cal[pi, 0]:.3f})"
         assert ds <= 1.5 * cal[pi, 1] + 0.15, f"{key} grad samples {n}: rel rms {ds:.3f} (calibration {cal[pi, 1]:.3f})"
     dev_norm, dev_samp = np.array(dev_norm), np.array(dev_samp)
     print(f"{key}: per-parameter |norm| deviation median {np.median(dev_norm):.4f} (cal {np.median(cal[:, 0]):.4f}), sampled rel rms median "
           f"{np.median(dev_samp):.3f} (cal {np.median(cal[:, 1]):.3f}), sample correlation median {np.median(corr):.3f}")
     assert np.median(dev_norm) <= 1.25 * np.median(cal[:, 0]) + 0.01
+    if distributional:
+        p95, c95 = np.percentile(dev_norm, 95), np.percentile(cal[:, 0], 95)
+        print(f"{key}: 95th percentile {p95:.3f} (cal {c95:.3f}), max {dev_norm.max():.3f} (cal {cal[:, 0].max():.3f})")
+        assert p95 <= 1.5 * c95 + 0.02 and dev_norm.max() <= 2.0 * cal[:, 0].max() + 0.1
     assert np.median(dev_samp) <= 1.1 * np.median(cal[:, 1]) + 0.02
-    assert np.median(corr) >= 0.85
+    # the samples point the same way as the reference's: 0.85, or — a fixture that stores it (g14) — no worse than what the reference's
+    # own bf16-autocast run reaches against its fp32 run on this model
+    want = 0.85
+    if f"{key}_pcorr" in g.files:
+        want = min(0.85, float(np.nanmedian(g[f"{key}_pcorr"])) - 0.05)
+    assert np.median(corr) >= want, f"{key}: sample correlation median {np.median(corr):.3f} < {want:.3f}"
 
 
 def test_v5s_full_backward_golden(dev):
     from yoloseries_amd import models
     x = np.random.RandomState(1112).rand(2, 3, 256, 256).astype(np.float32)
     _backward_check(dev, "v5s_bwd", lambda: models.YOLOV5Small(3, 80), x, lambda o: list(o))
+
+
+def test_v5l_full_backward_golden(dev):
+    """BASELINE config #4's model (models/normal/yolov5l.py:16-44; 128 ... 1 024-channel layers, three bottlenecks per C3 and more):
+    every parameter gradient of a training-mode step against the reference's (g14, calibrated like the YOLOv5s case)"""
+    from yoloseries_amd import models
+    x = np.random.RandomState(1412).rand(4, 3, 320, 320).astype(np.float32)
+    _backward_check(dev, "v5l_bwd", lambda: models.YOLOV5Large(3, 80), x, lambda o: list(o), fixture="g14_round5.npz")
 
 
 def test_yolox_full_backward_golden(dev):
@@ -460,7 +487,7 @@ def test_program_executor_matches_per_launch_calls(dev):
     assert (g1 - g0).abs().max() <= 1e-4 * g0.abs().max()
 
 
-@pytest.mark.parametrize("key", ["v5s_frozen", "yolox_frozen"])
+@pytest.mark.parametrize("key", ["v5s_frozen", "yolox_frozen", "v5l_frozen"])
 def test_full_graph_gradients_eval_mode_bn(dev, key):
     """A WELL-CONDITIONED check of the whole backward graph: the model in evaluation mode under autograd (BatchNorm on its
     running statistics: no batch coupling, so bf16 rounding is not amplified through ~60 batch normalisations) against the
@@ -468,10 +495,12 @@ def test_full_graph_gradients_eval_mode_bn(dev, key):
     3e-2 of the parameter's largest gradient element — a mis-scaled branch of a concat / upsample / residual / stacked GEMM
     gradient (5-10 %) cannot pass.  Under both backward schedules."""
     from yoloseries_amd import models
-    g = np.load(os.path.join(G, "g12_round3.npz"))
+    g = np.load(os.path.join(G, "g14_round5.npz" if key == "v5l_frozen" else "g12_round3.npz"))
     seed = int(g[f"{key}_seed"][0])
     if key == "v5s_frozen":
         model, xs, outs_of = models.YOLOV5Small(3, 80), 1201, (lambda o: list(o))
+    elif key == "v5l_frozen":            # config #4's model (g14, round 5): 499 parameters, 96 sampled elements each
+        model, xs, outs_of = models.YOLOV5Large(3, 80), 1401, (lambda o: list(o))
     else:
         model, xs, outs_of = models.YOLOXSmall(1, 3, 80, 0.01), 1202, (lambda o: list(o.values()))
     fill_state(model, seed)
@@ -507,6 +536,8 @@ def test_full_graph_gradients_eval_mode_bn(dev, key):
             tol_e, tol_n = max(3e-2, 1.5 * cal_e), max(2e-2, 1.5 * cal_n)
             if kind == "bn":                      # per-channel sums over all pixels: wider floor (the conv weights carry the wiring check)
                 tol_e, tol_n = max(8e-2, 2.0 * cal_e), max(5e-2, 2.0 * cal_n)
+            elif key == "v5l_frozen":             # twice the depth of YOLOv5s in front of the 8 x 8 stage (128 pixels per weight-gradient sum): its
+                tol_n = max(2.5e-2, 2.0 * cal_n)  # 512 -> 512 bottleneck conv, the parameter the reference's own bf16 run is furthest off on (1.1 %), sits at 2.2 %
             worst[kind] = max(worst.get(kind, 0.0), err / (s_max + 1e-30))
             if err > tol_e * s_max + 1e-7 or abs(nrm - s_norm) > tol_n * s_norm + 1e-7:
                 bad.append((n, round(err / (s_max + 1e-30), 4), round(abs(nrm - s_norm) / (s_norm + 1e-30), 4)))
@@ -515,3 +546,92 @@ def test_full_graph_gradients_eval_mode_bn(dev, key):
     # evaluation mode: the running statistics did not move
     for n, b in model.named_buffers():
         assert torch.equal(b.cpu(), rm0[n]), n
+
+
+def test_forward_fuse_deployment_flow(dev):
+    """the reference's deployment fusion (detect_yolov5.py:110-116): `m.conv = fuse_conv_bn(m.conv, m.bn); delattr(m, 'bn');
+    m.forward = m.forward_fuse` on every ConvBnAct — stand-alone block (utils/layer_tools.py:93-94) and whole YOLOv5s — gives the
+    predictions of the unfused evaluation model"""
+    from yoloseries_amd import models
+    from yoloseries_amd.utils.layer_tools import ConvBnAct, fuse_conv_bn
+
+    def fuse_all(model):
+        for m in model.modules():
+            if isinstance(m, ConvBnAct) and hasattr(m, 'bn'):
+                m.conv = fuse_conv_bn(m.conv, m.bn)
+                delattr(m, 'bn')
+                m.forward = m.forward_fuse
+    cb = ConvBnAct(32, 64, 3, 1, 1)
+    fill_state(cb, 1501)
+    cb = cb.to(dev).eval()
+    x = torch.from_numpy(np.random.RandomState(1502).randn(2, 32, 16, 16).astype(np.float32)).to(dev)
+    with pytest.raises(RuntimeError):
+        cb.forward_fuse(x)                                  # not fused yet
+    with torch.no_grad():
+        y0 = cb(x).float().cpu()
+        ref = torch.nn.functional.silu(torch.nn.functional.batch_norm(
+            torch.nn.functional.conv2d(x, cb.conv.weight, None, 1, 1), cb.bn.running_mean, cb.bn.running_var, cb.bn.weight, cb.bn.bias, False, 0.0, cb.bn.eps)).cpu()
+        fuse_all(cb)
+        assert not hasattr(cb, 'bn') and cb.conv.bias is not None and 'bn.weight' not in cb.state_dict()
+        y1 = cb(x).float().cpu()
+    _close(y0.numpy(), ref.numpy(), 3e-2, "ConvBnAct eval vs torch")
+    _close(y1.numpy(), ref.numpy(), 3e-2, "ConvBnAct fused vs torch")
+    assert (y1 - y0).abs().max() <= 2e-2 * max(1.0, ref.abs().max().item())
+    m = models.YOLOV5Small(3, 80)
+    fill_state(m, 1503)
+    m = m.to(dev).eval()
+    xi = torch.from_numpy(np.random.RandomState(1504).rand(2, 3, 64, 64).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        o0 = [o.float().cpu() for o in m(xi)]
+        fuse_all(m)
+        assert not any(k.endswith("bn.weight") for k in m.state_dict())
+        o1 = [o.float().cpu() for o in m(xi)]
+    for a, b in zip(o1, o0):
+        d = (a - b).abs()
+        assert d.max() <= 3e-2 * max(1.0, b.abs().max().item()) and d.mean() <= 3e-3 * max(1.0, b.abs().mean().item())
+
+
+def test_head_wider_than_256_channels_two_streams_vs_serial(dev):
+    """81 classes: the head layers have 3 * 86 = 258 output channels (row pitch 264 > 256), so the partial sums of their bias
+    gradients — on the weight-gradient stream in the two-stream backward — need the scratch sized from the widest head
+    (engine._head_scratch; ADVICE r03: a scratch shared with the main stream's BatchNorm reductions raced).  The two schedules must
+    give the same gradients (up to the fp32 atomics of the weight-gradient reduction), for every parameter incl. the head biases."""
+    from yoloseries_amd import models
+    from yoloseries_amd.loss import YOLOV5Loss
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
+    import bench
+    nc, B, img = 81, 2, 128
+    torch.manual_seed(0)
+    model = models.YOLOV5Small(3, nc).to(dev).train()
+    hyp = bench.make_hyp(dev, img, B)
+    hyp["num_class"] = nc
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(11)).to(dev)
+    t = torch.from_numpy(synth_targets(B, img, nc, 8, seed=12, min_boxes=4)).to(dev)
+    grads = {}
+    for rep in range(3):                                  # three rounds per schedule: a race shows as run-to-run differences
+        for streams in (1, 0):
+            outs = model(x)
+            assert outs[0].shape[1] == 3 * (5 + nc)
+            for prog in model._yh_state()['progs'].values():
+                if prog.bwd_ready:
+                    prog.two_streams = bool(streams)
+            YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), hyp)(outs, t)["tot_loss"].backward()
+            prog = next(iter(model._yh_state()['progs'].values()))
+            assert prog.two_streams == bool(streams) and prog.head_scratch.numel() >= 1024 * 2 * 264
+            if streams:
+                assert all(prog._head_on_side(o, True) for o in prog.outputs)
+            g = model._yh_last_flat_grad.double().cpu()
+            assert torch.isfinite(g).all()
+            grads.setdefault(streams, []).append(g)
+    ref = grads[0][0]
+    scale = ref.abs().max().item()
+    for streams in (1, 0):
+        for g in grads[streams]:
+            assert (g - ref).abs().max().item() <= 2e-3 * scale, f"streams={streams}: {(g - ref).abs().max().item() / scale:.2e}"
+    # the head biases specifically (column sums of the head gradients: the launches that moved to the side stream)
+    off = 0
+    for n, p in model.named_parameters():
+        if n.startswith("detect.") and n.endswith(".bias"):
+            a, b = grads[1][0][off:off + p.numel()], ref[off:off + p.numel()]
+            assert a.abs().max() > 0 and (a - b).abs().max() <= 1e-3 * b.abs().max() + 1e-7, n
+        off += p.numel()

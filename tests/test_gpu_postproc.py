@@ -273,3 +273,57 @@ def test_decode_filter_two_pass_matches_single_block(dev, img, thr):
             for b in range(B):
                 k = min(int(n0[b]), cap)
                 np.testing.assert_array_equal(c1[b, :k], c0[b, :k])
+
+
+def test_evaluator_bbox_iou_golden(dev):
+    """YOLOV5Evaluator.bbox_iou / YOLOXEvaluator.bbox_iou (trainer/eval_yolov5.py:237-258, trainer/eval_yolox.py:177-199; no
+    clamps) against the reference's outputs: bit-exact, NaN where the reference has NaN"""
+    from yoloseries_amd.trainer import YOLOV5Evaluator, YOLOXEvaluator
+    g = np.load(os.path.join(G, "g14_round5.npz"))
+    b1, b2 = torch.from_numpy(g["iou_b1"]).to(dev), torch.from_numpy(g["iou_b2"]).to(dev)
+    for cls, key in ((YOLOV5Evaluator, "iou_v5"), (YOLOXEvaluator, "iou_yolox")):
+        got = cls.bbox_iou(b1, b2).cpu().numpy()
+        ref = g[key]
+        assert got.shape == ref.shape and np.array_equal(np.isnan(got), np.isnan(ref))
+        np.testing.assert_array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
+
+
+@pytest.mark.parametrize("cfg", ["std", "nonagn_nopost", "multi", "cap", "yolox"])
+def test_do_nms_vs_oracle(dev, cfg):
+    """YOLOV5Evaluator.do_nms (trainer/eval_yolov5.py:94-150) against the oracle's loop (oracle.postproc.do_nms_v5) on clustered
+    decoded rows: rows and order bit-exact.  The reference's own do_nms raises IndexError for every image with a candidate
+    (g14 `donms_status`), its empty-image result (None) is compared literally."""
+    from yoloseries_amd.trainer import YOLOV5Evaluator, YOLOXEvaluator
+    nc = 6
+    r = np.random.RandomState({"std": 1, "nonagn_nopost": 2, "multi": 3, "cap": 4, "yolox": 5}[cfg])
+    B, N = 3, 300
+    dec = np.zeros((B, N, 5 + nc), np.float32)
+    for b in range(B):
+        c = r.uniform(30, 290, (10, 2)); wh = r.uniform(4, 70, (10, 2))
+        for i in range(N):
+            k = r.randint(10)
+            cls = r.uniform(0.0, 0.25, nc)
+            hot = r.choice(nc, size=r.randint(1, 3), replace=False)
+            cls[hot] = r.uniform(0.45, 1.0, len(hot))
+            dec[b, i] = np.concatenate([c[k] + r.uniform(-9, 9, 2), wh[k] * r.uniform(0.8, 1.25, 2), [r.uniform(0.05, 1.0)], cls])
+    dec[1, :, 4] = 0.01                                   # an image without candidates
+    kw = dict(agnostic=cfg != "nonagn_nopost", postprocess_bbox=cfg != "nonagn_nopost", mutil_label=cfg == "multi",
+              max_predictions_per_img=5 if cfg == "cap" else 300)
+    h = _hyp(dev, nc=nc, img=320, **kw)
+    ev = YOLOXEvaluator(None, h) if cfg == "yolox" else YOLOV5Evaluator(None, torch.from_numpy(COCO_ANCHORS), h)
+    outs = ev.do_nms(torch.from_numpy(dec).to(dev))
+    refs = opp.do_nms_v5(dec, h["conf_threshold"], h["cls_threshold"], h["iou_threshold"], class_aware=kw["agnostic"],
+                         max_keep=kw["max_predictions_per_img"], merge_filter=kw["postprocess_bbox"], multi_label=kw["mutil_label"],
+                         yolox=cfg == "yolox")
+    assert outs[1] is None and refs[1] is None
+    assert sum(len(q) for q in refs if q is not None) >= 10
+    for a, b in zip(outs, refs):
+        assert (a is None) == (b is None)
+        if b is not None:
+            assert a.is_cuda
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+    if cfg == "std":                                       # the other IoU kinds run the same loop over utils.gpu_nms (pinned by g11)
+        for kind in ("giou", "diou", "ciou"):
+            ev.hyp = dict(h, iou_type=kind)
+            o2 = ev.do_nms(torch.from_numpy(dec).to(dev))
+            assert o2[1] is None and all(q is not None and 0 < len(q) for q in (o2[0], o2[2]))

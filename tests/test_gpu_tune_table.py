@@ -1,0 +1,210 @@
+"""GPU parity of the kernels AT THE JUDGED SHAPES WITH THE SHIPPED LAUNCH TABLE: every training entry of
+yoloseries_amd/tune_defaults.json — the (algo, tile_k, grid_cap) of the forward convolutions / data gradients and the
+(splits, tile_k) of the weight gradients that `bench.py` actually executes for YOLOv5s / YOLOv5l / YOLOXs at batch 64, 640 x 640 —
+is rebuilt from its key as a descriptor at the REAL shape (B = 64, 160^2 ... 20^2 maps, M up to 1.6 M pixels, stream-K over
+192 / 256 workgroups), launched through the C ABI with the shipped parameters and compared with fp32 torch
+(`F.conv2d`, its autograd data / weight gradient) on identical bf16-representable inputs.  Bars as in tests/test_gpu_conv.py:
+bf16 outputs 1e-2 relative + 4e-2 of the scale, fp32 weight gradients 1e-2 of the largest element; BatchNorm partial sums and
+the fused BatchNorm-backward reduction against fp64 sums of the stored values.
+
+All entries run by default (a few minutes); YH_TUNE_TEST_PARTS=n YH_TUNE_TEST_PART=i runs the i-th of n seeded shares."""
+import ctypes as C
+import json
+import os
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _table():
+    with open(os.path.join(ROOT, "yoloseries_amd", "tune_defaults.json")) as f:
+        t = json.load(f)
+    from yoloseries_amd.engine import KEY_CONV, KEY_CONV_P3, KEY_CONV_S2D, KEY_WGRAD
+    conv, wgrad = [], []
+    for k, v in sorted(t.items()):
+        parts = k.split(":")
+        f = [int(x) for x in parts[-1].split(",")]
+        if parts[0] in (KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3) and parts[1] in ("fwd", "dgrad"):
+            conv.append((k, f, v))
+        elif parts[0] in (KEY_WGRAD, KEY_WGRAD + "f"):
+            wgrad.append((k, f, v, parts[0].endswith("f")))
+    return conv, wgrad
+
+
+def _share(items):
+    n = int(os.environ.get("YH_TUNE_TEST_PARTS", "1"))
+    if n <= 1:
+        return items
+    i = int(os.environ.get("YH_TUNE_TEST_PART", "0")) % n
+    order = list(range(len(items)))
+    random.Random(20260504).shuffle(order)
+    return [items[j] for j in sorted(order[i::n])]
+
+
+def _rand_bf16(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=dev) * scale).to(torch.bfloat16)
+
+
+def _close(got, ref, rtol, atol, what):
+    err = (got.float() - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bad.any(), f"{what}: max err {err.max().item():.4g} (ref max {ref.abs().max().item():.4g}), {int(bad.sum())} of {bad.numel()} out of tolerance"
+
+
+def test_shipped_table_covers_the_training_workloads():
+    conv, wgrad = _table()
+    assert len(conv) >= 200 and len(wgrad) >= 100
+    assert all(f[1] == 64 for _, f, _ in conv) and all(f[6] == 64 for _, f, _, _ in wgrad)
+
+
+def test_conv_entries_at_judged_shapes(dev):
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import ConvDesc, YH_CONV_DGRAD, check, lib
+    L = lib()
+    conv, _ = _table()
+    fams = {}
+    for ki, (key, f, (tile_k, grid_cap, algo)) in enumerate(_share(conv)):
+        (mode, B, Ho, Wo, Hi, Wi, k, stride, pad, N, nseg, C0, ld0s, ups0, C1, ups1, ldo, nsplit, accumulate, stats, res, act, bias, scale,
+         bnr, acc_rows) = f
+        assert not res and not act and not bias and not scale and not acc_rows and nsplit == N, key
+        seed = 1000 + 7 * ki
+        segC = [C0, C1][:nseg]
+        segups = [ups0, ups1][:nseg]
+        segs, xs = [], []
+        for si in range(nseg):
+            h, w = Hi >> segups[si], Wi >> segups[si]
+            ld = ld0s if si == 0 else segC[si]
+            buf = _rand_bf16((B, h, w, ld), dev, seed + si)
+            segs.append(hipk.Slice(buf, 0, segC[si], segups[si]))
+            xs.append(buf)
+        Ctot = sum(segC)
+        out = torch.full((B, Ho, Wo, ldo), 3.0, dtype=torch.bfloat16, device=dev)
+        out0 = out.clone()
+        if mode == YH_CONV_DGRAD:
+            # the GEMM's "input" is gy [B][Hi][Wi][Nk] (Nk = forward output channels rounded to 8), its N the forward layer's input channels
+            assert nseg == 1 and not ups0
+            Nk, Cin = C0, N
+            w = (torch.randn(Nk, Cin, k, k, device=dev, generator=torch.Generator(device=dev).manual_seed(seed + 5)) / (Nk * k * k) ** 0.5)
+            w = w.to(torch.bfloat16).float()
+            wp = hipk.pack_weight_dgrad(w)
+            d = hipk.conv_desc(segs, mode, B, Ho, Wo, Hi, Wi, k, stride, pad, wp, N, hipk.Slice(out, 0, N), accumulate=accumulate)
+        else:
+            w = (torch.randn(N, Ctot, k, k, device=dev, generator=torch.Generator(device=dev).manual_seed(seed + 5)) / (Ctot * k * k) ** 0.5)
+            w = w.to(torch.bfloat16).float()
+            wp = hipk.pack_weight_fwd(w)
+            d = hipk.conv_desc(segs, mode, B, Ho, Wo, Hi, Wi, k, stride, pad, wp, N, hipk.Slice(out, 0, N), accumulate=accumulate)
+        d.tile_k, d.grid_cap, d.algo = tile_k, grid_cap, algo
+        st = slab = z = ws = None
+        if stats:
+            st = torch.zeros(L.yh_conv_stat_blocks(C.byref(d)), 2, wp.shape[0], device=dev)
+            d.stats = st.data_ptr()
+        if bnr:
+            z = _rand_bf16((B, Ho, Wo, N), dev, seed + 8)
+            g = torch.Generator(device=dev).manual_seed(seed + 9)
+            ws = torch.cat([torch.rand(N, generator=g, device=dev) + 0.5, torch.randn(N, generator=g, device=dev)])
+            d.bnr_z, d.bnr_ldz, d.bnr_C, d.bnr_ws = z.data_ptr(), N, N, ws.data_ptr()
+            d.bnr_part = out.data_ptr()                     # placeholder: the row count only looks at null / non-null
+            rows = L.yh_conv_bnr_rows(C.byref(d))
+            assert rows > 0, f"{key}: the shipped entry asks for the fused reduction but the kernel family cannot take it"
+            slab = torch.zeros(rows, 2, N, device=dev)
+            d.bnr_part = slab.data_ptr()
+        name = C.create_string_buffer(96)
+        check(L.yh_conv_kernel_name(C.byref(d), name, 96), "yh_conv_kernel_name")
+        fams[name.value.decode().split("<")[0]] = fams.get(name.value.decode().split("<")[0], 0) + 1
+        check(L.yh_conv_igemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), f"yh_conv_igemm [{key}]")
+        # fp32 torch reference of the same op
+        if mode == YH_CONV_DGRAD:
+            gy = xs[0][..., :C0].float().permute(0, 3, 1, 2)
+            ref = torch.nn.grad.conv2d_input((B, N, Ho, Wo), w, gy, stride=stride, padding=pad).permute(0, 2, 3, 1)
+        else:
+            parts = []
+            for si in range(nseg):
+                x = xs[si][..., :segC[si]].float().permute(0, 3, 1, 2)
+                parts.append(F.interpolate(x, scale_factor=2, mode="nearest") if segups[si] else x)
+            ref = F.conv2d(torch.cat(parts, 1), w, None, stride=stride, padding=pad).permute(0, 2, 3, 1)
+        if accumulate:
+            ref = ref.to(torch.bfloat16).float() + out0[..., :N].float()
+        torch.cuda.synchronize()
+        _close(out[..., :N], ref, 1e-2, 4e-2, key)
+        assert torch.equal(out[..., N:], out0[..., N:]), f"{key}: wrote outside its channel slice"
+        o = out[..., :N].float().reshape(-1, N).double()
+        if stats:
+            # BatchNorm partial sums: some families sum the fp32 accumulators, others the stored (bf16-rounded) values — both are within
+            # the rounding noise of the stored tensor: per element <= 2^-9 |v|, random sign, i.e. a random walk of 2^-9 sqrt(sum v^2)
+            # (six sigma allowed); the sum of squares carries 2 v e
+            s1, s2 = st[:, 0, :N].double().sum(0), st[:, 1, :N].double().sum(0)
+            n1 = 2.0 ** -9 * (o * o).sum(0).sqrt() * 3.5 + 1e-2
+            n2 = 2.0 ** -8 * (o ** 4).sum(0).sqrt() * 3.5 + 1e-2
+            assert ((s1 - o.sum(0)).abs() <= n1 + 1e-5 * o.abs().sum(0)).all(), f"{key}: sum {(s1 - o.sum(0)).abs().max().item():.4g} vs noise bound {n1.max().item():.4g}"
+            assert ((s2 - (o * o).sum(0)).abs() <= n2 + 1e-5 * (o * o).sum(0)).all(), f"{key}: sum of squares {(s2 - (o * o).sum(0)).abs().max().item():.4g} vs {n2.max().item():.4g}"
+        if bnr:
+            zz = z.float().reshape(-1, N).double()
+            a = zz * ws[:N].double() + ws[N:].double()
+            sg = torch.sigmoid(a)
+            dz = o * (sg * (1 + a * (1 - sg)))
+            got = slab.double().sum(0)
+            assert torch.allclose(got[0], dz.sum(0), rtol=2e-3, atol=2e-3 * dz.abs().sum(0).max().item()), key
+            assert torch.allclose(got[1], (dz * zz).sum(0), rtol=2e-3, atol=2e-3 * (dz * zz).abs().sum(0).max().item()), key
+        del out, out0, ref, xs, segs, w, wp, st, slab, z, ws
+    print("kernel families exercised:", dict(sorted(fams.items())))
+    assert len(fams) >= 5
+
+
+def test_wgrad_entries_at_judged_shapes(dev):
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import check, lib
+    L = lib()
+    _, wgrad = _table()
+    fams = {}
+    for ki, (key, f, (splits, tile_k), fused) in enumerate(_share(wgrad)):
+        N, ldg, C0, ld0, ups, Ctot, B, Ho, Wo, Hi, Wi, k, stride, pad = f
+        seed = 5000 + 11 * ki
+        M = B * Ho * Wo
+        coff = Ctot - C0                                     # place the segment at the END of the layer's input channels
+        x = _rand_bf16((B, Hi >> ups, Wi >> ups, ld0), dev, seed)
+        gy = _rand_bf16((B, Ho, Wo, ldg), dev, seed + 1, 0.25)
+        dw = torch.zeros(N, k * k * Ctot, device=dev)
+        d = hipk.wgrad_desc(hipk.Slice(gy, 0, N), N, hipk.Slice(x, 0, C0, ups), coff, Ctot, B, Ho, Wo, Hi, Wi, k, stride, pad, dw, splits)
+        d.tile_k = tile_k
+        gz_ref = gy[..., :N].float()
+        if fused:
+            # the stem: gz is formed from (ga, z) where the gy tile is staged (yh_wgrad_desc.bn_*), bit for bit the apply pass's gz
+            g = torch.Generator(device=dev).manual_seed(seed + 2)
+            z = _rand_bf16((B, Ho, Wo, N), dev, seed + 3)
+            mean, invstd = torch.randn(N, generator=g, device=dev) * 0.3, torch.rand(N, generator=g, device=dev) + 0.5
+            gamma = torch.rand(N, generator=g, device=dev) + 0.5
+            beta = torch.randn(N, generator=g, device=dev) * 0.2
+            scale = gamma * invstd
+            ws = torch.cat([scale, beta - mean * scale, mean, invstd])
+            coef = torch.cat([torch.randn(N, generator=g, device=dev) * 0.05, torch.randn(N, generator=g, device=dev) * 0.05])
+            gz = torch.zeros(B, Ho, Wo, N, dtype=torch.bfloat16, device=dev)
+            hipk.bn_silu_bwd_apply(hipk.Slice(gy, 0, N), hipk.full(z), ws, gamma, coef, M, hipk.full(gz))
+            gz_ref = gz.float()
+            d.bn_z, d.bn_ldz = z.data_ptr(), N
+            d.bn_ws, d.bn_gamma, d.bn_coef = ws.data_ptr(), gamma.data_ptr(), coef.data_ptr()
+        name = Program_wgrad_name(L, d)
+        fams[name.split("<")[0]] = fams.get(name.split("<")[0], 0) + 1
+        check(L.yh_conv_wgrad(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), f"yh_conv_wgrad [{key}]")
+        xin = x[..., :C0].float().permute(0, 3, 1, 2)
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        rw = torch.nn.grad.conv2d_weight(xin, (N, C0, k, k), gz_ref.permute(0, 3, 1, 2), stride=stride, padding=pad)
+        rw = rw.permute(0, 2, 3, 1)                          # [N][kh][kw][C0]
+        torch.cuda.synchronize()
+        got = dw.view(N, k, k, Ctot)
+        _close(got[..., coff:], rw, 1e-2, 1e-2 * rw.abs().max().item(), key)
+        assert not got[..., :coff].any(), f"{key}: wrote outside its column slice"
+        del x, gy, dw, rw, got, xin
+    print("kernel families exercised:", dict(sorted(fams.items())))
+    assert "conv_wgs_kernel" in fams
+
+
+def Program_wgrad_name(L, d):
+    from yoloseries_amd.engine import Program
+    return Program._wgrad_name(L, d)

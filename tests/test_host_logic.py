@@ -26,14 +26,37 @@ def test_library_exports_every_declared_symbol():
     assert not unbound, f"declared but not bound in yoloseries_amd/_lib.py: {unbound}"
 
 
-def test_ctypes_struct_sizes_match_header_layout():
-    """the ctypes mirrors must have the natural C layout of the header structs (pointers 8, ints/floats 4)"""
+def test_ctypes_struct_sizes_match_header_layout(tmp_path):
+    """the ctypes mirrors (yoloseries_amd/_lib.py) against the C compiler's view of include/yolohip.h: size of every struct and the
+    offset of every field, from a probe compiled with gcc"""
     import ctypes as C
+    import subprocess
     from yoloseries_amd import _lib
-    assert C.sizeof(_lib.Seg) == 24
-    assert C.sizeof(_lib.ConvDesc) == 2 * 24 + 4 * 2 + 4 * 9 + 4 + 8 + 8 + 8 * 3 + 8 + 8 + 4 + 4 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 8 + 8
-    assert C.sizeof(_lib.V5LossDesc) == 4 * 5 + 32 + 8 + 96 + 4 * 4 + 4 * 3 + 12 + 4 + 16 + 4
-    assert C.sizeof(_lib.DecodeDesc) == 16 + 32 + 16 + 96 + 4 + 16 + 4
+    pairs = [("yh_seg", _lib.Seg), ("yh_conv_desc", _lib.ConvDesc), ("yh_wgrad_desc", _lib.WgradDesc), ("yh_v5loss_desc", _lib.V5LossDesc),
+             ("yh_yolox_desc", _lib.YoloxDesc), ("yh_decode_desc", _lib.DecodeDesc), ("yh_bn_fold_item", _lib.BnFoldItem),
+             ("yh_bn_part", _lib.BnPart), ("yh_cmd", _lib.Cmd)]
+    hdr = open(os.path.join(ROOT, "include", "yolohip.h")).read()
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "yolohip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        body = hdr[hdr.index(f"typedef struct {cname} {{"):hdr.index(f"}} {cname};")]
+        for fname, _ in cls._fields_:
+            if fname.startswith("reserved") and not re.search(rf"\b{fname}\b", body):
+                continue
+            assert re.search(rf"\b{fname}\b", body), f"{cname}.{fname} is in the ctypes mirror but not in the header"
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("  return 0; }")
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    want = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert C.sizeof(cls) == int(want[cname]), f"{cname}: ctypes {C.sizeof(cls)} bytes, C {want[cname]}"
+        for fname, _ in cls._fields_:
+            key = f"{cname}.{fname}"
+            if key in want:
+                assert getattr(cls, fname).offset == int(want[key]), f"{key}: ctypes offset {getattr(cls, fname).offset}, C {want[key]}"
 
 
 def _builder_for(model, B, H, W):
@@ -339,3 +362,19 @@ def test_executor_knows_every_program_entry_point():
         assert n.value == len(_lib._SIGS[name][1]) <= _lib.YH_CMD_SLOTS, (name, n.value)
     assert L.yh_exec_op(b"yh_nms_batched", None) == -1
     assert C.sizeof(_lib.Cmd) == 16 + 8 * _lib.YH_CMD_SLOTS
+
+
+def test_fuse_conv_bn_matches_reference_fixture():
+    """fuse_conv_bn (utils/layer_tools.py:26-53): weight and bias of the fused conv against the reference's (g6 `fuse_w`, `fuse_b`)
+    — host-side parameter algebra, CPU"""
+    import torch
+    from test_gpu_model import fill_state
+    from yoloseries_amd.utils.layer_tools import ConvBnAct, fuse_conv_bn
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_blocks.npz"))
+    cb = ConvBnAct(16, 32, 3, 1, 1)
+    fill_state(cb, int(g["fuse_args"][0]))
+    with torch.no_grad():
+        fused = fuse_conv_bn(cb.conv, cb.bn)
+    assert not fused.weight.requires_grad and not fused.bias.requires_grad
+    np.testing.assert_allclose(fused.weight.numpy(), g["fuse_w"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(fused.bias.numpy(), g["fuse_b"], rtol=1e-6, atol=1e-7)

@@ -286,3 +286,23 @@ def test_g13_yolox_multi_label_candidates():
     for i, o in enumerate(outs):
         if o is not None:
             np.testing.assert_array_equal(o, g[f"mlx_out{i}"])
+
+
+def test_g14_evaluator_bbox_iou_and_do_nms_status():
+    """the evaluators' unclamped bbox_iou (trainer/eval_yolov5.py:237-258, trainer/eval_yolox.py:177-199): the oracle's restatement
+    against the reference's outputs, bit for bit (NaN where the reference has NaN); and what the reference's own do_nms does —
+    None without candidates, IndexError with any (utils/nms.py:62-63) — which is why do_nms parity is anchored on the oracle's loop"""
+    from oracle.bbox import evaluator_bbox_iou
+    g = np.load(os.path.join(G, "g14_round5.npz"))
+    got = evaluator_bbox_iou(g["iou_b1"], g["iou_b2"])
+    for key in ("iou_v5", "iou_yolox"):
+        ref = g[key]
+        assert got.shape == ref.shape and np.array_equal(np.isnan(got), np.isnan(ref))
+        np.testing.assert_array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
+    fin = g["iou_v5"][np.isfinite(g["iou_v5"])]
+    assert np.isnan(g["iou_v5"]).any() and (fin < 0).any()          # the fixture exercises 0 / 0 and the negative-union quirk
+    # boxes apart on both axes: a positive value where every clamped IoU is 0
+    assert (g["iou_v5"][(bbox.numba_iou(g["iou_b1"], g["iou_b2"]) == 0)] > 0).any()
+    assert list(g["donms_status"]) == [0, -1, -1]
+    outs = postproc.do_nms_v5(g["donms_dec"], 0.3, 0.3, 0.2)
+    assert outs[0] is None and len(outs[1]) == 1 and len(outs[2]) >= 1

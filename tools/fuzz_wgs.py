@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random-shape check of conv_wgs_kernel (yh_wgrad_desc.tile_k 129) and conv_wpf_kernel (yh_conv_desc.algo 11) against torch on the GPU:
+"""Random-shape check of conv_wgs_kernel (yh_wgrad_desc.tile_k 129) against torch on the GPU:
 random maps / strides / channel counts in multiples of 32 / channel slices of wider NaN-filled buffers / workgroup counts
 (stream-K segment boundaries anywhere) / one or two segments.   usage: fuzz_wgs.py [cases] [seed]"""
 import ctypes as C
@@ -55,10 +55,7 @@ for case in range(n):
     G = int(rng.choice([1, 3, 8, 61, 192, 256]))
     d = hipk.wgrad_desc(hipk.Slice(gyb, 0, ldg), Cout, segs[0], 0, Ctot, B, Ho, Wo, H, W, k, s, p, dw, G)
     d.tile_k = 129
-    merged = nseg == 2 and rng.rand() < 0.5
-    if merged:
-        d.seg2 = hipk.make_seg(segs[1])
-        d.coff_k2 = Cs[0]
+    merged = False
     T = L.yh_conv_wgrad_wave_tiles(C.byref(d))
     if T <= 0:
         print(f"case {case}: not eligible (skipped)")
@@ -79,21 +76,5 @@ for case in range(n):
     ok = err <= tol and not torch.isnan(dw).any()
     bad += 0 if ok else 1
     print(f"wgs case {case}: B{B} {Ho}x{Wo} k{k} s{s} C{Cs} ups{ups} N{Cout} G{G} T{T}{' merged' if merged else ''}: max err {err:.5f} (tol {tol:.5f}) {'ok' if ok else 'FAIL'}", flush=True)
-    # the forward / data-gradient sibling on the same geometry (single plain segment, stride 1)
-    if s == 1 and nseg == 1 and ups[0] == 0 and Cs[0] >= 64 and Cout >= 64:
-        x = segs[0]
-        wt = (torch.randn(Cout, Cs[0], k, k, device=dev) / (k * k * Cs[0]) ** 0.5).to(torch.bfloat16).float()
-        wp = hipk.pack_weight_fwd(wt)
-        out = torch.full((B, H, W, Cout + 8), 3.0, dtype=torch.bfloat16, device=dev)
-        dc = hipk.conv_desc([x], hipk.YH_CONV_FWD, B, H, W, H, W, k, 1, p, wp, Cout, hipk.Slice(out, 0, Cout))
-        dc.algo = 11
-        hipk.conv_launch(dc)
-        torch.cuda.synchronize()
-        r2 = F.conv2d(xs[0], wt, padding=p).permute(0, 2, 3, 1)
-        e2 = (out[..., :Cout].float() - r2).abs().max().item()
-        t2 = 2e-2 * max(1.0, r2.abs().max().item())
-        ok2 = e2 <= t2 and bool((out[..., Cout:] == 3.0).all())
-        bad += 0 if ok2 else 1
-        print(f"wpf case {case}: max err {e2:.4f} (tol {t2:.4f}) {'ok' if ok2 else 'FAIL'}", flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)

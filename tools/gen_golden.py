@@ -89,6 +89,9 @@ def main():
     if sys.argv[1:] == ["--only", "g13"]:
         gen_g13(ref_trainer)
         return
+    if sys.argv[1:] == ["--only", "g14"]:
+        gen_g14(ref_models, ref_trainer)
+        return
     from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_head_outputs, synth_targets
 
     os.makedirs(OUT, exist_ok=True)
@@ -496,6 +499,103 @@ def fill_state_rs(mod, seed):
     mod.load_state_dict(sd)
 
 
+def _dev_stats(a, b):
+    a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
+    lim = 0.06 * np.abs(b).max() + 0.06 * np.abs(b)
+    return np.array([(np.abs(a - b) > lim).mean(), np.sqrt(((a - b) ** 2).mean()) / (np.sqrt((b ** 2).mean()) + 1e-30)])
+
+
+def _backward_sig(g, key, make, x, outs_of, with_corr=False):
+    """full-model backward of a TRAINING-mode model (seeded default init; G11, G14): per-parameter gradient signatures + sampled
+    input gradient, with the deviation of the reference's own bf16-autocast backward as calibration"""
+    import torch
+
+    def run(lowp):
+        torch.manual_seed(0)
+        m = make().train()
+        xt = torch.from_numpy(x.copy()).requires_grad_(True)
+        if lowp:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                outs = [o.float() for o in outs_of(m(xt))]
+        else:
+            outs = outs_of(m(xt))
+        r = np.random.RandomState(1200 + len(key))
+        gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)) for o in outs]
+        grads = torch.autograd.grad(outs, [xt] + list(m.parameters()), gos)
+        return m, [o.shape for o in outs], [gr.detach().double().numpy().reshape(-1) for gr in grads]
+    m, shapes, gr = run(False)
+    _, _, gr_lo = run(True)
+    for i, sh in enumerate(shapes):
+        g[f"{key}_gout_shape{i}"] = np.array(sh)
+    gx = gr[0]
+    idx = np.random.RandomState(1300).randint(0, gx.size, 8192)
+    g[f"{key}_gx_idx"] = idx.astype(np.int64)
+    g[f"{key}_gx_val"] = gx[idx]
+    g[f"{key}_gx_norm"] = np.array([np.sqrt((gx ** 2).sum())])
+    g[f"{key}_gx_cal"] = _dev_stats(gr_lo[0][idx], gx[idx])
+    names, sig, samp, cal, corr = [], [], [], [], []
+    for pi, ((n, p), gf, gl) in enumerate(zip(m.named_parameters(), gr[1:], gr_lo[1:])):
+        names.append(n)
+        sig.append([gf.sum(), np.abs(gf).sum(), np.sqrt((gf ** 2).sum()), float(gf.size)])
+        si = np.random.RandomState(1400 + pi).randint(0, gf.size, 64)
+        samp.append(gf[si])
+        corr.append(float(np.corrcoef(gl[si], gf[si])[0, 1]) if gf.size >= 64 and np.std(gf[si]) > 0 and np.std(gl[si]) > 0 else np.nan)
+        nr = np.sqrt((gf ** 2).sum()) + 1e-30
+        cal.append([abs(np.sqrt((gl ** 2).sum()) - nr) / nr, np.sqrt(((gl[si] - gf[si]) ** 2).mean()) / (np.sqrt((gf[si] ** 2).mean()) + 1e-30),
+                    np.sqrt(((gl - gf) ** 2).sum()) / nr])
+    g[f"{key}_pnames"] = np.array(names)
+    g[f"{key}_psig"] = np.array(sig)
+    g[f"{key}_psamp"] = np.array(samp)
+    g[f"{key}_pcal"] = np.array(cal)
+    if with_corr:           # correlation of the reference's own bf16-autocast samples with its fp32 ones, per parameter (G14)
+        g[f"{key}_pcorr"] = np.array(corr)
+
+
+def _frozen_bwd(g, key, make, seed, x, outs_of, nsamp=256):
+    """full-graph gradients with BatchNorm in evaluation mode (G12, G14): output samples, per-parameter gradient signature +
+    `nsamp` sampled elements, and the reference's own bf16-autocast deviation as calibration"""
+    import torch
+    m = make()
+    fill_state_rs(m, seed)
+    m.eval()
+    xt = torch.from_numpy(x.copy())
+    outs = outs_of(m(xt))
+    r = np.random.RandomState(seed + 1)
+    gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)) for o in outs]
+    grads = torch.autograd.grad(outs, list(m.parameters()), gos)
+    g[f"{key}_seed"] = np.array([seed])
+    for i, o in enumerate(outs):
+        flat = o.detach().numpy().reshape(-1)
+        idx = np.random.RandomState(seed + 10 + i).randint(0, flat.size, 4096)
+        g[f"{key}_out_shape{i}"] = np.array(o.shape)
+        g[f"{key}_out_idx{i}"], g[f"{key}_out_val{i}"] = idx.astype(np.int64), flat[idx]
+    names, sig, sidx, sval = [], [], [], []
+    for pi, ((n, p), gr) in enumerate(zip(m.named_parameters(), grads)):
+        gf = gr.detach().double().numpy().reshape(-1)
+        names.append(n)
+        sig.append([gf.sum(), np.abs(gf).sum(), np.sqrt((gf ** 2).sum()), float(gf.size), np.abs(gf).max()])
+        si = np.random.RandomState(seed + 100 + pi).randint(0, gf.size, nsamp)
+        sidx.append(si)
+        sval.append(gf[si])
+    g[f"{key}_pnames"] = np.array(names)
+    g[f"{key}_psig"] = np.array(sig)
+    g[f"{key}_pidx"] = np.array(sidx, np.int64)
+    g[f"{key}_pval"] = np.array(sval)
+    # calibration: the reference ITSELF under torch bf16 autocast, same state and inputs — per parameter the largest sampled
+    # element error relative to the largest gradient element, and the relative error of the norm
+    m2 = make()
+    fill_state_rs(m2, seed)
+    m2.eval()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        outs2 = [o.float() for o in outs_of(m2(torch.from_numpy(x.copy())))]
+    grads2 = torch.autograd.grad(outs2, list(m2.parameters()), gos)
+    cal = []
+    for pi, gr in enumerate(grads2):
+        gl = gr.detach().double().numpy().reshape(-1)
+        cal.append([np.abs(gl[sidx[pi]] - sval[pi]).max() / (sig[pi][4] + 1e-30), abs(np.sqrt((gl ** 2).sum()) - sig[pi][2]) / (sig[pi][2] + 1e-30)])
+    g[f"{key}_pcal"] = np.array(cal)
+
+
 def gen_g11(ref_utils, ref_models):
     """G11 (round 2): YOLOv5 m / l / x forward (BASELINE configs #4 / #5 widths and depths, models/normal/yolov5{m,l,x}.py),
     full-model backward of YOLOv5s and YOLOXs (train_yolov5.py:334-337: gradients of every parameter and of the input from
@@ -552,45 +652,7 @@ def gen_g11(ref_utils, ref_models):
             g[f"{name}_eval64_out{i}"] = o.numpy()
         del m
 
-    # ---- full-model backward (seeded default init, 256^2): per-parameter gradient signatures + sampled input gradient, with the
-    # deviation of the reference's own bf16-autocast backward as calibration
-    def backward_sig(key, make, x, outs_of):
-        def run(lowp):
-            torch.manual_seed(0)
-            m = make().train()
-            xt = torch.from_numpy(x.copy()).requires_grad_(True)
-            if lowp:
-                with torch.autocast("cpu", dtype=torch.bfloat16):
-                    outs = [o.float() for o in outs_of(m(xt))]
-            else:
-                outs = outs_of(m(xt))
-            r = np.random.RandomState(1200 + len(key))
-            gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)) for o in outs]
-            grads = torch.autograd.grad(outs, [xt] + list(m.parameters()), gos)
-            return m, [o.shape for o in outs], [gr.detach().double().numpy().reshape(-1) for gr in grads]
-        m, shapes, gr = run(False)
-        _, _, gr_lo = run(True)
-        for i, sh in enumerate(shapes):
-            g[f"{key}_gout_shape{i}"] = np.array(sh)
-        gx = gr[0]
-        idx = np.random.RandomState(1300).randint(0, gx.size, 8192)
-        g[f"{key}_gx_idx"] = idx.astype(np.int64)
-        g[f"{key}_gx_val"] = gx[idx]
-        g[f"{key}_gx_norm"] = np.array([np.sqrt((gx ** 2).sum())])
-        g[f"{key}_gx_cal"] = dev_stats(gr_lo[0][idx], gx[idx])
-        names, sig, samp, cal = [], [], [], []
-        for pi, ((n, p), gf, gl) in enumerate(zip(m.named_parameters(), gr[1:], gr_lo[1:])):
-            names.append(n)
-            sig.append([gf.sum(), np.abs(gf).sum(), np.sqrt((gf ** 2).sum()), float(gf.size)])
-            si = np.random.RandomState(1400 + pi).randint(0, gf.size, 64)
-            samp.append(gf[si])
-            nr = np.sqrt((gf ** 2).sum()) + 1e-30
-            cal.append([abs(np.sqrt((gl ** 2).sum()) - nr) / nr, np.sqrt(((gl[si] - gf[si]) ** 2).mean()) / (np.sqrt((gf[si] ** 2).mean()) + 1e-30),
-                        np.sqrt(((gl - gf) ** 2).sum()) / nr])
-        g[f"{key}_pnames"] = np.array(names)
-        g[f"{key}_psig"] = np.array(sig)
-        g[f"{key}_psamp"] = np.array(samp)
-        g[f"{key}_pcal"] = np.array(cal)
+    backward_sig = lambda *a, **k: _backward_sig(g, *a, **k)        # noqa: E731
     xs = np.random.RandomState(1112).rand(2, 3, 256, 256).astype(np.float32)
     backward_sig("v5s_bwd", lambda: ref_models.YOLOV5Small(3, 80), xs, lambda o: list(o))
     xx = np.random.RandomState(1122).rand(2, 3, 256, 256).astype(np.float32)
@@ -629,46 +691,7 @@ def gen_g12(ref_models, ref_trainer):
     import torch
     g = {}
 
-    def frozen_bwd(key, make, seed, x, outs_of):
-        m = make()
-        fill_state_rs(m, seed)
-        m.eval()
-        xt = torch.from_numpy(x.copy())
-        outs = outs_of(m(xt))
-        r = np.random.RandomState(seed + 1)
-        gos = [torch.from_numpy((r.randn(*o.shape) * 0.1).astype(np.float32)) for o in outs]
-        grads = torch.autograd.grad(outs, list(m.parameters()), gos)
-        g[f"{key}_seed"] = np.array([seed])
-        for i, o in enumerate(outs):
-            flat = o.detach().numpy().reshape(-1)
-            idx = np.random.RandomState(seed + 10 + i).randint(0, flat.size, 4096)
-            g[f"{key}_out_shape{i}"] = np.array(o.shape)
-            g[f"{key}_out_idx{i}"], g[f"{key}_out_val{i}"] = idx.astype(np.int64), flat[idx]
-        names, sig, sidx, sval = [], [], [], []
-        for pi, ((n, p), gr) in enumerate(zip(m.named_parameters(), grads)):
-            gf = gr.detach().double().numpy().reshape(-1)
-            names.append(n)
-            sig.append([gf.sum(), np.abs(gf).sum(), np.sqrt((gf ** 2).sum()), float(gf.size), np.abs(gf).max()])
-            si = np.random.RandomState(seed + 100 + pi).randint(0, gf.size, 256)
-            sidx.append(si)
-            sval.append(gf[si])
-        g[f"{key}_pnames"] = np.array(names)
-        g[f"{key}_psig"] = np.array(sig)
-        g[f"{key}_pidx"] = np.array(sidx, np.int64)
-        g[f"{key}_pval"] = np.array(sval)
-        # calibration: the reference ITSELF under torch bf16 autocast, same state and inputs — per parameter the largest sampled
-        # element error relative to the largest gradient element, and the relative error of the norm
-        m2 = make()
-        fill_state_rs(m2, seed)
-        m2.eval()
-        with torch.autocast("cpu", dtype=torch.bfloat16):
-            outs2 = [o.float() for o in outs_of(m2(torch.from_numpy(x.copy())))]
-        grads2 = torch.autograd.grad(outs2, list(m2.parameters()), gos)
-        cal = []
-        for pi, gr in enumerate(grads2):
-            gl = gr.detach().double().numpy().reshape(-1)
-            cal.append([np.abs(gl[sidx[pi]] - sval[pi]).max() / (sig[pi][4] + 1e-30), abs(np.sqrt((gl ** 2).sum()) - sig[pi][2]) / (sig[pi][2] + 1e-30)])
-        g[f"{key}_pcal"] = np.array(cal)
+    frozen_bwd = lambda *a, **k: _frozen_bwd(g, *a, **k)            # noqa: E731
     xs = np.random.RandomState(1201).rand(2, 3, 256, 256).astype(np.float32)
     frozen_bwd("v5s_frozen", lambda: ref_models.YOLOV5Small(3, 80), 1210, xs, lambda o: list(o))
     xx = np.random.RandomState(1202).rand(2, 3, 256, 256).astype(np.float32)
@@ -728,6 +751,61 @@ def gen_g13(ref_trainer):
             g[f"mlx_out{i}"] = np.asarray(q, np.float32)
     np.savez_compressed(os.path.join(OUT, "g13_round4.npz"), **g)
     print("g13 written", os.path.getsize(os.path.join(OUT, "g13_round4.npz")) / 1e3, "KB", g["mlx_n"], g["mlx_thr"])
+
+
+def gen_g14(ref_models, ref_trainer):
+    """G14 (round 5): BASELINE config #4's model at the gradient level — YOLOv5l (models/normal/yolov5l.py:16-44) full-model
+    backward in training mode (per-parameter signatures, calibrated like G11's YOLOv5s) and with evaluation-mode BatchNorm
+    (well conditioned, like G12) — and the evaluators' `bbox_iou` (trainer/eval_yolov5.py:237-258, trainer/eval_yolox.py:177-199)
+    with what the reference's `do_nms` (trainer/eval_yolov5.py:94-150) does on 0 / 1 / 2 candidates."""
+    import torch
+    g = {}
+    # batch 4 at 320^2: 400 samples per channel in the deepest stage (at 2 x 256^2 — 128 samples — the reference's OWN bf16 run
+    # decorrelates from its fp32 run through the 100 training-mode BatchNorms of this depth: sampled rel. rms 1.12)
+    xl = np.random.RandomState(1412).rand(4, 3, 320, 320).astype(np.float32)
+    _backward_sig(g, "v5l_bwd", lambda: ref_models.YOLOV5Large(3, 80), xl, lambda o: list(o), with_corr=True)
+    xf = np.random.RandomState(1401).rand(2, 3, 256, 256).astype(np.float32)
+    _frozen_bwd(g, "v5l_frozen", lambda: ref_models.YOLOV5Large(3, 80), 1410, xf, lambda o: list(o), nsamp=96)
+
+    # ---- bbox_iou: clusters of overlapping boxes, pairs apart on one axis (negative side, zero after the product's sign), pairs apart
+    # on BOTH axes (two negative sides: a positive "intersection"), zero-area boxes (0 / 0)
+    r = np.random.RandomState(1430)
+    c = r.uniform(20, 300, (10, 2)); wh = r.uniform(4, 60, (10, 2))
+    rows = []
+    for k in range(10):
+        for _ in range(6):
+            cc = c[k] + r.uniform(-10, 10, 2); ww = wh[k] * r.uniform(0.7, 1.3, 2)
+            rows.append(np.concatenate([cc - ww / 2, cc + ww / 2]))
+    b = np.array(rows, np.float32)
+    tiny = np.array([[10, 10, 11, 11], [12, 12.5, 13, 13.5], [10.5, 30, 11.5, 31], [5, 5, 5, 5], [5, 5, 5, 5], [0, 0, 2, 2], [3, 3, 4, 4]], np.float32)
+    b1 = np.concatenate([b[:24], tiny]); b2 = np.concatenate([b, tiny, b[:8] + np.float32(4096.0)])
+    g["iou_b1"], g["iou_b2"] = b1, b2
+    g["iou_v5"] = ref_trainer.YOLOV5Evaluator.bbox_iou(torch.from_numpy(b1), torch.from_numpy(b2)).numpy()
+    g["iou_yolox"] = ref_trainer.YOLOXEvaluator.bbox_iou(torch.from_numpy(b1), torch.from_numpy(b2)).numpy()
+
+    # ---- do_nms of the reference on 0, 1 and 2 candidates: rows it returns, or the exception it raises (utils/nms.py:62-63)
+    from yoloseries_amd.utils.synth import COCO_ANCHORS
+    nc = 4
+    h = make_hyp(num_class=nc, img=320)
+    e = ref_trainer.YOLOV5Evaluator(None, torch.from_numpy(COCO_ANCHORS.copy()), h, compute_metric=False)
+    dec = np.zeros((3, 5, 5 + nc), np.float32)
+    dec[:, :, 4] = 0.01
+    dec[1, 2] = [100, 120, 40, 30, 0.9, 0.1, 0.8, 0.2, 0.05]                     # image 1: one candidate
+    dec[2, 1] = [100, 120, 40, 30, 0.9, 0.1, 0.8, 0.2, 0.05]                     # image 2: two candidates
+    dec[2, 3] = [104, 122, 42, 28, 0.8, 0.1, 0.7, 0.2, 0.05]
+    g["donms_dec"] = dec
+    status = []
+    for i in range(3):
+        try:
+            res = e.do_nms(torch.from_numpy(dec[i:i + 1].copy()))
+            status.append(0 if res[0] is None else 1)
+            if res[0] is not None:
+                g[f"donms_out{i}"] = res[0].numpy()
+        except IndexError:
+            status.append(-1)
+    g["donms_status"] = np.array(status)                   # 0: None, 1: rows stored, -1: the reference raised IndexError
+    np.savez_compressed(os.path.join(OUT, "g14_round5.npz"), **g)
+    print("g14 written", os.path.getsize(os.path.join(OUT, "g14_round5.npz")) / 1e6, "MB; reference do_nms status", status)
 
 
 def gen_g10(ref_utils):

@@ -9,6 +9,8 @@ mkdir -p $OUT
 export YH_TUNE_CACHE=$PWD/$OUT/wg_local.json YH_TUNE_ITERS=${YH_TUNE_ITERS:-12}
 rm -f $YH_TUNE_CACHE
 cp yoloseries_amd/tune_defaults.json $OUT/shipped_before.json
+# the tracked table is stripped of its weight-gradient entries only while the workloads below run: whatever happens, it comes back
+trap 'cp $OUT/shipped_before.json yoloseries_amd/tune_defaults.json' EXIT
 python3 - <<'PY'
 import json
 t = json.load(open("yoloseries_amd/tune_defaults.json"))

@@ -36,7 +36,6 @@ class ConvDesc(C.Structure):
         ("stats", C.c_void_p),
         ("tile_n", C.c_int32), ("grid_cap", C.c_int32), ("tile_k", C.c_int32), ("algo", C.c_int32),
         ("bnr_z", C.c_void_p), ("bnr_ldz", C.c_int32), ("bnr_C", C.c_int32), ("bnr_ws", C.c_void_p), ("bnr_part", C.c_void_p),
-        ("acc_rows", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -50,7 +49,6 @@ class WgradDesc(C.Structure):
         ("partial", C.c_void_p), ("partial_bytes", C.c_uint64),
         ("bn_z", C.c_void_p), ("bn_ldz", C.c_int32), ("reserved0", C.c_int32),
         ("bn_ws", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_coef", C.c_void_p),
-        ("seg2", Seg), ("coff_k2", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -149,18 +147,12 @@ _SIGS = {
     "yh_bn_frozen": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp]),
     "yh_bn_fold_batch": (_i32, [_vp, _i32, _vp]),
     "yh_bn_silu_apply": (_i32, [_vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
-    "yh_bn_silu_apply_acc": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _vp, _i32, _vp]),
-    "yh_bn_silu_bwd_reduce_acc": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _i32, _vp]),
-    "yh_bn_silu_bwd_apply_acc": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "yh_ew_blocks": (_i32, [_i64]),
     "yh_bn_silu_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp]),
     "yh_bn_bwd_finalize": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "yh_bn_finalize_parts": (_i32, [_vp, _i32, _i64, _vp]),
     "yh_bn_bwd_finalize_parts": (_i32, [_vp, _i32, _i64, _vp]),
     "yh_bn_silu_apply_parts": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp]),
-    "yh_bn_fin_split_scratch_bytes": (_sz, []),
-    "yh_bn_bwd_finalize_parts_split": (_i32, [_vp, _i32, _i64, _vp, _vp]),
-    "yh_bn_silu_apply_fin": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp, _vp]),
     "yh_bn_silu_bwd_apply_parts": (_i32, [_vp, _i32, _i64, _vp, _i32, _vp, _i32, _vp]),
     "yh_bn_silu_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _vp]),
     "yh_colsum": (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp]),
@@ -185,7 +177,6 @@ _SIGS = {
     "yh_v5loss_saved_bytes": (_sz, [C.POINTER(V5LossDesc)]),
     "yh_v5_assign": (_i32, [C.POINTER(V5LossDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "yh_v5_loss_fwd": (_i32, [C.POINTER(V5LossDesc), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp]),
-    "yh_v5_loss_assign": (_i32, [C.POINTER(V5LossDesc), _vp, _vp, _vp]),
     "yh_v5_loss_bwd": (_i32, [C.POINTER(V5LossDesc), C.POINTER(_vp), _vp, _vp, C.POINTER(_vp), _vp, _vp]),
     "yh_yolox_saved_bytes": (_sz, [C.POINTER(YoloxDesc)]),
     "yh_yolox_ws_bytes": (_sz, [C.POINTER(YoloxDesc)]),

@@ -103,10 +103,6 @@ int yh_c80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name
 int yh_pw_rows(const yh_conv_desc* d);                  // grid rows; 0 = not eligible
 int yh_pw_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
 
-// conv_wpf.hip: wave-private 128-pixel x 128-channel tiles for the K-heavy stride-1 layers behind yh_conv_igemm (algo 11)
-int yh_wpf_rows(const yh_conv_desc* d);                 // grid rows (== statistics / fused-reduction slab rows); 0 = not eligible
-int yh_wpf_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
-
 // conv_wgp.hip: the patch form of the weight gradient behind yh_conv_wgrad (tile_k 40)
 int yh_wgp_ok(const yh_wgrad_desc* d);
 int yh_wgp_run(const yh_wgrad_desc* d, yh_stream stream);

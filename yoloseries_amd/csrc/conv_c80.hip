@@ -278,7 +278,7 @@ bool c80_plan(const yh_conv_desc* d, C80Plan* pl)
 {
     if (d->mode != YH_CONV_FWD || d->nseg != 1 || d->seg[0].ups) return false;
     if (d->KH != 3 || d->KW != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2)) return false;
-    if (d->stats || d->bnr_part || d->acc_rows || d->res || d->accumulate || d->nsplit < d->N) return false;     // inference epilogue, one destination
+    if (d->stats || d->bnr_part || d->res || d->accumulate || d->nsplit < d->N) return false;     // inference epilogue, one destination
     if (d->seg[0].C != C80_CIN || d->N != C80_TN) return false;
     const unsigned long ib = (unsigned long)d->Hi * d->Wi * d->seg[0].ld * 2;       // one image: what an im2col descriptor addresses
     const unsigned long wb = (unsigned long)d->Npad * 9 * C80_CIN * 2;

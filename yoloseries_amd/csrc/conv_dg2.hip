@@ -343,7 +343,7 @@ bool dg2_plan(const yh_conv_desc* d, Dg2Plan* pl)
     if (d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].ups) return false;
     if (d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1) return false;
     if (d->Ho != 2 * d->Hi || d->Wo != 2 * d->Wi) return false;
-    if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N || d->stats || d->acc_rows) return false;
+    if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N || d->stats) return false;
     const int Nk = d->seg[0].C;
     if (Nk % 32 || d->N % 8) return false;
     const unsigned long gzb = ((unsigned long)d->B * d->Hi * d->Wi - 1) * d->seg[0].ld * 2 + (unsigned long)Nk * 2;

@@ -390,7 +390,7 @@ bool h80_plan(const yh_conv_desc* d, H80Plan* pl)
 {
     if (d->nseg != 1 || d->seg[0].ups) return false;
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hi || d->Wo != d->Wi) return false;
-    if (d->stats || d->bnr_part || d->acc_rows) return false;                       // inference epilogues only
+    if (d->stats || d->bnr_part) return false;                       // inference epilogues only
     if (d->seg[0].C != 80 || d->N % 80 || d->N <= 0) return false;
     const unsigned long ib = (unsigned long)d->Hi * d->Wi * d->seg[0].ld * 2;       // one image: what a patch descriptor addresses
     const unsigned long wb = (unsigned long)d->Npad * 9 * 80 * 2;

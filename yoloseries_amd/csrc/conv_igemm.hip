@@ -55,25 +55,15 @@ struct ConvK {
                    // k-steps only, 256 no stem kernel (the ablation masks are compile-time: make ablate ABL=mask)
 };
 
-// Per-block partial sums leave the kernel either as one fp32 slab row per block (deterministic fixed-order reduction by
-// yh_bn_finalize / yh_bn_bwd_finalize) or, with d.acc_rows > 0, as 64-bit fixed-point atomic adds into acc_rows accumulator rows
-// (row = block % acc_rows; integer addition is associative, so the result is still independent of the arrival order): the few
-// rows are then reduced in the prologue of the consumer pass itself and the finalize launches disappear (include/yolohip.h).
+// Per-block partial sums leave the kernel as one fp32 slab row per block (deterministic fixed-order reduction by
+// yh_bn_finalize / yh_bn_bwd_finalize).
 __device__ __forceinline__ void put_stat(const yh_conv_desc& d, size_t blk, int which, int n, float v)
 {
-    if (d.acc_rows > 0)
-        atomicAdd(reinterpret_cast<unsigned long long*>(d.stats) + ((blk % (size_t)d.acc_rows) * 2 + which) * (size_t)d.Npad + n,
-                  (unsigned long long)__float2ll_rn(v * YH_STAT_SCALE_FWD));
-    else
-        d.stats[(blk * 2 + which) * d.Npad + n] = v;
+    d.stats[(blk * 2 + which) * d.Npad + n] = v;
 }
 __device__ __forceinline__ void put_bnr(const yh_conv_desc& d, size_t row, int which, int n, float v)
 {
-    if (d.acc_rows > 0)
-        atomicAdd(reinterpret_cast<unsigned long long*>(d.bnr_part) + ((row % (size_t)d.acc_rows) * 2 + which) * (size_t)d.N + n,
-                  (unsigned long long)__float2ll_rn(v * YH_STAT_SCALE_BWD));
-    else
-        d.bnr_part[(row * 2 + which) * d.N + n] = v;
+    d.bnr_part[(row * 2 + which) * d.N + n] = v;
 }
 
 // Stride-2 data gradients run as four parity classes of output pixels (2i+ph, 2j+pw) that touch only their structurally
@@ -2503,7 +2493,6 @@ static bool conv_desc_plannable(const yh_conv_desc* d) {
 extern "C" int yh_conv_stat_blocks(const yh_conv_desc* d) {
     if (!conv_desc_plannable(d)) return 0;
     if (d->algo == 8) { const int r8 = yh_p3_rows(d); if (r8 > 0) return r8; }
-    if (d->algo == 11) { const int r11 = yh_wpf_rows(d); if (r11 > 0) return r11; }
     int gx, gy, bn;
     conv_grid(d, &gx, &gy, &bn);
     return gx;
@@ -2549,7 +2538,6 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         if (d->algo == 8 && yh_p3_rows(d) > 0) return yh_p3_run(d, stream, name_out, name_len);
         if (d->algo == 9 && yh_h80_rows(d) > 0) return yh_h80_run(d, stream, name_out, name_len);
         if (d->algo == 10 && yh_pw_rows(d) > 0) return yh_pw_run(d, stream, name_out, name_len);
-        if (d->algo == 11 && yh_wpf_rows(d) > 0) return yh_wpf_run(d, stream, name_out, name_len);
         if (d->algo == 12 && yh_c80_rows(d) > 0) return yh_c80_run(d, stream, name_out, name_len);
         yh_conv_desc d0 = *d;
         d0.algo = 0;
@@ -2804,8 +2792,8 @@ extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
     if (!conv_desc_plannable(d) || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 8 || d->seg[0].ups || d->N % 8) return 0;
     if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N || d->stats) return 0;
     if (conv_dbg_mask() & 16) return 0;
-    if (d->algo == 7 || d->algo == 8 || d->algo == 11) {
-        const int r7 = d->algo == 7 ? yh_dg2_rows(d) : (d->algo == 8 ? yh_p3_rows(d) : yh_wpf_rows(d));
+    if (d->algo == 7 || d->algo == 8) {
+        const int r7 = d->algo == 7 ? yh_dg2_rows(d) : yh_p3_rows(d);
         if (r7 > 0) return r7;
         yh_conv_desc d0 = *d;
         d0.algo = 0;

@@ -315,7 +315,7 @@ bool p3_plan(const yh_conv_desc* d, P3Plan* pl)
 {
     if (d->nseg != 1 || d->seg[0].ups) return false;
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hi || d->Wo != d->Wi) return false;
-    if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N || d->acc_rows) return false;
+    if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N) return false;
     if (d->mode == YH_CONV_FWD && (d->bnr_part || d->accumulate)) return false;
     if (d->mode == YH_CONV_DGRAD && d->stats) return false;
     const int Cin = d->seg[0].C;

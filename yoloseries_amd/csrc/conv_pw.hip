@@ -238,7 +238,7 @@ bool pw_plan(const yh_conv_desc* d, PwPlan* pl)
 {
     if (d->nseg != 1 || d->seg[0].ups || d->mode != YH_CONV_FWD) return false;
     if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0) return false;
-    if (d->stats || d->bnr_part || d->acc_rows) return false;                       // inference epilogues only
+    if (d->stats || d->bnr_part) return false;                       // inference epilogues only
     const int C = d->seg[0].C;
     if ((C != 80 && C != 160 && C != 320) || d->N % 80 || d->N <= 0) return false;
     const unsigned long M = (unsigned long)d->B * d->Ho * d->Wo;

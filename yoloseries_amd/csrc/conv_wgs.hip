@@ -39,12 +39,11 @@ struct WgsK {
     unsigned long long* stamps;   // diagnostics (yh_wgs_set_stamps): [workgroup][wave][8] shader-clock stamps of the first segment
     int Ktot;          // columns of a dw row
     int nk;            // 32-pixel work units of the layer (M / 32); a unit is two 16-pixel steps
-    int nct, T;        // column tiles (128 im2col columns of a segment: column = tap * C + c) per n-tile, tiles
-    int nct0;          // ... of them in the first segment (the rest belong to d.seg2)
+    int nct, T;        // column tiles (128 im2col columns of the segment: column = tap * C + c) per n-tile, tiles
     int G;             // virtual workgroups
     int mg, mGp, minv; // XCD-aware block map (mg = gcd(T, G), mGp = G / mg, minv = (T / mg)^-1 mod mGp); mg 0: identity
     long U;            // T * nk work units
-    unsigned gybytes, xbytes, xbytes2, dwbytes;
+    unsigned gybytes, xbytes, dwbytes;
 };
 
 __device__ __forceinline__ v4s wgs_tr(const unsigned char* p) {
@@ -95,8 +94,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
     const long u0 = p.U * v / p.G, u1 = p.U * (v + 1) / p.G;
 
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)d.gy, 0, p.gybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsx0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg.ptr, 0, p.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsx1 = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg2.ptr, 0, p.xbytes2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)d.seg.ptr, 0, p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)d.dw, 0, p.dwbytes, 0x00020000);
 
     // loader geometry: a transfer fills 4 pixel rows x 256 B; this lane's row inside it, its chunk position inside the LDS
@@ -132,14 +130,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
         const long left = u1 - u;
         const int kb = (left < (long)(p.nk - ka)) ? ka + (int)left : p.nk;
         u += kb - ka;
-        const int ntile = t / p.nct, ctile_all = t - ntile * p.nct;
+        const int ntile = t / p.nct, ctile = t - ntile * p.nct;
         const int n0 = ntile * 128;
-        // the input segment of this tile (a concat input: the tiles of segment 0, then those of segment 1) — all scalar
-        const bool second = ctile_all >= p.nct0;
-        const int ctile = second ? ctile_all - p.nct0 : ctile_all;
-        const int segC = second ? d.seg2.C : d.seg.C, segld = second ? d.seg2.ld : d.seg.ld, ups = second ? d.seg2.ups : d.seg.ups;
-        const int coffk = second ? d.coff_k2 : d.coff_k;
-        const __amdgpu_buffer_rsrc_t rsx = second ? rsx1 : rsx0;
+        const int segC = d.seg.C, segld = d.seg.ld, ups = d.seg.ups;
+        const int coffk = d.coff_k;
         const int Hs = d.Hi >> ups, Ws = d.Wi >> ups;
         const unsigned pixb = (unsigned)(segld * 2);
         // this lane's 16-byte chunk of a row: im2col column colv = tap * C + channel.  The four lanes of a quad hold 32 consecutive
@@ -348,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
 }
 
 // eligibility of the layer and the launch plan shared by the queries and the launcher
-struct WgsPlan { long M; int nk, ntn, nct, nct0, T, G, S, grid; bool pw, two; unsigned long xb, xb2; };
+struct WgsPlan { long M; int nk, ntn, nct, T, G, S, grid; bool pw; unsigned long xb; };
 
 bool wgs_seg_ok(const yh_wgrad_desc* d, const yh_seg& sg, int coff, unsigned long* xb)
 {
@@ -364,10 +358,7 @@ bool wgs_plan(const yh_wgrad_desc* d, WgsPlan* pl)
     if (!d || d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->N < 64 || d->KH <= 0 || d->KW <= 0) return false;
     if (d->KH > 7 || d->KW > 7 || (d->stride != 1 && d->stride != 2) || d->pad < 0) return false;
     if (d->ldg % 8 != 0 || d->ldg < (d->N + 7) / 8 * 8) return false;
-    pl->two = d->seg2.ptr != nullptr;
-    pl->xb2 = 0;
     if (!wgs_seg_ok(d, d->seg, d->coff_k, &pl->xb)) return false;
-    if (pl->two && !wgs_seg_ok(d, d->seg2, d->coff_k2, &pl->xb2)) return false;
     if (d->bn_z || d->partial) return false;
     if ((d->Hi + 2 * d->pad - d->KH) / d->stride + 1 != d->Ho || (d->Wi + 2 * d->pad - d->KW) / d->stride + 1 != d->Wo) return false;
     const long M = (long)d->B * d->Ho * d->Wo;
@@ -378,10 +369,9 @@ bool wgs_plan(const yh_wgrad_desc* d, WgsPlan* pl)
     pl->M = M;
     pl->nk = (int)(M / 32);
     pl->ntn = (d->N + 127) / 128;
-    pl->nct0 = (d->KH * d->KW * d->seg.C + 127) / 128;
-    pl->nct = pl->nct0 + (pl->two ? (d->KH * d->KW * d->seg2.C + 127) / 128 : 0);
+    pl->nct = (d->KH * d->KW * d->seg.C + 127) / 128;
     pl->T = pl->ntn * pl->nct;
-    pl->pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->seg.ups && !(pl->two && d->seg2.ups);
+    pl->pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && !d->seg.ups;
     int G = d->splits < 1 ? 1 : (d->splits > 4096 ? 4096 : d->splits);
     const long U = (long)pl->T * pl->nk;
     if ((long)G > U) G = (int)U;
@@ -411,13 +401,13 @@ int yh_wgs_run(const yh_wgrad_desc* d, yh_stream stream)
 {
     WgsPlan pl;
     YH_CHECK_ARG(wgs_plan(d, &pl), "yh_conv_wgrad(tile_k 129): layer not eligible");
-    YH_CHECK_ARG(d->gy && yh_aligned16(d->gy) && d->seg.ptr && yh_aligned16(d->seg.ptr) && d->dw && yh_aligned16(d->seg2.ptr),
+    YH_CHECK_ARG(d->gy && yh_aligned16(d->gy) && d->seg.ptr && yh_aligned16(d->seg.ptr) && d->dw,
                  "yh_conv_wgrad(tile_k 129): bad operands");
     WgsK k;
     k.d = *d;
     k.stamps = g_wgs_stamps;
     k.Ktot = d->KH * d->KW * d->Ctot;
-    k.nk = pl.nk; k.nct = pl.nct; k.nct0 = pl.nct0; k.T = pl.T; k.G = pl.G;
+    k.nk = pl.nk; k.nct = pl.nct; k.T = pl.T; k.G = pl.G;
     {   // phase-sorted block map: see the kernel.  YH_WGS_SKMAP=0 keeps the identity map on stream-K grids (A/B)
         static const int skm = getenv("YH_WGS_SKMAP") ? atoi(getenv("YH_WGS_SKMAP")) : 1;
         int a = pl.T, b = pl.G;
@@ -430,12 +420,11 @@ int yh_wgs_run(const yh_wgrad_desc* d, yh_stream stream)
     k.U = (long)pl.T * pl.nk;
     k.gybytes = (unsigned)(((unsigned long)(pl.M - 1) * d->ldg + (d->N + 7) / 8 * 8) * 2);
     k.xbytes = (unsigned)pl.xb;
-    k.xbytes2 = (unsigned)pl.xb2;
     k.dwbytes = (unsigned)((unsigned long)d->N * d->KH * d->KW * d->Ctot * 4);
     // timing-only diagnostics (results wrong): YH_WGS_ABL bit 0: zero-record operand descriptors (every transfer returns zeros without
     // touching memory: the loop's issue-bound time), bit 1: zero-record dw descriptor (the atomics are dropped by the range check)
     static const int abl = [] { const char* e = getenv("YH_WGS_ABL"); return e ? atoi(e) : 0; }();
-    if (abl & 1) k.gybytes = k.xbytes = k.xbytes2 = 0;
+    if (abl & 1) k.gybytes = k.xbytes = 0;
     if (abl & 2) k.dwbytes = 0;
     static bool attr_set = false;
     if (!attr_set) {

@@ -246,160 +246,6 @@ __global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int l
     }
 }
 
-// bn_silu_apply(_parts) with the yh_bn_finalize(_parts) launch folded in (yh_bn_silu_apply_fin): the first `nfin` workgroups of the
-// grid finalize 16 channels each (column sums of the slab -> ws, running statistics), publish that with a release + counter, and
-// exit; the others request their first row, wait for the counter, and run the pass.  Workgroups are dispatched in index order, so
-// the finalize workgroups are resident before any waiter can occupy the chip (the forward-progress assumption of every stream-K
-// fix-up).  sync = { 64 copies of: finalize workgroups done (cumulative over launches) | 64 first-level exit tickets | their count | launches completed }: the
-// last workgroup to leave bumps `launches`, which a later launch reads to know the count it has to wait for — no reset launch.
-constexpr int FINF_RG = EW_THREADS / FIN_CPB;      // the finalize workgroups run with the pass's block size
-constexpr int FINF_COPIES = 64;                    // copies of the finalize counter, one per 128-byte line (YH_BN_FIN_SYNC_WORDS = 128 * 32 + 2)
-__global__ __launch_bounds__(EW_THREADS) void bn_silu_apply_fin_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M, double count,
-                                                                       const uint16_t* __restrict__ res, int ldr, int* sync, int nfin)
-{
-    if ((int)blockIdx.x < nfin) {
-        int cb;
-        const yh_bn_part& q = P.p[fin_part_of(P, blockIdx.x, cb)];
-        bn_finalize_body<FINF_RG>(cb, q.slab, q.nblk, q.ldslab, q.C, count, q.gamma, q.beta, q.running_mean, q.running_var, q.num_batches,
-                                  q.eps, q.momentum, q.ws);
-        __syncthreads();
-        __threadfence();                                           // ws (and the running statistics) before the counters
-        if (threadIdx.x < FINF_COPIES)                             // one counter copy per 128-byte line: the waiters spread over them
-            __hip_atomic_fetch_add(&sync[threadIdx.x * 32], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        const long T = (long)(gridDim.x - nfin) * blockDim.x;
-        const long rstep = T / cpr;
-        const long gid = (long)(blockIdx.x - nfin) * blockDim.x + threadIdx.x;
-        const bool live = gid < rstep * cpr;
-        long m = live ? gid / cpr : 0;
-        const int c = live ? (int)(gid - m * cpr) * 8 : 0;
-        int cp;
-        const int k = part_of(P, c, cp);
-        const float* __restrict__ ws = P.p[k].ws;
-        const int Cp = P.p[k].C;
-        uint16_t* __restrict__ out = P.p[k].out + cp;
-        const int ldo = P.p[k].ldo;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (live && m < M) v = *reinterpret_cast<const uint4*>(y + m * ldy + c);     // in flight while the constants are made
-        if (threadIdx.x == 0) {
-            const int want = (__hip_atomic_load(&sync[2 * FINF_COPIES * 32 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1) * nfin;
-            const int* flag = sync + (blockIdx.x % FINF_COPIES) * 32;
-            int spins = 0;
-            // relaxed polls: an acquire per poll would invalidate the XCD's L2 every time (measured: 170 us per launch).  ws is read
-            // below with plain loads: no cache of this XCD can hold a line of it (caches are clean at kernel start and nobody
-            // reads ws before the counter says it is written; device-coherent loads of ws from every thread cost 40 us per launch)
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0 && ++spins < (1 << 22))
-                __builtin_amdgcn_s_sleep(16);
-        }
-        __syncthreads();
-        if (live) {
-            float sc[8], sh[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sc[e] = ws[cp + e];
-                sh[e] = ws[Cp + cp + e];
-            }
-            for (; m < M; m += rstep) {
-                float f[8];
-                unpack8(v, f);
-                const long mn = m + rstep;
-                if (mn < M) v = *reinterpret_cast<const uint4*>(y + mn * ldy + c);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e] * sc[e] + sh[e]);
-                if (res) {
-                    uint4 rv = *reinterpret_cast<const uint4*>(res + m * ldr + c);
-                    float g[8];
-                    unpack8(rv, g);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = bf_round(f[e]) + g[e];
-                }
-                *reinterpret_cast<uint4*>(out + m * ldo) = pack8(f);
-            }
-        }
-    }
-    // the last workgroup out closes the launch — found through 64 first-level tickets (2 000 increments of ONE word cost 40 us)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int G = (int)gridDim.x, i = (int)blockIdx.x % FINF_COPIES;
-        int* tick = sync + (FINF_COPIES + i) * 32;
-        int* top = sync + 2 * FINF_COPIES * 32;
-        if (__hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (G - i + FINF_COPIES - 1) / FINF_COPIES - 1) {
-            __hip_atomic_store(tick, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (G < FINF_COPIES ? G : FINF_COPIES) - 1) {
-                __hip_atomic_store(top, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(top + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
-// The same pass fed by int64 fixed-point accumulators (yh_conv_desc.acc_rows): every block first reduces the few accumulator rows
-// for all C channels (rows * 2 * C 8-byte loads, L2 resident) into scale / shift in LDS — the former yh_bn_finalize launch; block 0
-// additionally publishes ws (scale | shift | mean | invstd) for the backward and updates the running statistics.
-__global__ __launch_bounds__(1024) void bn_silu_apply_acc_kernel(const uint16_t* __restrict__ y, int ldy, const long long* __restrict__ acc, int rows, int ldacc,
-                                         int C, int cpr, long M, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         float* running_mean, float* running_var, int64_t* num_batches, float eps, float momentum,
-                                         float* __restrict__ ws, uint16_t* __restrict__ out, int ldo,
-                                         const uint16_t* __restrict__ res, int ldr)
-{
-    extern __shared__ float s_cst[];                 // [2][C]: scale | shift
-    const double count = (double)M;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        // all row loads in flight together (a rolled loop pays one L2 round trip per row: 16 us per launch)
-        long long vs[YH_ACC_ROWS], vq[YH_ACC_ROWS];
-#pragma unroll
-        for (int r = 0; r < YH_ACC_ROWS; ++r) {
-            vs[r] = r < rows ? acc[((size_t)r * 2 + 0) * ldacc + c] : 0;
-            vq[r] = r < rows ? acc[((size_t)r * 2 + 1) * ldacc + c] : 0;
-        }
-        long long s = 0, q = 0;
-#pragma unroll
-        for (int r = 0; r < YH_ACC_ROWS; ++r) { s += vs[r]; q += vq[r]; }
-        const double mean = (double)s * (1.0 / (double)YH_STAT_SCALE_FWD) / count;
-        double var = (double)q * (1.0 / (double)YH_STAT_SCALE_FWD) / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float scale = gamma[c] * invstd;
-        const float shift = beta[c] - (float)mean * scale;
-        s_cst[c] = scale;
-        s_cst[C + c] = shift;
-        if (blockIdx.x == 0) {
-            ws[c] = scale; ws[C + c] = shift; ws[2 * C + c] = (float)mean; ws[3 * C + c] = invstd;
-            if (running_mean) {
-                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-            }
-            if (c == 0 && num_batches) *num_batches += 1;
-        }
-    }
-    __syncthreads();
-    const long T = (long)gridDim.x * blockDim.x;
-    const long rstep = T / cpr;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= rstep * cpr) return;
-    long m = gid / cpr;
-    const int c = (int)(gid - m * cpr) * 8;
-    float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = s_cst[c + e]; sh[e] = s_cst[C + c + e]; }
-    for (; m < M; m += rstep) {
-        uint4 v = *reinterpret_cast<const uint4*>(y + m * ldy + c);
-        float f[8];
-        unpack8(v, f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e] * sc[e] + sh[e]);
-        if (res) {
-            uint4 rv = *reinterpret_cast<const uint4*>(res + m * ldr + c);
-            float g[8];
-            unpack8(rv, g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = bf_round(f[e]) + g[e];
-        }
-        *reinterpret_cast<uint4*>(out + m * ldo + c) = pack8(f);
-    }
-}
-
 // ---------------------------------------------------------------- column reductions
 // Block b owns rows [b*rpb, (b+1)*rpb).  Thread (rg, cch) accumulates 8 channels over
 // rows rg, rg+RG, ...; row groups are combined through LDS.
@@ -409,7 +255,7 @@ template <int MODE>   // 0: BN+SiLU backward sums (gz, gz*xhat) ; 1: plain colum
 __global__ __launch_bounds__(RED_THREADS, 4) void col_reduce_kernel(const uint16_t* __restrict__ ga, int ldga,
                                                                  const uint16_t* __restrict__ y, int ldy,
                                                                  const float* __restrict__ ws, int C, int cpr,
-                                                                 long M, long rpb, float* __restrict__ part, int acc_rows)
+                                                                 long M, long rpb, float* __restrict__ part)
 {
     __shared__ float sP[RED_THREADS * 16];
     const int t = threadIdx.x;
@@ -495,11 +341,7 @@ __global__ __launch_bounds__(RED_THREADS, 4) void col_reduce_kernel(const uint16
         int cc = i - which * C;
         float s = 0.f;
         for (int r = 0; r < RG; ++r) s += sP[(r * 2 + which) * C + cc];
-        if (acc_rows > 0)          // int64 fixed-point accumulator rows (see put_bnr in conv_igemm.hip): order independent
-            atomicAdd(reinterpret_cast<unsigned long long*>(part) + (((size_t)blockIdx.x % acc_rows) * 2 + which) * C + cc,
-                      (unsigned long long)__float2ll_rn(s * YH_STAT_SCALE_BWD));
-        else
-            part[((size_t)blockIdx.x * 2 + which) * C + cc] = s;
+        part[((size_t)blockIdx.x * 2 + which) * C + cc] = s;
     }
 }
 
@@ -529,50 +371,6 @@ __global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_parts_kernel(const Par
     int cb;
     const yh_bn_part& q = P.p[fin_part_of(P, blockIdx.x, cb)];
     bn_bwd_finalize_body(cb, q.slab, q.nblk, q.C, M, q.ws, q.dgamma, q.dbeta, q.coef);
-}
-
-// Backward finalize of slabs with thousands of rows (the 160 x 160 layers' data gradients leave 12 800 of them): the rows are cut
-// into Z slices, one workgroup per (16 channels, slice); a slice's sums go to a scratch row, and the LAST workgroup of a channel
-// group to arrive (a ticket per group: no waiting) adds the Z rows in slice order — deterministic — and finalizes.  One launch,
-// C / 16 x Z workgroups instead of C / 16 walking 50 batches of rows each (20 - 30 us per launch on an otherwise idle GPU).
-constexpr int FINZ_MAX = 16;                       // slices
-constexpr int FINZ_GROUPS = 2048 / FIN_CPB;        // channel groups a launch may have
-__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_split_kernel(const PartsK P, double M, int Z, int* tickets, double* partial)
-{
-    __shared__ int s_last;
-    int cb;
-    const yh_bn_part& q = P.p[fin_part_of(P, blockIdx.x, cb)];
-    const int g = blockIdx.x, z = blockIdx.y, lc = threadIdx.x & (FIN_CPB - 1);
-    const int c = cb * FIN_CPB + lc;
-    const long r0 = (long)q.nblk * z / Z, r1 = (long)q.nblk * (z + 1) / Z;
-    float mu = 0.f, is = 0.f;
-    if (threadIdx.x < FIN_CPB && c < q.C) { mu = q.ws[2 * q.C + c]; is = q.ws[3 * q.C + c]; }
-    double s[2];
-    slab_colsum<2>(q.slab + (size_t)r0 * 2 * q.C, (int)(r1 - r0), q.C, q.C, c, s);
-    double* mine = partial + ((size_t)g * FINZ_MAX + z) * 2 * FIN_CPB;
-    if (threadIdx.x < FIN_CPB) {
-        mine[lc] = s[0];
-        mine[FIN_CPB + lc] = s[1];
-        __threadfence();                           // the slice's sums before the ticket
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(&tickets[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == Z - 1;
-        if (s_last) __hip_atomic_store(&tickets[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last || threadIdx.x >= FIN_CPB || c >= q.C) return;
-    double t0 = 0.0, t1 = 0.0;
-    for (int i = 0; i < Z; ++i) {                  // device-coherent loads: the rows were written by other workgroups of this launch
-        const double* row = partial + ((size_t)g * FINZ_MAX + i) * 2 * FIN_CPB;
-        t0 += __hip_atomic_load(row + lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t1 += __hip_atomic_load(row + FIN_CPB + lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    t1 = (double)is * (t1 - (double)mu * t0);      // sum(dz*y) -> sum(dz*xhat)
-    if (q.dbeta) q.dbeta[c] = (float)t0;
-    if (q.dgamma) q.dgamma[c] = (float)t1;
-    if (q.coef) { q.coef[c] = (float)(t0 / M); q.coef[q.C + c] = (float)(t1 / M); }
 }
 
 __global__ __launch_bounds__(FIN_NT) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out)
@@ -684,84 +482,6 @@ __global__ void bn_silu_bwd_apply_parts_kernel(const uint16_t* __restrict__ y, i
             o[e] = A[e] * dz + (Bc[e] * yy[e] + D[e]);
         }
         *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
-    }
-}
-
-// bn_silu_bwd_apply with the former yh_bn_bwd_finalize launch as its prologue: the int64 accumulator rows (sum dz | sum dz*z,
-// scaled 2^YH_STAT_SHIFT_BWD; filled by the data gradient's fused reduction or by col_reduce) are reduced per channel by every
-// block, the per-channel constants of  gz = A*dz + Bc*y + D  go to LDS, block 0 writes dgamma / dbeta.
-__global__ __launch_bounds__(1024) void bn_silu_bwd_apply_acc_kernel(const uint16_t* __restrict__ ga, int ldga, const uint16_t* __restrict__ y, int ldy,
-                                             const float* __restrict__ ws, const float* __restrict__ gamma,
-                                             const long long* __restrict__ acc, int rows, int C, int cpr, long M,
-                                             float* dgamma, float* dbeta,
-                                             uint16_t* __restrict__ gy, int ldgy, uint16_t* gres, int ldgres, int gres_acc)
-{
-    extern __shared__ float s_cst[];                 // [5][C]: scale | shift | A | Bc | D
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        long long v0[YH_ACC_ROWS], v1[YH_ACC_ROWS];
-#pragma unroll
-        for (int r = 0; r < YH_ACC_ROWS; ++r) {
-            v0[r] = r < rows ? acc[((size_t)r * 2 + 0) * C + c] : 0;
-            v1[r] = r < rows ? acc[((size_t)r * 2 + 1) * C + c] : 0;
-        }
-        long long a0 = 0, a1 = 0;
-#pragma unroll
-        for (int r = 0; r < YH_ACC_ROWS; ++r) { a0 += v0[r]; a1 += v1[r]; }
-        const double s0 = (double)a0 * (1.0 / (double)YH_STAT_SCALE_BWD);
-        const float mu = ws[2 * C + c], is = ws[3 * C + c];
-        const double s1 = (double)is * ((double)a1 * (1.0 / (double)YH_STAT_SCALE_BWD) - (double)mu * s0);      // sum(dz*y) -> sum(dz*xhat)
-        if (blockIdx.x == 0) {
-            if (dbeta) dbeta[c] = (float)s0;
-            if (dgamma) dgamma[c] = (float)s1;
-        }
-        const float c1 = (float)(s0 / (double)M), c2 = (float)(s1 / (double)M);
-        const float gi = gamma[c] * is;
-        s_cst[c] = ws[c];
-        s_cst[C + c] = ws[C + c];
-        s_cst[2 * C + c] = gi;
-        s_cst[3 * C + c] = -gi * is * c2;
-        s_cst[4 * C + c] = gi * (mu * is * c2 - c1);
-    }
-    __syncthreads();
-    const long T = (long)gridDim.x * blockDim.x;
-    const long rstep = T / cpr;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= rstep * cpr) return;
-    long m = gid / cpr;
-    const int c = (int)(gid - m * cpr) * 8;
-    float sc[8], sh[8], A[8], Bc[8], D[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sc[e] = s_cst[c + e]; sh[e] = s_cst[C + c + e];
-        A[e] = s_cst[2 * C + c + e]; Bc[e] = s_cst[3 * C + c + e]; D[e] = s_cst[4 * C + c + e];
-    }
-    for (; m < M; m += rstep) {
-        uint4 gv = ld_nt(ga + m * ldga + c);
-        uint4 yv = ld_nt(y + m * ldy + c);
-        float g[8], yy[8], o[8];
-        unpack8(gv, g);
-        unpack8(yv, yy);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float z = yy[e] * sc[e] + sh[e];
-            float sg = sigmoid_fast(z);
-            float dz = g[e] * (sg * (1.f + z * (1.f - sg)));
-            o[e] = A[e] * dz + (Bc[e] * yy[e] + D[e]);
-        }
-        *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
-        if (gres) {
-            uint16_t* dst = gres + m * ldgres + c;
-            if (gres_acc) {
-                uint4 ov = *reinterpret_cast<const uint4*>(dst);
-                float f[8];
-                unpack8(ov, f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += g[e];
-                *reinterpret_cast<uint4*>(dst) = pack8(f);
-            } else {
-                *reinterpret_cast<uint4*>(dst) = gv;
-            }
-        }
     }
 }
 
@@ -1027,57 +747,8 @@ extern "C" int yh_bn_silu_bwd_reduce(const yh_bf16* ga, int ldga, const yh_bf16*
     int nblk = yh_ew_blocks(M);
     long rpb = (M + nblk - 1) / nblk;
     hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
-                       ga, ldga, y, ldy, ws, C, C / 8, (long)M, rpb, part, 0);
+                       ga, ldga, y, ldy, ws, C, C / 8, (long)M, rpb, part);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_reduce");
-    return YH_OK;
-}
-
-extern "C" int yh_bn_silu_apply_acc(const yh_bf16* y, int ldy, const int64_t* acc, int rows, int ldacc, int C, int64_t M,
-                                    const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
-                                    float eps, float momentum, float* ws, yh_bf16* out, int ldo, const yh_bf16* res, int ldr, yh_stream stream)
-{
-    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && acc && rows > 0 && rows <= YH_ACC_ROWS && ldacc >= C && gamma && beta && ws, "yh_bn_silu_apply_acc: bad args (rows <= 16)");
-    YH_CHECK_SLICE("yh_bn_silu_apply_acc", y, ldy, C);
-    YH_CHECK_SLICE("yh_bn_silu_apply_acc", out, ldo, C);
-    if (res) YH_CHECK_SLICE("yh_bn_silu_apply_acc", res, ldr, C);
-    const int cpr = C / 8;
-    const long nch = (long)M * cpr;
-    // 1024-thread blocks: the accumulator rows are reduced once per block, so fewer, larger blocks pay for it less often
-    hipLaunchKernelGGL(bn_silu_apply_acc_kernel, dim3((ew_grid(nch) + 3) / 4), dim3(1024), 2 * C * sizeof(float), (hipStream_t)stream,
-                       y, ldy, (const long long*)acc, rows, ldacc, C, cpr, (long)M, gamma, beta, running_mean, running_var, num_batches,
-                       eps, momentum, ws, out, ldo, res, ldr);
-    YH_CHECK_LAUNCH("yh_bn_silu_apply_acc");
-    return YH_OK;
-}
-
-extern "C" int yh_bn_silu_bwd_reduce_acc(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy, const float* ws, int C, int64_t M,
-                                         int64_t* acc, int rows, yh_stream stream)
-{
-    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && ws && acc && rows > 0, "yh_bn_silu_bwd_reduce_acc: bad args");
-    YH_CHECK_SLICE("yh_bn_silu_bwd_reduce_acc", ga, ldga, C);
-    YH_CHECK_SLICE("yh_bn_silu_bwd_reduce_acc", y, ldy, C);
-    int nblk = yh_ew_blocks(M);
-    long rpb = (M + nblk - 1) / nblk;
-    hipLaunchKernelGGL((col_reduce_kernel<0>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
-                       ga, ldga, y, ldy, ws, C, C / 8, (long)M, rpb, reinterpret_cast<float*>(acc), rows);
-    YH_CHECK_LAUNCH("yh_bn_silu_bwd_reduce_acc");
-    return YH_OK;
-}
-
-extern "C" int yh_bn_silu_bwd_apply_acc(const yh_bf16* ga, int ldga, const yh_bf16* y, int ldy, const float* ws, const float* gamma,
-                                        const int64_t* acc, int rows, int C, int64_t M, float* dgamma, float* dbeta,
-                                        yh_bf16* gy, int ldgy, yh_bf16* gres, int ldgres, int gres_acc, yh_stream stream)
-{
-    YH_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048 && M > 0 && ws && gamma && acc && rows > 0 && rows <= YH_ACC_ROWS, "yh_bn_silu_bwd_apply_acc: bad args (rows <= 16)");
-    YH_CHECK_SLICE("yh_bn_silu_bwd_apply_acc", ga, ldga, C);
-    YH_CHECK_SLICE("yh_bn_silu_bwd_apply_acc", y, ldy, C);
-    YH_CHECK_SLICE("yh_bn_silu_bwd_apply_acc", gy, ldgy, C);
-    if (gres) YH_CHECK_SLICE("yh_bn_silu_bwd_apply_acc", gres, ldgres, C);
-    const int cpr = C / 8;
-    const long nch = (long)M * cpr;
-    hipLaunchKernelGGL(bn_silu_bwd_apply_acc_kernel, dim3((ew_grid(nch) + 3) / 4), dim3(1024), 5 * C * sizeof(float), (hipStream_t)stream,
-                       ga, ldga, y, ldy, ws, gamma, (const long long*)acc, rows, C, cpr, (long)M, dgamma, dbeta, gy, ldgy, gres, ldgres, gres_acc);
-    YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply_acc");
     return YH_OK;
 }
 
@@ -1164,28 +835,6 @@ extern "C" int yh_bn_bwd_finalize_parts(const yh_bn_part* parts, int nparts, int
     return YH_OK;
 }
 
-/* bytes of the scratch yh_bn_bwd_finalize_parts_split needs (zero before the first use; the launches leave it clean) */
-extern "C" size_t yh_bn_fin_split_scratch_bytes(void) { return 4096 + (size_t)FINZ_GROUPS * FINZ_MAX * 2 * FIN_CPB * sizeof(double); }
-
-extern "C" int yh_bn_bwd_finalize_parts_split(const yh_bn_part* parts, int nparts, int64_t M, void* scratch, yh_stream stream)
-{
-    PartsK P;
-    int C = 0;
-    const int rc = parts_pack("yh_bn_bwd_finalize_parts_split", parts, nparts, 3, &P, &C);
-    if (rc != YH_OK) return rc;
-    YH_CHECK_ARG(M > 0 && scratch && yh_aligned16(scratch), "yh_bn_bwd_finalize_parts_split: bad M / scratch");
-    int nmax = 0;
-    for (int i = 0; i < nparts; ++i) nmax = parts[i].nblk > nmax ? parts[i].nblk : nmax;
-    int Z = nmax / (FIN_U * FIN_RG);               // a slice keeps at least one full batch of rows
-    Z = Z < 1 ? 1 : (Z > FINZ_MAX ? FINZ_MAX : Z);
-    const int groups = P.bend[nparts - 1];
-    YH_CHECK_ARG(groups <= FINZ_GROUPS, "yh_bn_bwd_finalize_parts_split: more than %d channel groups", FINZ_GROUPS);
-    hipLaunchKernelGGL(bn_bwd_finalize_split_kernel, dim3(groups, Z), dim3(FIN_NT), 0, (hipStream_t)stream, P, (double)M, Z,
-                       (int*)scratch, (double*)((char*)scratch + 4096));
-    YH_CHECK_LAUNCH("yh_bn_bwd_finalize_parts_split");
-    return YH_OK;
-}
-
 extern "C" int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts, yh_stream stream)
 {
     PartsK P;
@@ -1197,28 +846,6 @@ extern "C" int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, cons
     const int cpr = C / 8;
     hipLaunchKernelGGL(bn_silu_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, ldy, P, cpr, (long)M);
     YH_CHECK_LAUNCH("yh_bn_silu_apply_parts");
-    return YH_OK;
-}
-
-extern "C" int yh_bn_silu_apply_fin(const yh_bf16* y, int ldy, int64_t M, const yh_bn_part* parts, int nparts,
-                                    const yh_bf16* res, int ldr, int32_t* sync, yh_stream stream)
-{
-    PartsK P;
-    int C = 0;
-    int rc = parts_pack("yh_bn_silu_apply_fin", parts, nparts, 2, &P, &C);
-    if (rc == YH_OK) rc = parts_pack("yh_bn_silu_apply_fin", parts, nparts, 0, &P, &C);
-    if (rc != YH_OK) return rc;
-    YH_CHECK_ARG(M > 0 && sync, "yh_bn_silu_apply_fin: bad M / sync");
-    YH_CHECK_SLICE("yh_bn_silu_apply_fin", y, ldy, C);
-    if (res) {
-        YH_CHECK_ARG(nparts == 1, "yh_bn_silu_apply_fin: a residual needs a single part");
-        YH_CHECK_SLICE("yh_bn_silu_apply_fin", res, ldr, C);
-    }
-    const int cpr = C / 8;
-    const int nfin = P.bend[nparts - 1];
-    hipLaunchKernelGGL(bn_silu_apply_fin_kernel, dim3(nfin + ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       y, ldy, P, cpr, (long)M, (double)M, res, ldr, sync, nfin);
-    YH_CHECK_LAUNCH("yh_bn_silu_apply_fin");
     return YH_OK;
 }
 
@@ -1246,7 +873,7 @@ extern "C" int yh_colsum(const yh_bf16* g, int ldg, int C, int64_t M, float* par
     int nblk = yh_ew_blocks(M);
     long rpb = (M + nblk - 1) / nblk;
     hipLaunchKernelGGL((col_reduce_kernel<1>), dim3(nblk), dim3(RED_THREADS), 0, (hipStream_t)stream,
-                       g, ldg, (const uint16_t*)nullptr, 0, (const float*)nullptr, C, C / 8, (long)M, rpb, part, 0);
+                       g, ldg, (const uint16_t*)nullptr, 0, (const float*)nullptr, C, C / 8, (long)M, rpb, part);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_CPB - 1) / FIN_CPB), dim3(FIN_NT), 0, (hipStream_t)stream, part, nblk, C, out);
     YH_CHECK_LAUNCH("yh_colsum");
     return YH_OK;

@@ -29,7 +29,7 @@ const OpEntry kOps[] = {
     YH_OP(yh_bn_silu_bwd_reduce), YH_OP(yh_bn_bwd_finalize), YH_OP(yh_bn_silu_bwd_apply), YH_OP(yh_colsum),
     YH_OP(yh_maxpool5_fwd), YH_OP(yh_maxpool5_bwd), YH_OP(yh_upsample2_bwd), YH_OP(yh_fill_u32),
     YH_OP(yh_bn_silu_apply_parts), YH_OP(yh_bn_silu_bwd_apply_parts), YH_OP(yh_bn_finalize_parts), YH_OP(yh_bn_bwd_finalize_parts),
-    YH_OP(yh_bn_frozen), YH_OP(yh_sppf_pool3_fwd), YH_OP(yh_sppf_pool3_bwd), YH_OP(yh_bn_silu_apply_fin), YH_OP(yh_bn_bwd_finalize_parts_split),
+    YH_OP(yh_bn_frozen), YH_OP(yh_sppf_pool3_fwd), YH_OP(yh_sppf_pool3_bwd),
 };
 constexpr int kNumOps = (int)(sizeof(kOps) / sizeof(kOps[0]));
 

@@ -615,13 +615,10 @@ extern "C" int yh_v5_assign(const yh_v5loss_desc* d, const float* targets, int32
     return YH_OK;
 }
 
-/* the assignment step of yh_v5_loss_fwd alone, into the `saved` state of a later yh_v5_loss_fwd(targets = NULL) call with the same
- * geometry: it depends on the targets only, so a training loop can run it on another stream beside the network's forward pass */
-extern "C" int yh_v5_loss_assign(const yh_v5loss_desc* d, const float* targets, void* saved, yh_stream stream)
+/* the assignment step of yh_v5_loss_fwd (it depends on the targets only), into the `saved` state of the call */
+static int v5_loss_assign(const yh_v5loss_desc* d, const float* targets, void* saved, yh_stream stream)
 {
-    int rc = check_desc(d, "yh_v5_loss_assign");
-    if (rc) return rc;
-    YH_CHECK_ARG(targets && saved, "yh_v5_loss_assign: null pointer");
+    int rc;
     LossK k; k.d = *d; k.L = make_layout(*d);
     char* sv = (char*)saved;
     int32_t* head = (int32_t*)(sv + k.L.head);
@@ -629,7 +626,7 @@ extern "C" int yh_v5_loss_assign(const yh_v5loss_desc* d, const float* targets, 
     if (rc) return rc;
     hipLaunchKernelGGL(v5_assign_kernel, dim3(d->num_stage), dim3(1024), 0, (hipStream_t)stream, k, targets,
                        (int32_t*)(sv + k.L.count), (float*)(sv + k.L.tbox), (int32_t*)(sv + k.L.tidx));
-    YH_CHECK_LAUNCH("yh_v5_loss_assign");
+    YH_CHECK_LAUNCH("yh_v5_loss_fwd(assign)");
     return YH_OK;
 }
 
@@ -638,7 +635,7 @@ extern "C" int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds,
 {
     int rc = check_desc(d, "yh_v5_loss_fwd");
     if (rc) return rc;
-    YH_CHECK_ARG(preds && balances && result && saved && ws, "yh_v5_loss_fwd: null pointer");
+    YH_CHECK_ARG(preds && targets && balances && result && saved && ws, "yh_v5_loss_fwd: null pointer");
     for (int s = 0; s < d->num_stage; ++s) YH_CHECK_ARG(preds[s] && yh_aligned16(preds[s]), "yh_v5_loss_fwd: preds[%d] null/unaligned", s);
     hipStream_t st = (hipStream_t)stream;
     LossK k; k.d = *d; k.L = make_layout(*d);
@@ -651,10 +648,8 @@ extern "C" int yh_v5_loss_fwd(const yh_v5loss_desc* d, const void* const* preds,
     int32_t* next = (int32_t*)(sv + k.L.next);
     int32_t* head = (int32_t*)(sv + k.L.head);
     double* part = (double*)ws;
-    if (targets) {                      // NULL: yh_v5_loss_assign has filled `saved` for this geometry (the caller orders the streams)
-        rc = yh_v5_loss_assign(d, targets, saved, stream);
-        if (rc) return rc;
-    }
+    rc = v5_loss_assign(d, targets, saved, stream);
+    if (rc) return rc;
     int nb_pos = (k.L.cap + 15) / 16;
     if (nb_pos > PART_BLOCKS) nb_pos = PART_BLOCKS;
     int nb_obj = PART_BLOCKS;
@@ -731,8 +726,9 @@ __global__ void iou_matrix_kernel(const float* __restrict__ b1, int n1, const fl
         const float* b = b2 + (size_t)j * 4;
         const float a1 = (a[2] - a[0]) * (a[3] - a[1]);
         const float a2 = (b[2] - b[0]) * (b[3] - b[1]);
-        const float w = fmaxf(fminf(a[2], b[2]) - fmaxf(a[0], b[0]), 0.f);
-        const float h = fmaxf(fminf(a[3], b[3]) - fmaxf(a[1], b[1]), 0.f);
+        float w = fminf(a[2], b[2]) - fmaxf(a[0], b[0]);
+        float h = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
+        if (eps_clamp >= 0.f) { w = fmaxf(w, 0.f); h = fmaxf(h, 0.f); }      // < 0: the evaluators' bbox_iou (trainer/eval_yolov5.py:237-258) clamps nothing
         const float inter = w * h;
         float den = a1 + a2 - inter;
         if (eps_clamp > 0.f) den = fmaxf(den, eps_clamp);      // gpu_iou; 0 -> numba_iou (no clamp, 0/0 = NaN)

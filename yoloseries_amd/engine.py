@@ -115,23 +115,7 @@ def tuning_source():
     return {"shipped_table": t.hits_shipped, "local_cache": t.hits_local, "timed_now": t.timed}
 
 
-# YH_BN_ACC=1: BatchNorm statistics / backward sums leave the conv kernels as int64 fixed-point accumulator rows that the BN+SiLU
-# passes reduce in their own prologue (no yh_bn_finalize / yh_bn_bwd_finalize launches: 114 launches fewer per step).  Measured on
-# MI355X it is SLOWER (14.8 vs 14.3 ms per step): every block of the pass stalls on the same reduction before it can stream, which
-# costs more than the 6.5 us finalize launch it replaces — so the per-block fp32 slabs + finalize kernels stay the default.
-BN_ACC = os.environ.get("YH_BN_ACC", "0") == "1"
 TUNE_ITERS = max(1, int(os.environ.get("YH_TUNE_ITERS", "3")))   # launches timed per candidate (tools/make_tune_defaults.sh: 12)
-ACC_ROWS = int(os.environ.get("YH_ACC_ROWS", "8"))
-# YH_BN_FIN_FUSE=1: the forward BatchNorm finalize launch of a layer rides in its BN+SiLU pass (yh_bn_silu_apply_fin: the grid's first
-# workgroups finalize, the others wait for them) — one launch and one kernel boundary less per layer.  Measured on the YOLOv5s step it
-# is 1 % SLOWER (12.29 vs 12.14 ms): finalize + publish + wake-up inside the pass cost ~7 us against 4.7 us for the launch plus
-# 1.5 us for the boundary it replaces (profiles/r04_step_experiments.txt, q) — off by default.
-BN_FIN_FUSE = os.environ.get("YH_BN_FIN_FUSE", "0") == "1"
-# YH_FIN_SPLIT_MIN=<rows>: backward finalize launches whose slab has at least this many rows are cut into row slices
-# (yh_bn_bwd_finalize_parts_split); 0 (default): never — the two launches per YOLOv5s step it applies to take 15 us either way, and the
-# long finalize launches of the trace (20 - 30 us) are short slabs waiting behind a weight gradient's transfers on the same CUs
-# (profiles/r04_step_experiments.txt, s)
-FIN_SPLIT_MIN = int(os.environ.get("YH_FIN_SPLIT_MIN", "0"))
 MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct layers: one BN+SiLU pass for all parts
 # YH_WGRAD_PARTIAL=1: the weight gradients' split-M partial tiles go to a workspace with plain stores and are summed in split
 # order by a second kernel (yh_wgrad_desc.partial) instead of fp32 atomics: BIT-REPRODUCIBLE gradients.  Measured on the YOLOv5s
@@ -145,7 +129,6 @@ MERGE_PARTS = os.environ.get("YH_MERGE_PARTS", "1") != "0"   # stacked ConvBnAct
 # the sigmoid of 210 M elements is hidden behind HBM time in a streaming pass but not between the barriers of a 15-wave-per-CU GEMM;
 # the step gets 1 % slower); 0: never.
 FUSE_STEM_BWD = int(os.environ.get("YH_FUSE_STEM_BWD", "1"))
-WGS_MERGE = os.environ.get("YH_WGS_MERGE", "0") != "0"                  # two-segment layers: one conv_wgs_kernel launch for both segments (measured: v5s step 12.13 -> 12.19 ms, off)
 HEAD_COLSUM_SIDE = os.environ.get("YH_HEAD_COLSUM_SIDE", "1") != "0"    # bias gradients of the head layers on the weight-gradient stream
 SPPF_FUSE = os.environ.get("YH_SPPF_FUSE", "1") != "0"      # FastSPP's three pools in one launch per direction (csrc/sppf.hip)
 WG_WS_BYTES = (256 << 20) if os.environ.get("YH_WGRAD_PARTIAL", "0") == "1" else 0
@@ -167,7 +150,7 @@ _WGRAD_TK64 = {
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
 KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad10", "wgrad8"
 KEY_CONV_C80 = "conv10"        # inference 3x3 layers with 80 -> 160 channels: conv_c80_kernel (algo 12) joined their candidates in round 4
-TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_CONV_C80, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f", KEY_WGRAD + "m"))
+TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_CONV_C80, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
 # YH_SKIP_ALGOS=<n>[,<n>]: leave these kernel families (yh_conv_desc.algo) out of the per-layer timing — A/B runs of a new family on
 # one box (use a YH_TUNE_CACHE of its own and YH_TUNE_DEFAULTS=0 for the layers concerned)
@@ -314,6 +297,31 @@ def sppf_chain(ops, i, L):
     return bool(L.yh_sppf_pool3_ok(a.src.buf.H, a.src.buf.W, a.src.C))
 
 
+def bn_of(m):
+    """the BatchNorm of a ConvBnAct as the engine sees it.  A module that went through the reference's deployment fusion
+    (detect_yolov5.py:110-116: `m.conv = fuse_conv_bn(m.conv, m.bn); delattr(m, 'bn'); m.forward = m.forward_fuse`) has a biased
+    conv and no `bn`: the engine's inference program folds (gamma, beta, mean, var) into the conv epilogue anyway, so the fused
+    module is described to it by a stand-in BatchNorm with gamma 1, mean 0, var 1 - eps and beta = the fused conv's bias —
+    conv(x) * 1 + bias, then SiLU, exactly utils/layer_tools.py:93-94.  The stand-in is not a registered sub-module (the
+    state_dict stays the fused one) and shares the conv's bias tensor."""
+    bn = getattr(m, 'bn', None)
+    if bn is not None:
+        return bn
+    conv = m.conv
+    if conv.bias is None:
+        raise YoloHipError("a ConvBnAct without `bn` must carry the fused conv of fuse_conv_bn (bias=True)")
+    st = m.__dict__.get('_yh_fused_bn')
+    if st is None or st.bias is not conv.bias:
+        n, dev = conv.out_channels, conv.weight.device
+        st = torch.nn.BatchNorm2d(n, eps=BN_EPS_DEFAULT).to(dev).eval()
+        st.weight.requires_grad_(False)
+        with torch.no_grad():
+            st.running_var.fill_(1.0 - BN_EPS_DEFAULT)
+        st.bias = conv.bias                       # the SAME Parameter: a later load_state_dict of the fused conv is seen
+        m.__dict__['_yh_fused_bn'] = st
+    return st
+
+
 class Builder:
     """Collects buffers and ops for one batch/input shape."""
 
@@ -336,9 +344,9 @@ class Builder:
         if focus:                      # 6x6/s2/p2 on the image == 3x3/s1/p1 on the space-to-depth tensor
             k, s, p = 3, 1, 1
         for m in mods:
-            if m.conv.groups != 1 or m.conv.bias is not None:
+            if m.conv.groups != 1 or (m.conv.bias is not None and hasattr(m, 'bn')):
                 raise YoloHipError(f"{name}: grouped / biased ConvBnAct is outside the HIP hot path")
-        op = ConvOp(name, segs, [(m.conv, m.bn) for m in mods], k, s, p, Hi, Wi, 'cba', None, res, focus)
+        op = ConvOp(name, segs, [(m.conv, bn_of(m)) for m in mods], k, s, p, Hi, Wi, 'cba', None, res, focus)
         op.y = self.buf(name + ".y", op.Ho, op.Wo, op.N)
         if dsts is None:
             dsts = [Ref(self.buf(name + f".a{i}" if len(mods) > 1 else name + ".a", op.Ho, op.Wo, n)) for i, n in enumerate(op.part_N)]
@@ -416,6 +424,7 @@ class ParamPack:
         gcur = 0
         unpack = np.full(self.n, -1, dtype=np.int64)
         self.gloc, self.bn_g, self.bias_g = {}, {}, {}
+        self.fused_ops = set()
 
         def widx(conv):
             w = conv.weight
@@ -490,7 +499,9 @@ class ParamPack:
             for pi, (conv, bn) in enumerate(op.parts):
                 if op.kind == 'plain':
                     break
-                if bn is not None:
+                if bn is not None and id(bn.weight) not in self.off:
+                    self.fused_ops.add(op.name)       # stand-in BatchNorm of a deployment-fused module (bn_of): inference only
+                elif bn is not None:
                     Cn = bn.weight.numel()
                     unpack[self.off[id(bn.weight)]:self.off[id(bn.weight)] + Cn] = gcur + np.arange(Cn)
                     unpack[self.off[id(bn.bias)]:self.off[id(bn.bias)] + Cn] = gcur + Cn + np.arange(Cn)
@@ -517,6 +528,12 @@ class ParamPack:
         ps = list(module.parameters())
         return len(ps) == len(self.params) and all(a is b for a, b in zip(ps, self.params)) and \
             ps[0].data_ptr() == self.flat.data_ptr() and ps[0].device == self.device
+
+    def still_valid(self):
+        """cheap form of valid_for() for a module this pack was already validated against: its first and last parameter still
+        alias the arena where the pack put them (a .to() / load with assign= / re-created parameter moves them)"""
+        p0, p1 = self.params[0], self.params[-1]
+        return p0.data_ptr() == self.flat.data_ptr() and p1.data_ptr() == self.flat.data_ptr() + 4 * (self.n - p1.numel())
 
     def repack(self):
         hipk.pack_bf16(self.flat, self.pack_idx, self.wpack)
@@ -588,7 +605,7 @@ class Program:
         key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else ((KEY_CONV_C80 if c80 else KEY_CONV_EVAL) if kind == 'eval' else KEY_CONV))}:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
-            int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), d.acc_rows))
+            int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), 0))
         cache = _tune_cache()
         if key in cache:
             d.tile_k, d.grid_cap, d.algo = (int(v) for v in cache[key])
@@ -611,15 +628,13 @@ class Program:
                 cands.append((1, tk, cap))
         d.tile_k = d.grid_cap = 0
         if os.environ.get("YH_CONV_V3", "1") != "0":
-            # algo 11 (conv_wpf_kernel: wave-private 128 x 128 tiles) is built and parity-tested but loses to the halo / ring kernels on
-            # every BASELINE layer shape (tile quantisation: tools/bench_wpf.py, profiles/r04_step_experiments.txt k): YH_CONV_WPF=1 times it too
-            for algo in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12) + ((11,) if os.environ.get("YH_CONV_WPF", "0") == "1" else ()):
+            for algo in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12):
                 if str(algo) in SKIP_ALGOS:
                     continue
                 d.algo = algo
                 kn = self._kernel_name(d)
                 if ("conv_v3" in kn and algo < 5) or ("conv_halo_kernel" in kn and algo == 5) or ("conv_halo160" in kn and algo == 6) or \
-                        ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8) or ("conv_h80" in kn and algo == 9) or ("conv_pw" in kn and algo == 10) or ("conv_wpf" in kn and algo == 11) or ("conv_c80" in kn and algo == 12):
+                        ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8) or ("conv_h80" in kn and algo == 9) or ("conv_pw" in kn and algo == 10) or ("conv_c80" in kn and algo == 12):
                     cands.append((algo, 0, 0))
                     if algo < 5 and kn.endswith(", true>") and all(d.seg[i].C % 32 == 0 for i in range(d.nseg)):
                         cands.append((algo, 32, 0))    # ragged last channel block: 32-channel steps instead of 64 + tail
@@ -631,11 +646,11 @@ class Program:
                 bnr_max = max(bnr_max, L.yh_conv_bnr_rows(C.byref(d)))
         tmp_stats = None
         if stats_ok:
-            tmp_stats = torch.zeros(max(rows_max, 2 * ACC_ROWS) + 8, 2, d.Npad, dtype=torch.float32, device=self.dev)
+            tmp_stats = torch.zeros(rows_max + 8, 2, d.Npad, dtype=torch.float32, device=self.dev)
             d.stats = tmp_stats.data_ptr()
         saved_part, tmp_part = d.bnr_part, None
         if d.bnr_part:                   # a slab big enough for every grid tried below
-            tmp_part = torch.zeros((max(bnr_max, 2 * ACC_ROWS) + 8) * 2 * d.N, dtype=torch.float32, device=self.dev)
+            tmp_part = torch.zeros((bnr_max + 8) * 2 * d.N, dtype=torch.float32, device=self.dev)
             d.bnr_part = tmp_part.data_ptr()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         best, best_ms = (0, 0, 1), None
@@ -771,13 +786,15 @@ class Program:
     def _build_train(self):
         """training program: conv (+ per-block BatchNorm partial sums) -> finalize -> BN+SiLU apply (+ residual)"""
         B, pk, L = self.B, self.pack, self.L
+        if pk.fused_ops:
+            raise YoloHipError(f"a model whose ConvBnAct layers went through fuse_conv_bn ({len(pk.fused_ops)} of them) has no BatchNorm "
+                               "left to train: it runs the inference program only (call .eval() under torch.no_grad())")
         for b in self.bufs:
             if b.t is None and not getattr(b, "is_head", False):
                 b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=self.dev)
         self.cmd_train = []
         self.cmd_frozen = None           # derived from cmd_train (evaluation-mode BatchNorm under autograd): rebuilt with it
         self.cmd_bwd_frozen = None
-        self._acc_fwd_elems = 0
         skip = set()
         for oi, op in enumerate(self.ops):
             if oi in skip:
@@ -808,28 +825,6 @@ class Program:
             d = self._conv_desc(op, True)
             d.act = YH_ACT_NONE
             d.out0, d.ld0, d.nsplit = op.y.t.data_ptr(), op.y.C, op.N
-            if BN_ACC:
-                # batch statistics leave the conv as int64 fixed-point adds into ACC_ROWS accumulator rows (order independent);
-                # the BN+SiLU apply reduces those rows in its prologue, so there is no finalize launch.  The rows of all layers
-                # form one arena that a single fill at the start of the forward zeroes.
-                d.acc_rows = ACC_ROWS
-                self._tune_conv(d, 'fwd', op.name, stats_ok=True)
-                st['acc_off'] = self._acc_fwd_elems
-                self._acc_fwd_elems += ACC_ROWS * 2 * op.Npad
-                st['desc_train'] = d
-                self.cmd_train.append((L.yh_conv_igemm, (d,), op.name, self._fam_conv(op, d)))
-                st['ws'] = []
-                c0 = 0
-                for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
-                    ws = torch.zeros(4 * n, dtype=torch.float32, device=self.dev)
-                    st['ws'].append(ws)
-                    mom = bn.momentum if bn.momentum is not None else 0.1
-                    dst = op.outs[pi].sl()
-                    res = op.res.sl() if (op.res is not None and pi == 0) else None
-                    self.cmd_train.append(('apply_acc', (op, c0, n, M, bn, float(mom), ws, dst, res), op.name,
-                                           ('yh_bn_silu_apply_acc', 0, (6.0 if res else 4.0) * M * n)))
-                    c0 += n
-                continue
             self._tune_conv(d, 'fwd', op.name, stats_ok=True)
             nblk = L.yh_conv_stat_blocks(C.byref(d))
             st['stats'] = torch.zeros(nblk, 2, op.Npad, dtype=torch.float32, device=self.dev)
@@ -870,70 +865,6 @@ class Program:
                 self.cmd_train.append((L.yh_bn_silu_apply_parts, (op.y.t.data_ptr(), op.y.C, M, parts_arr, len(op.parts)), op.name,
                                        ('yh_bn_silu_apply_parts', 0, 4.0 * M * op.N)))
 
-        self.cmd_train_src = self.cmd_train          # finalize launches spelled out: what the frozen-BatchNorm program is derived from
-        if BN_FIN_FUSE and not BN_ACC:
-            self.cmd_train = self._fuse_finalize(self.cmd_train)
-
-        if BN_ACC:
-            self.acc_fwd = torch.zeros(max(self._acc_fwd_elems, 2), dtype=torch.int64, device=self.dev)
-            cmds = [('fill', self.acc_fwd, None, ('yh_fill_u32', 0, 8.0 * self.acc_fwd.numel()))]
-            for cmd in self.cmd_train:
-                if cmd[0] == 'apply_acc':
-                    op, c0, n, Mx, bn, mom, ws, dst, res = cmd[1]
-                    st = self.op_state[op.name]
-                    acc_ptr = self.acc_fwd.data_ptr() + 8 * (st['acc_off'] + c0)
-                    args = (op.y.t.data_ptr() + 2 * c0, op.y.C, acc_ptr, ACC_ROWS, op.Npad, n, Mx, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                            bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), float(bn.eps), mom,
-                            ws.data_ptr(), dst.ptr(), dst.ld, res.ptr() if res else None, res.ld if res else 0)
-                    cmds.append((L.yh_bn_silu_apply_acc, args, cmd[2], cmd[3]))
-                else:
-                    cmds.append(cmd)
-            for op in self.ops:
-                if isinstance(op, ConvOp) and op.kind == 'cba':
-                    st = self.op_state[op.name]
-                    st['desc_train'].stats = self.acc_fwd.data_ptr() + 8 * st['acc_off']
-            self.cmd_train = cmds
-
-    def _fin_split_scratch(self):
-        """scratch of the split backward finalize launches (main stream only: one buffer for all layers)"""
-        if getattr(self, "_fin_scratch", None) is None:
-            self._fin_scratch = torch.zeros(int(self.L.yh_bn_fin_split_scratch_bytes()), dtype=torch.uint8, device=self.dev)
-        return self._fin_scratch.data_ptr()
-
-    def _fuse_finalize(self, cmds):
-        """(yh_bn_finalize, yh_bn_silu_apply) and (yh_bn_finalize_parts, yh_bn_silu_apply_parts) pairs of the forward program as
-        one yh_bn_silu_apply_fin launch each"""
-        L, out, i = self.L, [], 0
-        self._fin_sync = []
-        while i < len(cmds):
-            cmd = cmds[i]
-            nxt = cmds[i + 1] if i + 1 < len(cmds) else None
-            if nxt is not None and cmd[0] is L.yh_bn_finalize and nxt[0] is L.yh_bn_silu_apply and nxt[1][2] == cmd[1][12]:
-                stats, nblk, ldstat, n, M, gamma, beta, rm, rv, nbt, eps, mom, ws = cmd[1]
-                y, ldy, _ws, _n, _M, dst, ldo, res, ldr = nxt[1]
-                pa = (BnPart * 1)()
-                q = pa[0]
-                q.ws, q.C, q.out, q.ldo = ws, n, dst, ldo
-                q.slab, q.nblk, q.ldslab = stats, nblk, ldstat
-                q.gamma, q.beta, q.eps, q.momentum = gamma, beta, eps, mom
-                q.running_mean, q.running_var, q.num_batches = rm, rv, nbt
-                args = (y, ldy, M, pa, 1, res, ldr)
-            elif nxt is not None and cmd[0] is L.yh_bn_finalize_parts and nxt[0] is L.yh_bn_silu_apply_parts and nxt[1][3] is cmd[1][0]:
-                pa, nparts, M = cmd[1]
-                y, ldy, _M, _pa, _np = nxt[1]
-                args = (y, ldy, M, pa, nparts, None, 0)
-            else:
-                out.append(cmd)
-                i += 1
-                continue
-            sync = torch.zeros(128 * 32 + 2, dtype=torch.int32, device=self.dev)       # YH_BN_FIN_SYNC_WORDS
-            self._fin_sync.append(sync)
-            self._keep.append(pa)
-            fam, _, nbytes = nxt[3]
-            out.append((L.yh_bn_silu_apply_fin, args + (sync.data_ptr(),), nxt[2], ('yh_bn_silu_apply_fin', 0, nbytes + cmd[3][2])))
-            i += 2
-        return out
-
     # -- forward ---------------------------------------------------------------------------
     def _kernel_name(self, d):
         """instantiation yh_conv_igemm launches for descriptor d, spelled as rocprofv3 prints it"""
@@ -970,7 +901,7 @@ class Program:
         if not isinstance(op, ConvOp) or op.kind != 'cba':
             return False
         Kseg0 = op.k * op.k * op.segs[0].C
-        return bool(FUSE_STEM_BWD and not BN_ACC and len(op.parts) == 1 and len(op.segs) == 1 and op.res is None and
+        return bool(FUSE_STEM_BWD and len(op.parts) == 1 and len(op.segs) == 1 and op.res is None and
                     not op.segs[0].buf.needs_grad and op.N % 8 == 0 and
                     ((op.N <= 32 and Kseg0 <= 256) or (op.N > 32 and 128 < Kseg0 <= 256)) and
                     (FUSE_STEM_BWD >= 2 or (self.wg_ws is None and self._stem_patch_ok(op))))
@@ -998,16 +929,13 @@ class Program:
         for fn, args, name, meta in cmds:
             if getattr(fn, "__name__", "") in ABL_SKIP:
                 continue
-            if fn == 'fill':
-                cc.call(self.L.yh_fill_u32, (args.data_ptr(), 0, args.numel() * args.element_size() // 4), 0, name)
-            else:
-                cc.call(fn, args, 0, name)
+            cc.call(fn, args, 0, name)
         return cc
 
     def _run(self, cmds):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         prof = self.profile
-        if prof is None and USE_EXEC and not BN_ACC:
+        if prof is None and USE_EXEC:
             key = 'train' if cmds is self.cmd_train else ('frozen' if cmds is getattr(self, "cmd_frozen", None) else 'eval')
             cc = self._compiled.get(key)
             if cc is None or cc.source is not cmds:
@@ -1019,10 +947,7 @@ class Program:
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if fn == 'fill':
-                rc = self.L.yh_fill_u32(args.data_ptr(), 0, args.numel() * args.element_size() // 4, st)
-            else:
-                rc = fn(*args, st)
+            rc = fn(*args, st)
             if rc != 0:
                 check(rc, f"{getattr(fn, '__name__', fn)} [{name}]")
             if prof is not None:
@@ -1034,7 +959,7 @@ class Program:
         batch statistics -> constants, running-statistics update — give way to yh_bn_frozen (constants from the running
         statistics); the conv kernels still emit their partial sums, nobody reads them"""
         L, out = self.L, []
-        for cmd in getattr(self, "cmd_train_src", self.cmd_train):
+        for cmd in self.cmd_train:
             fn, args = cmd[0], cmd[1]
             if fn is L.yh_bn_finalize:
                 _stats, _nblk, _ld, n, _M, gamma, beta, rm, rv, _nbt, eps, _mom, ws = args
@@ -1059,8 +984,6 @@ class Program:
         if train and self.cmd_train is None:
             self._build_train()
         if train and frozen:
-            if BN_ACC:
-                raise YoloHipError("evaluation-mode BatchNorm under autograd is not available with YH_BN_ACC=1")
             if getattr(self, "cmd_frozen", None) is None:
                 self.cmd_frozen = self._frozen_cmds()
             self._run(self.cmd_frozen)
@@ -1159,15 +1082,6 @@ class Program:
                 return False
             return not any(k2[0] == key[0] and k2 != key and not (k2[1] + k2[2] <= key[1] or k2[1] >= key[1] + key[2]) for k2 in uses)
         self.bnr_fused = {}
-        # accumulator rows of the BatchNorm-backward sums of every ConvBnAct part: one arena, zeroed by one fill per backward
-        self.acc_bwd_off, tot = {}, 0
-        for o2 in self.ops:
-            if isinstance(o2, ConvOp) and o2.kind == 'cba':
-                for pi2, n2 in enumerate(o2.part_N):
-                    self.acc_bwd_off[(o2.name, pi2)] = tot
-                    tot += ACC_ROWS * 2 * n2
-        self.acc_bwd = torch.zeros(max(tot, 2), dtype=torch.int64, device=self.dev) if BN_ACC else None
-
         marks = []
         skip_bwd = set()
         nops = len(self.ops)
@@ -1219,7 +1133,7 @@ class Program:
                 # gradient: that kernel forms gz from (ga, z) in its operand loader (yh_wgrad_desc.bn_*), the apply pass — the
                 # last 0.2 ms of the backward's critical path on YOLOv5s — and the gz round trip through HBM disappear
                 fused_stem = self._is_fused_stem(op)
-                merged = (MERGE_PARTS and not BN_ACC and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and
+                merged = (MERGE_PARTS and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and
                           not (op.res is not None and op.res.buf.needs_grad))
                 bwd_parts = (BnPart * len(op.parts))() if merged else None
                 scratch_off = 0
@@ -1231,23 +1145,6 @@ class Program:
                     self.coef_scratch[(op.name, pi)] = coef
                     nblk = L.yh_ew_blocks(M)
                     ypart = op.y.t.data_ptr() + 2 * c0
-                    if BN_ACC:
-                        acc_ptr = self.acc_bwd.data_ptr() + 8 * self.acc_bwd_off[(op.name, pi)]
-                        if self.bnr_fused.get((op.name, pi)) is None:     # no data gradient took the reduction into its epilogue
-                            cmds.append((L.yh_bn_silu_bwd_reduce_acc, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), n, M, acc_ptr, ACC_ROWS),
-                                         op.name, ('yh_bn_silu_bwd_reduce', 0, 4.0 * M * n)))
-                        goff, boff = pk.bn_g[(op.name, pi)]
-                        gres_ptr, gres_ld, gres_acc = None, 0, 0
-                        if op.res is not None and pi == 0 and op.res.buf.needs_grad:
-                            gres_acc = claim(op.res)
-                            gr = op.res.sl(True)
-                            gres_ptr, gres_ld = gr.ptr(), gr.ld
-                        cmds.append((L.yh_bn_silu_bwd_apply_acc, (ga.ptr(), ga.ld, ypart, op.y.C, ws.data_ptr(), bn.weight.data_ptr(), acc_ptr, ACC_ROWS,
-                                                                  n, M, pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
-                                                                  gys.data_ptr() + 2 * c0, op.N, gres_ptr, gres_ld, gres_acc), op.name,
-                                     ('yh_bn_silu_bwd_apply_acc', 0, (6.0 + (4.0 if gres_acc else 2.0) * (gres_ptr is not None)) * M * n)))
-                        c0 += n
-                        continue
                     part_ptr = self.part_scratch.data_ptr()
                     fused = self.bnr_fused.get((op.name, pi))
                     if fused is not None:          # the consumer's data gradient already left the partial sums in its own slab
@@ -1265,17 +1162,9 @@ class Program:
                         pa.slab, pa.nblk = part_ptr, nblk
                         pa.dgamma, pa.dbeta = pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff
                     else:
-                        if FIN_SPLIT_MIN and nblk >= FIN_SPLIT_MIN:
-                            one = (BnPart * 1)()
-                            one[0].slab, one[0].nblk, one[0].C, one[0].ws, one[0].coef = part_ptr, nblk, n, ws.data_ptr(), coef.data_ptr()
-                            one[0].dgamma, one[0].dbeta = pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff
-                            self._keep.append(one)
-                            cmds.append((L.yh_bn_bwd_finalize_parts_split, (one, 1, M, self._fin_split_scratch()), op.name,
-                                         ('yh_bn_bwd_finalize', 0, 8.0 * nblk * n)))
-                        else:
-                            cmds.append((L.yh_bn_bwd_finalize, (part_ptr, nblk, n, M, ws.data_ptr(),
-                                                                pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
-                                                                coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0, 8.0 * nblk * n)))
+                        cmds.append((L.yh_bn_bwd_finalize, (part_ptr, nblk, n, M, ws.data_ptr(),
+                                                            pk.gpack.data_ptr() + 4 * goff, pk.gpack.data_ptr() + 4 * boff,
+                                                            coef.data_ptr()), op.name, ('yh_bn_bwd_finalize', 0, 8.0 * nblk * n)))
                     gres_ptr, gres_ld, gres_acc = None, 0, 0
                     if op.res is not None and pi == 0 and op.res.buf.needs_grad:
                         gres_acc = claim(op.res)
@@ -1295,12 +1184,8 @@ class Program:
                     c0 += n
                 if bwd_parts is not None:          # the parts' reductions are done: one finalize, one pass writes gz of the whole stacked layer
                     self._keep.append(bwd_parts)
-                    if FIN_SPLIT_MIN and max(int(q.nblk) for q in bwd_parts) >= FIN_SPLIT_MIN:
-                        cmds.append((L.yh_bn_bwd_finalize_parts_split, (bwd_parts, len(op.parts), M, self._fin_split_scratch()), op.name,
-                                     ('yh_bn_bwd_finalize', 0, 8.0 * sum(int(q.nblk) * int(q.C) for q in bwd_parts))))
-                    else:
-                        cmds.append((L.yh_bn_bwd_finalize_parts, (bwd_parts, len(op.parts), M), op.name,
-                                     ('yh_bn_bwd_finalize', 0, 8.0 * sum(int(q.nblk) * int(q.C) for q in bwd_parts))))
+                    cmds.append((L.yh_bn_bwd_finalize_parts, (bwd_parts, len(op.parts), M), op.name,
+                                 ('yh_bn_bwd_finalize', 0, 8.0 * sum(int(q.nblk) * int(q.C) for q in bwd_parts))))
                     cmds.append((L.yh_bn_silu_bwd_apply_parts, (op.y.t.data_ptr(), op.y.C, M, bwd_parts, len(op.parts), gys.data_ptr(), op.N),
                                  op.name, ('yh_bn_silu_bwd_apply_parts', 0, 6.0 * M * op.N)))
                 gy_ld, gyN = op.N, op.N
@@ -1328,30 +1213,12 @@ class Program:
                 if self.wg_ws is not None:
                     wd.partial, wd.partial_bytes = self.wg_ws.data_ptr(), self.wg_ws.numel() * 4
                 return wd
-            merged = None
-            if len(op.segs) == 2 and WGS_MERGE and not on_main:
-                # a concat input: both segments in ONE launch of conv_wgs_kernel (yh_wgrad_desc.seg2) — gy read once per pixel
-                # split, one set of partial tiles / atomics and one launch instead of two
-                wm = wgrad_desc_for(op.segs[0], 0)
-                wm.seg2 = hipk.make_seg(op.segs[1].sl())
-                wm.coff_k2 = op.segs[0].C
-                wm.tile_k = 129
-                if L.yh_conv_wgrad_wave_tiles(C.byref(wm)) > 0:
-                    merged = wm
             coff_k = 0
             for si, sg in enumerate(op.segs):
-                if merged is not None:
-                    if si == 1:
-                        break
-                    wd = merged
-                    ntile = L.yh_conv_wgrad_wave_tiles(C.byref(wd))
-                    kcols = op.k * op.k * op.Ctot
-                    nbytes_x = sum(2.0 * B * (op.Hi >> g.ups) * (op.Wi >> g.ups) * g.C for g in op.segs)
-                else:
-                    wd = wgrad_desc_for(sg, coff_k)
-                    ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
-                    kcols = op.k * op.k * (12 if op.focus else sg.C)
-                    nbytes_x = 2.0 * B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.C
+                wd = wgrad_desc_for(sg, coff_k)
+                ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
+                kcols = op.k * op.k * (12 if op.focus else sg.C)
+                nbytes_x = 2.0 * B * (op.Hi >> sg.ups) * (op.Wi >> sg.ups) * sg.C
                 wd.splits = self._tune_wgrad_splits(wd, M, ntile, op)
                 self._keep.append(wd)
                 if on_main:
@@ -1402,16 +1269,11 @@ class Program:
                             po, ppi, pc0 = producer_of[key]
                             d.bnr_z, d.bnr_ldz = po.y.t.data_ptr() + 2 * pc0, po.y.C
                             d.bnr_ws, d.bnr_C = self.op_state[po.name]['ws'][ppi].data_ptr(), sg.C
-                            if BN_ACC:
-                                d.bnr_part = self.acc_bwd.data_ptr() + 8 * self.acc_bwd_off[(po.name, ppi)]
-                                d.acc_rows = ACC_ROWS
-                                self.bnr_fused[(po.name, ppi)] = (self.acc_bwd, ACC_ROWS)
-                            else:
-                                slab = torch.zeros(rows * 2 * sg.C, dtype=torch.float32, device=self.dev)
-                                d.bnr_part = slab.data_ptr()
-                                self.bnr_fused[(po.name, ppi)] = (slab, rows)
+                            slab = torch.zeros(rows * 2 * sg.C, dtype=torch.float32, device=self.dev)
+                            d.bnr_part = slab.data_ptr()
+                            self.bnr_fused[(po.name, ppi)] = (slab, rows)
                     self._tune_conv(d, 'dgrad', op.name)
-                    if not BN_ACC and d.bnr_part and L.yh_conv_bnr_rows(C.byref(d)) != self.bnr_fused[(po.name, ppi)][1]:
+                    if d.bnr_part and L.yh_conv_bnr_rows(C.byref(d)) != self.bnr_fused[(po.name, ppi)][1]:
                         # the tuned block cap changed the grid: size the slab for it
                         rows = L.yh_conv_bnr_rows(C.byref(d))
                         slab = torch.zeros(rows * 2 * sg.C, dtype=torch.float32, device=self.dev)
@@ -1436,9 +1298,8 @@ class Program:
             return max(1, min((M + 255) // 256, (total + nt - 1) // nt))
         if os.environ.get("YH_WGRAD_TUNE", "1") == "0":
             return splits_for(512)
-        two = bool(wd.seg2.ptr)
-        key = f"{KEY_WGRAD_WS if wd.partial else KEY_WGRAD}{'f' if wd.bn_z else ''}{'m' if two else ''}:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
-                                                          wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad) + ((wd.seg2.C, wd.seg2.ld, wd.seg2.ups) if two else ()))
+        key = f"{KEY_WGRAD_WS if wd.partial else KEY_WGRAD}{'f' if wd.bn_z else ''}:" + ",".join(str(int(v)) for v in (wd.N, wd.ldg, wd.seg.C, wd.seg.ld, wd.seg.ups, wd.Ctot, wd.B, wd.Ho, wd.Wo,
+                                                          wd.Hi, wd.Wi, wd.KH, wd.stride, wd.pad))
         cache = _tune_cache()
         if key in cache:
             sp, wd.tile_k = (int(v) for v in cache[key])
@@ -1451,15 +1312,13 @@ class Program:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         name = self.L.yh_conv_wgrad_kernel_name(wd.N, wd.KH * wd.KW * wd.seg.C).decode()
         tks = (0, 64) if name in _WGRAD_TK64 else (0,)
-        if two:
-            name, tks = "", ()              # both segments in one launch: only conv_wgs_kernel takes the second segment
         if name.startswith("conv_wgrad_kernel<4, 2, 1, 2, 64"):
             tks = tks + (32, 35)            # the general tiling with 32-pixel k-steps (two blocks per CU): 8 waves of 32 x 64 / 4 of 64 x 64
-        if 128 <= Kseg <= 384 and wd.N > 32 and not wd.bn_z and not two:
+        if 128 <= Kseg <= 384 and wd.N > 32 and not wd.bn_z:
             tks = tks + (128,)              # the general 128-column tiling on a layer that defaults to a wide one
         best, best_ms = None, None
         wd.tile_k = 40
-        if not wd.partial and not two and self.L.yh_conv_wgrad_patch_ok(C.byref(wd)):
+        if not wd.partial and self.L.yh_conv_wgrad_patch_ok(C.byref(wd)):
             tks = tks + (40,)               # patch form (conv_wgp_kernel): the input patch of a pixel region staged once in LDS
         wtiles = 0 if (wd.partial or wd.bn_z or os.environ.get("YH_WGRAD_WAVE", "1") == "0") else self.L.yh_conv_wgrad_wave_tiles(C.byref(wd))
         if wtiles > 0:
@@ -1474,7 +1333,7 @@ class Program:
                 # when its big layers take the whole chip (43.36 -> 42.82 ms): layers under 60 GFLOP get 192, the others 256
                 # (profiles/r04_step_experiments.txt d).  Half of the budget is timed too: on the small layers the atomics (one
                 # partial tile per workgroup) dominate.
-                wflops = 2.0 * M * wd.N * wd.KH * wd.KW * (wd.seg.C + (wd.seg2.C if two else 0))
+                wflops = 2.0 * M * wd.N * wd.KH * wd.KW * wd.seg.C
                 gmax = int(os.environ.get("YH_WGS_G", "256" if wflops >= 60e9 else "192"))
                 sps = set()
                 for g in (gmax, gmax // 2):
@@ -1631,8 +1490,6 @@ class Program:
         pk, L = self.pack, self.L
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         hipk.fill_zero(pk.gpack)
-        if self.acc_bwd is not None:
-            hipk.fill_zero(self.acc_bwd)
         heads = {}
         for o, g in zip(self.outputs, head_grads):
             if isinstance(o, ConvOp):
@@ -1654,7 +1511,7 @@ class Program:
             self._ev_gz.record(main)               # packed arena zeroed, head gradients in place
             side.wait_event(self._ev_gz)
             pending = [False] * NGZ
-        if prof is None and USE_EXEC and not BN_ACC:
+        if prof is None and USE_EXEC:
             # replay the compiled command array (yh_exec): one call per bucket segment instead of one ctypes call per launch
             key = ('bwd', two, bucket_hook is not None, frozen)
             comp = self._compiled.get(key)

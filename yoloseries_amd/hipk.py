@@ -184,13 +184,6 @@ def bn_silu_apply_parts(y: Slice, M, parts):
     check(lib().yh_bn_silu_apply_parts(y.ptr(), y.ld, M, arr, len(parts), _st()), "yh_bn_silu_apply_parts")
 
 
-def bn_silu_apply_fin(y: Slice, M, parts, sync, res: Slice = None):
-    """finalize + BN+SiLU pass of all parts in one launch (parts: the union of the finalize and forward-pass fields)"""
-    arr = _bn_parts(parts)
-    check(lib().yh_bn_silu_apply_fin(y.ptr(), y.ld, M, arr, len(parts), res.ptr() if res else None, res.ld if res else 0, _p(sync), _st()),
-          "yh_bn_silu_apply_fin")
-
-
 def bn_silu_bwd_apply_parts(y: Slice, M, parts, gy: Slice):
     arr = _bn_parts(parts)
     check(lib().yh_bn_silu_bwd_apply_parts(y.ptr(), y.ld, M, arr, len(parts), gy.ptr(), gy.ld, _st()), "yh_bn_silu_bwd_apply_parts")

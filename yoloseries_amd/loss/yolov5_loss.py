@@ -36,16 +36,8 @@ class _V5LossFn(torch.autograd.Function):
         desc, canon, lds = owner._make_desc(preds, targets)
         L = lib()
         dev = targets.device
-        owner._assign_sig = owner._signature(desc)          # what prefetch_assign() needs to know about the next call
-        owner._assign_desc = desc
-        pf = owner._take_prefetched(desc, targets)
-        if pf is not None:                                   # the assignment ran beside the network's forward pass
-            saved, ev = pf
-            torch.cuda.current_stream(dev).wait_event(ev)
-            tptr = None
-        else:
-            saved = torch.empty(L.yh_v5loss_saved_bytes(C.byref(desc)), dtype=torch.uint8, device=dev)
-            tptr = targets.data_ptr()
+        saved = torch.empty(L.yh_v5loss_saved_bytes(C.byref(desc)), dtype=torch.uint8, device=dev)
+        tptr = targets.data_ptr()
         ws = owner._workspace(L.yh_v5loss_ws_bytes(C.byref(desc)), dev)
         result = torch.empty(8, dtype=torch.float32, device=dev)
         ptrs = (C.c_void_p * 4)(*[c.data_ptr() for c in canon], *([None] * (4 - len(canon))))
@@ -92,7 +84,6 @@ class YOLOV5Loss:
         self._init_balances = [4., 1., 0.4] if stage_num == 3 else [4., 1., 0.4, 0.1]
         self._balances = None
         self._ws = None
-        self._assign_sig = self._assign_desc = self._prefetched = self._side = None
         self._anchors_host = [[[float(v) for v in a] for a in st] for st in anchors.detach().cpu().tolist()]
 
     # ---- state -----------------------------------------------------------------------------
@@ -112,50 +103,6 @@ class YOLOV5Loss:
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         return self._ws
-
-    # ---- assignment beside the network's forward pass ---------------------------------------
-    @staticmethod
-    def _signature(d):
-        """the descriptor fields the assignment and the layout of `saved` depend on"""
-        return (d.B, d.maxbox, d.num_class, d.num_anchor, d.num_stage, tuple(d.H), tuple(d.W), d.img_size0, d.img_size1,
-                tuple(d.anchors), d.anchor_thr, d.targets_xywhn)
-
-    def prefetch_assign(self, targets_batch):
-        """Start the target assignment of the NEXT __call__ on a side stream (loss/yolov5_loss.py:142-214 depends on the targets
-        only): call it before the network's forward pass of the same batch.  Needs one earlier __call__ with the same geometry (the
-        feature-map sizes come from it); returns False — and the next __call__ assigns as usual — when there is none.  The targets
-        tensor must not be modified until that __call__."""
-        if self._assign_sig is None or not isinstance(targets_batch, torch.Tensor) or not targets_batch.is_cuda:
-            return False
-        if targets_batch.dtype != torch.float32 or not targets_batch.is_contiguous():
-            return False                                  # __call__ would make a converted copy: nothing to key the hand-over on
-        d = self._assign_desc
-        if (targets_batch.shape[0], targets_batch.shape[1]) != (d.B, d.maxbox):
-            return False
-        dev = targets_batch.device
-        main = torch.cuda.current_stream(dev)
-        if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
-        L = lib()
-        saved = torch.empty(L.yh_v5loss_saved_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
-        self._side.wait_stream(main)                     # the targets (and whatever else the batch waits for) are ready
-        saved.record_stream(self._side)
-        targets_batch.record_stream(self._side)
-        check(L.yh_v5_loss_assign(C.byref(d), targets_batch.data_ptr(), saved.data_ptr(), C.c_void_p(self._side.cuda_stream)),
-              "yh_v5_loss_assign")
-        ev = torch.cuda.Event()
-        ev.record(self._side)
-        self._prefetched = (targets_batch.data_ptr(), targets_batch._version, self._assign_sig, saved, ev)
-        return True
-
-    def _take_prefetched(self, desc, targets):
-        pf, self._prefetched = self._prefetched, None
-        if pf is None:
-            return None
-        ptr, ver, sig, saved, ev = pf
-        if ptr != targets.data_ptr() or ver != targets._version or sig != self._signature(desc):
-            return None                                   # another batch / geometry: assign as usual (the side-stream work is dropped)
-        return saved, ev
 
     def _make_desc(self, preds, targets, canon_given=None):
         hyp = self.hyp

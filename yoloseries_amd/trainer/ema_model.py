@@ -25,6 +25,7 @@ class ExponentialMovingAverageModel:
         for parm in self.ema.parameters():
             parm.requires_grad_(False)
         self._flat = None
+        self._fast = None               # (source pack, destination arenas) validated by an earlier update
 
     def _flat_views(self, src_pack):
         """(re)alias the EMA module's parameters / float buffers onto two flat tensors laid out like the source arenas"""
@@ -63,6 +64,16 @@ class ExponentialMovingAverageModel:
         the device counter / decay pair is rebuilt by the next eager update"""
         self.update_num = snap
         self._dev_state = None
+        self._fast = None
+
+    def _dst_unchanged(self, fast):
+        """the EMA module's parameters still live where the last full update found them: in its own engine arenas (it has been
+        evaluated) or in the flat views of _flat_views() (it has not — and still has no engine state of its own)"""
+        est = self.ema.__dict__.get('_yh')
+        epack = est['pack'] if est else None
+        if fast[3] is not None:
+            return epack is fast[3] and epack.still_valid()
+        return epack is None and next(self.ema.parameters()).data_ptr() == fast[1].data_ptr()
 
     def update(self, model):
         with torch.no_grad():
@@ -71,8 +82,20 @@ class ExponentialMovingAverageModel:
             src = _unwrap(model)
             st = src.__dict__.get('_yh')
             pack = st['pack'] if st else None
+            from .. import hipk
+            fast = self._fast
+            if fast is not None and fast[0] is pack and pack.still_valid() and self._dev_state is not None and \
+                    self._dev_state[2] == self.update_num - 1 and self._dst_unchanged(fast):
+                # steady state of a training loop: same arenas as last time — three launches and no walk over the 177 parameters
+                # (the full validity checks below cost ~0.2 ms of host time per step, a visible gap in a profiler trace)
+                cnt, dec = self._dev_state[0], self._dev_state[1]
+                hipk.ema_advance(cnt, dec, self.decay_ratio, 2000.0)
+                self._dev_state[2] = self.update_num
+                hipk.ema_update_dev(fast[1], pack.flat, dec)
+                if pack.nbuf:
+                    hipk.ema_update_dev(fast[2], pack.fbuf, dec)
+                return
             if pack is not None and pack.valid_for(src):
-                from .. import hipk
                 # the decay of this update is produced on the device from a device-resident update counter (same formula,
                 # evaluated in double): the launch takes no host scalar, so a captured step replays correctly
                 if self._dev_state is None or self._dev_state[2] != self.update_num - 1 or self._dev_state[0].device != pack.device:
@@ -95,11 +118,13 @@ class ExponentialMovingAverageModel:
                     _ema(epack.flat, pack.flat)
                     if pack.nbuf:
                         _ema(epack.fbuf, pack.fbuf)
+                    self._fast = (pack, epack.flat, epack.fbuf, epack)
                     return
                 fp, fb = self._flat_views(pack)
                 _ema(fp, pack.flat)
                 if pack.nbuf:
                     _ema(fb, pack.fbuf)
+                self._fast = (pack, fp, fb, None)
                 # integer buffers (num_batches_tracked) are not averaged by the reference either
                 return
             state = src.state_dict()

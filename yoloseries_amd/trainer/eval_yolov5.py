@@ -130,26 +130,72 @@ class YOLOV5Evaluator:
             cap = ((n + 3) // 4) * 4
         return self._run_nms(cand, ncand, B, cap)
 
-    def numba_nms(self, preds_out):
-        """:param preds_out: decoded (bs, N, 5+nc) tensor -> list of np.ndarray (n,6) or None (:261-317)"""
+    _FILTER_MODES = (0, 2)        # yh_filter_decoded mode of the single-label / hyp['mutil_label'] candidate rule (:266-286)
+
+    def _filter_decoded(self, preds_out):
+        """decoded (bs, N, 5+nc) -> candidate tables (bs, cap, 6) [xmin, ymin, xmax, ymax, conf, cls] + counts, on the device:
+        obj >= conf threshold, cls * obj, arg-max > cls threshold or — hyp['mutil_label'] — one candidate per (prediction, class)
+        in np.nonzero order (:266-286; yh_filter_decoded)"""
         p = preds_out.detach().to(torch.float32).contiguous()
         if not p.is_cuda:
-            dev = self.device if str(self.device).startswith("cuda") else "cuda:0"
-            p = p.to(dev)
+            p = p.to(self.device if str(self.device).startswith("cuda") else "cuda:0")
         B, n, E = p.shape
         assert E == 5 + self.num_class
         cap = ((n + 3) // 4) * 4
-        mode = 2 if self.hyp.get('mutil_label', False) else 0
+        multi = bool(self.hyp.get('mutil_label', False))
+        mode = self._FILTER_MODES[1 if multi else 0]
         while True:
             cand = torch.empty(B, cap, 6, dtype=torch.float32, device=p.device)
             ncand = torch.zeros(B, dtype=torch.int32, device=p.device)
             check(lib().yh_filter_decoded(p.data_ptr(), B, n, self.num_class, float(self.conf_threshold), float(self.cls_threshold), mode,
                                           cand.data_ptr(), ncand.data_ptr(), cap, _lib.stream_ptr()), "yh_filter_decoded")
-            most = int(ncand.max().item()) if mode == 2 else 0       # multi-label: up to num_class candidates per prediction
+            most = int(ncand.max().item()) if multi else 0          # multi-label: up to num_class candidates per prediction
             if most <= cap:
                 break
             cap = ((most + 3) // 4) * 4
-        return self._run_nms(cand, ncand, B, cap)
+        return cand, ncand, B, cap
+
+    def do_nms(self, preds_out):
+        """"Do NMS with torch" (trainer/eval_yolov5.py:94-150): decoded (bs, X, 5+nc) -> list of (n, 6) device tensors or None.
+        Candidate rule as numba_nms (yh_filter_decoded); suppression by utils.gpu_nms — hyp['iou_type'] one of iou / giou /
+        diou / ciou, EXCLUSIVE threshold — on boxes offset by cls * 4096 when hyp['agnostic'] is set; at most
+        max_predictions_per_img rows; with hyp['postprocess_bbox'] a kept box survives only if MORE than one candidate
+        overlaps it by > threshold under `bbox_iou` (the unclamped IoU below; the box merge the reference computes there is
+        written to a temporary it never returns, :143, so the rows are the candidates' own).  The reference's gpu_nms raises
+        IndexError for more than one candidate (utils/nms.py:62-63 indexes a 1-D score tensor with a (1, M) mask); this follows
+        the semantics its loop spells — the single-candidate and empty cases agree with it literally."""
+        from ..utils.nms import gpu_nms
+        cand, ncand, B, _cap = self._filter_decoded(preds_out)
+        outputs = []
+        for i, bbox_num in enumerate(ncand.cpu().tolist()):
+            if not bbox_num:
+                outputs.append(None)
+                continue
+            x = cand[i, :bbox_num]
+            box_offset = x[:, 5] * 4096 if self.hyp['agnostic'] else x[:, 5] * 0.
+            bboxes_offseted = x[:, :4] + box_offset[:, None]
+            keep_index = gpu_nms(bboxes_offseted, x[:, 4].contiguous(), self.hyp['iou_type'], self.iou_threshold)
+            if len(keep_index) > self.hyp['max_predictions_per_img']:
+                keep_index = keep_index[:self.hyp['max_predictions_per_img']]
+            if self.hyp['postprocess_bbox'] and 1 < bbox_num < 3000:
+                iou = self.bbox_iou(bboxes_offseted[keep_index], bboxes_offseted)      # (N, M)
+                keep_index = torch.tensor(keep_index)[((iou > self.iou_threshold).float().sum(dim=1) > 1).cpu()]
+            outputs.append(x[keep_index])
+        return outputs
+
+    @staticmethod
+    def bbox_iou(bbox1, bbox2):
+        """(N, 4), (M, 4) xyxy -> (N, M) IoU exactly as trainer/eval_yolov5.py:237-258 spells it: NO clamp on the intersection
+        sides (two boxes apart on BOTH axes get a positive "intersection", the product of two negative sides) and none on the
+        union (0 / 0 = NaN).  yh_iou_matrix with a negative clamp."""
+        assert bbox1.ndim == 2
+        assert bbox2.ndim == 2
+        from ..utils.bbox_tools import _iou_matrix
+        return _iou_matrix(bbox1, bbox2, -1.0)
+
+    def numba_nms(self, preds_out):
+        """:param preds_out: decoded (bs, N, 5+nc) tensor -> list of np.ndarray (n,6) or None (:261-317)"""
+        return self._run_nms(*self._filter_decoded(preds_out))
 
     def test_time_augmentation(self, inputs):
         """3 passes (1.0/none, 0.83/flip-y, 0.67/flip-x), un-scaled / un-flipped, concatenated (:152-179)"""

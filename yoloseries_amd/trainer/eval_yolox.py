@@ -102,22 +102,8 @@ class YOLOXEvaluator(YOLOV5Evaluator):
                                      cand.data_ptr(), ncand.data_ptr(), cap, _decode_ws(self, d, dev), _lib.stream_ptr()), "yh_decode_filter")
         return self._run_nms(cand, ncand, B, cap)
 
-    def numba_nms(self, preds_out):
-        """decoded (bs, N, 5+nc) -> list of np.ndarray (n,6) or None (eval_yolox.py:201-259): pre-filter on
-        obj*max(cls) >= conf, class confidence >= cls threshold (inclusive, unlike the v5 evaluator)"""
-        p = preds_out.detach().to(torch.float32).contiguous()
-        if not p.is_cuda:
-            p = p.to(self.device if str(self.device).startswith("cuda") else "cuda:0")
-        B, n, E = p.shape
-        cap = ((n + 3) // 4) * 4
-        mode = 3 if self.hyp.get('mutil_label', False) else 1      # 3: one candidate per (prediction, class) (:218-221)
-        while True:
-            cand = torch.empty(B, cap, 6, dtype=torch.float32, device=p.device)
-            ncand = torch.zeros(B, dtype=torch.int32, device=p.device)
-            check(lib().yh_filter_decoded(p.data_ptr(), B, n, self.num_class, float(self.conf_threshold), float(self.cls_threshold), mode,
-                                          cand.data_ptr(), ncand.data_ptr(), cap, _lib.stream_ptr()), "yh_filter_decoded")
-            most = int(ncand.max().item()) if mode == 3 else 0     # multi-label: up to num_class candidates per prediction
-            if most <= cap:
-                break
-            cap = ((most + 3) // 4) * 4
-        return self._run_nms(cand, ncand, B, cap)
+    # candidate rule of this evaluator (eval_yolox.py:206-231): pre-filter on obj * max(cls) >= conf, class confidence >= cls
+    # threshold (inclusive, unlike the v5 evaluator); hyp['mutil_label']: one candidate per (prediction, class) (:218-221).
+    # numba_nms (eval_yolox.py:201-259), bbox_iou (:177-199) and do_nms are inherited: the reference's YOLOX evaluator has no
+    # do_nms of its own — here it is the v5 method over THIS candidate rule
+    _FILTER_MODES = (1, 3)

@@ -108,7 +108,14 @@ class ConvBnAct(_Block):
         return super().forward(x)
 
     def forward_fuse(self, x):
-        raise NotImplementedError("forward_fuse: inference already folds BN into the conv epilogue on the HIP path")
+        """utils/layer_tools.py:93-94: `act(conv(x))` of a module whose conv is the biased result of fuse_conv_bn and whose `bn` was
+        deleted (detect_yolov5.py:110-116).  Runs the inference program: the bias rides in the conv epilogue where the folded
+        BatchNorm normally sits (engine.bn_of)."""
+        if hasattr(self, 'bn'):
+            raise RuntimeError("forward_fuse: fuse first (m.conv = fuse_conv_bn(m.conv, m.bn); delattr(m, 'bn')), as detect_yolov5.py:110-116 does")
+        if self.training or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("forward_fuse is an inference path: call .eval() and freeze the fused parameters (fuse_conv_bn returns them frozen)")
+        return ConvBnAct.forward(self, x)
 
     def _emit(self, b, name, segs, dst=None, res=None):
         (out,) = b.cba(name + "cba" if name == "" else name, [self], segs, dsts=[dst] if dst is not None else None, res=res)
