@@ -114,7 +114,11 @@ typedef struct yh_conv_desc {
                            * profiles/r04_step_experiments.txt k);
                            * 12 the 80 -> 160 channel tap kernel (conv_c80_kernel: 3x3 / s1 or s2 / p1 forward with exactly 80 input and 160
                            * output channels, inference epilogue into one destination, no residual: 256 pixels x 160 channels per
-                           * workgroup, one tap per stage — no padding of N or K; YOLOv5x's stage-1 downsampling layer) */
+                           * workgroup, one tap per stage — no padding of N or K; YOLOv5x's stage-1 downsampling layer);
+                           * 13 the training pointwise kernel (conv_pt_kernel: 1x1 / s1 / p0, forward or data gradient, 128 or 256 input
+                           * channels in one segment or in two equal halves (either may be upsampled), one destination; plain /
+                           * statistics / generic / fused-reduction epilogues: 32-pixel tiles whole in LDS through a four-deep ring with
+                           * counted waits, the 128 x C weight tile resident, no k loop over memory) */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
      * contributions already in out0 are added first and the sums are taken over the rounded total):

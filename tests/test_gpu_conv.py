@@ -476,6 +476,8 @@ def _expect_family(d, algo):
         assert "conv_h80_kernel" in kn, kn
     if algo == 12:
         assert "conv_c80_kernel" in kn, kn
+    if algo == 13:
+        assert "conv_pt_kernel" in kn, kn
 
 
 @pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])
@@ -1115,3 +1117,132 @@ def test_conv_input_beyond_two_gib_stays_on_the_lds_dma_kernel(dev, case):
             xs[0] = xs[0].repeat_interleave(2, 1).repeat_interleave(2, 2)
         ref = F.conv2d(_nchw(torch.cat(xs, -1)), w, None, stride=s, padding=p).permute(0, 2, 3, 1)
     _close(out[i:i + 1], ref, 1e-2, 4e-2)
+
+
+PT_CASES = [
+    # B, H, W, C0, C1, ups0, ups1, N: conv_pt_kernel (algo 13) — 1x1 layers of the training step with 128 / 256 input channels
+    (2, 20, 20, 128, 0, 0, 0, 128),       # bottleneck conv_bn_act_1 (40 x 40 class), 800 pixels = 25 tiles
+    (2, 16, 16, 256, 0, 0, 0, 256),       # C3 cba1 | cba2 of stage 3: two output-channel groups
+    (3, 13, 17, 128, 0, 0, 0, 64),        # odd pixel count (663: a ragged last tile), fewer channels than a group
+    (1, 24, 40, 64, 64, 0, 0, 128),       # cba3 of stage 2: concat of two 64-channel halves
+    (2, 16, 24, 128, 128, 0, 0, 256),     # cba3 of stage 3
+    (2, 16, 16, 128, 128, 1, 0, 128),     # neck join: the first half through the nearest-2x upsample
+    (1, 20, 12, 64, 64, 0, 1, 192),       # ... the second half; N = 1.5 groups
+    (1, 40, 40, 256, 0, 0, 0, 255),       # Detect: 255 outputs (row pitch 256), bias
+    (4, 40, 40, 128, 0, 0, 0, 128),       # 6 400 pixels: more tiles than one round of workgroups (persistent blocks walk several tiles)
+]
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,ups0,ups1,N", PT_CASES)
+def test_conv_pointwise_training_kernel(dev, B, H, W, C0, C1, ups0, ups1, N):
+    """conv_pt_kernel (algo 13): forward plain / with the BatchNorm partial sums / with bias, data-gradient form accumulating and with
+    the fused BatchNorm-backward reduction (plain and as the last of several writers), inputs and outputs as channel slices of
+    wider NaN-filled buffers — against fp32 torch"""
+    import ctypes as C
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import lib
+    g = torch.Generator().manual_seed(300 + N + C0)
+    M = B * H * W
+    nan = float("nan")
+    segs, parts = [], []
+    for si, (Cs, ups) in enumerate(((C0, ups0), (C1, ups1))):
+        if Cs == 0:
+            continue
+        buf = torch.full((B, H >> ups, W >> ups, Cs + 16), nan, dtype=torch.bfloat16, device=dev)
+        buf[..., 8:8 + Cs] = _nhwc(B, H >> ups, W >> ups, Cs, dev, 310 + si)
+        segs.append(hipk.Slice(buf, 8, Cs, ups=ups))
+        x = _nchw(buf[..., 8:8 + Cs])
+        parts.append(F.interpolate(x, scale_factor=2, mode="nearest") if ups else x)
+    xin = torch.cat(parts, 1)
+    Ct = C0 + C1
+    w = (torch.randn(N, Ct, 1, 1, generator=g) / Ct ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    ref = F.conv2d(xin, w).permute(0, 2, 3, 1)
+    ldo = ((N + 7) // 8) * 8 + 16
+    Nr = ((N + 7) // 8) * 8
+
+    def desc(out, **kw):
+        d = hipk.conv_desc(segs, hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, N, hipk.Slice(out, 8, Nr), **kw)
+        d.algo = 13
+        return d
+    # (1) plain store
+    out = torch.full((B, H, W, ldo), 5.0, dtype=torch.bfloat16, device=dev)
+    d = desc(out)
+    assert f"conv_pt_kernel<{C0}, {C1}, 0>" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out[..., 8:8 + N], ref, 8e-3, 2e-2)
+    assert (out[..., :8] == 5.0).all() and (out[..., 8 + Nr:] == 5.0).all()
+    # (2) BatchNorm partial sums of the stored values (slab rows = pixel slots of the grid; NaN-filled: every row must be written)
+    out.fill_(5.0)
+    rows = hipk.conv_stat_blocks(d)
+    assert rows > 0 and rows % 8 == 0
+    stats = torch.full((rows, 2, wp.shape[0]), nan, device=dev)
+    d.stats = stats.data_ptr()
+    assert f"conv_pt_kernel<{C0}, {C1}, 1>" in _kname(d) and hipk.conv_stat_blocks(d) == rows
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out[..., 8:8 + N], ref, 8e-3, 2e-2)
+    o = out[..., 8:8 + N].float().reshape(-1, N).double()
+    assert not torch.isnan(stats).any()
+    assert ((stats[:, 0, :N].double().sum(0) - o.sum(0)).abs() <= 1e-3 + 1e-5 * o.abs().sum(0)).all()
+    assert ((stats[:, 1, :N].double().sum(0) - (o ** 2).sum(0)).abs() <= 1e-3 + 1e-5 * (o ** 2).sum(0)).all()
+    assert (stats[:, :, N:] == 0).all()
+    # (3) bias (Detect) / accumulate onto an existing tensor (generic epilogue)
+    bias = torch.randn(N, generator=g).to(dev)
+    acc0 = torch.full((B, H, W, ldo), 5.0, dtype=torch.bfloat16, device=dev)
+    acc0[..., 8:8 + N] = _nhwc(B, H, W, N, dev, 320)
+    acc = acc0.clone()
+    d3 = desc(acc, bias=bias, accumulate=1)
+    assert f"conv_pt_kernel<{C0}, {C1}, 2>" in _kname(d3)
+    hipk.conv_launch(d3)
+    torch.cuda.synchronize()
+    _close(acc[..., 8:8 + N], (ref + bias).to(torch.bfloat16).float() + acc0[..., 8:8 + N].float(), 1e-2, 4e-2)
+    assert (acc[..., :8] == 5.0).all() and (acc[..., 8 + Nr:] == 5.0).all()
+    if N % 8 or C1 or ups0 or ups1:
+        return
+    # (4) the data-gradient form of a 1x1 layer IS this GEMM (gy [M][Ct] x W^T): fused BatchNorm-backward reduction, plain store and
+    # as the last writer of a gradient with earlier contributions
+    z = _nhwc(B, H, W, N, dev, 330)
+    ws = torch.cat([torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)]).to(dev)
+    for accumulate in (0, 1):
+        gx0 = _nhwc(B, H, W, N, dev, 340)
+        gx = gx0.clone()
+        d4 = hipk.conv_desc(segs, hipk.YH_CONV_DGRAD, B, H, W, H, W, 1, 1, 0, wp, N, hipk.full(gx), accumulate=accumulate)
+        d4.algo = 13
+        rows = lib().yh_conv_bnr_rows(C.byref(d4))
+        assert rows > 0
+        slab = torch.full((rows, 2, N), nan, device=dev)
+        d4.bnr_z, d4.bnr_ldz, d4.bnr_C, d4.bnr_ws, d4.bnr_part = z.data_ptr(), N, N, ws.data_ptr(), slab.data_ptr()
+        assert lib().yh_conv_bnr_rows(C.byref(d4)) == rows and f"conv_pt_kernel<{C0}, {C1}, 3>" in _kname(d4)
+        hipk.conv_launch(d4)
+        torch.cuda.synchronize()
+        want = ref.to(torch.bfloat16).float() + gx0.float() if accumulate else ref
+        _close(gx, want, 1e-2, 4e-2)
+        gq = gx.float().reshape(-1, N).double()
+        zz = z.float().reshape(-1, N).double()
+        a = zz * ws[:N].double() + ws[N:].double()
+        sg = torch.sigmoid(a)
+        dz = gq * (sg * (1 + a * (1 - sg)))
+        assert not torch.isnan(slab).any()
+        got = slab.double().sum(0)
+        assert torch.allclose(got[0], dz.sum(0), rtol=2e-3, atol=2e-3 * dz.abs().sum(0).max().item())
+        assert torch.allclose(got[1], (dz * zz).sum(0), rtol=2e-3, atol=2e-3 * (dz * zz).abs().sum(0).max().item())
+
+
+def test_conv_pointwise_training_kernel_eligibility(dev):
+    """shapes the kernel does not take fall back to the library default (algo 13 ignored)"""
+    from yoloseries_amd import hipk
+    for (C0, C1, k, N) in [(64, 0, 1, 64), (512, 0, 1, 256), (128, 64, 1, 128), (128, 0, 3, 128), (96, 0, 1, 96)]:
+        B, H, W = 1, 8, 8
+        segs = [hipk.full(_nhwc(B, H, W, C0, dev, 1))] + ([hipk.full(_nhwc(B, H, W, C1, dev, 2))] if C1 else [])
+        w = torch.randn(N, C0 + C1, k, k, device=dev)
+        wp = hipk.pack_weight_fwd(w)
+        out = torch.zeros(B, H, W, N, dtype=torch.bfloat16, device=dev)
+        d = hipk.conv_desc(segs, hipk.YH_CONV_FWD, B, H, W, H, W, k, 1, k // 2, wp, N, hipk.full(out))
+        d.algo = 13
+        assert "conv_pt_kernel" not in _kname(d), _kname(d)
+        hipk.conv_launch(d)
+        torch.cuda.synchronize()
+        xin = torch.cat([_nchw(sg.buf) for sg in segs], 1)
+        _close(out, F.conv2d(xin, w.to(torch.bfloat16).float(), padding=k // 2).permute(0, 2, 3, 1), 1e-2, 4e-2)

@@ -103,6 +103,10 @@ int yh_c80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name
 int yh_pw_rows(const yh_conv_desc* d);                  // grid rows; 0 = not eligible
 int yh_pw_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
 
+// conv_pt.hip: the pointwise (1x1) kernel of the TRAINING step (128 / 256 input channels; all four epilogues) behind yh_conv_igemm (algo 13)
+int yh_pt_rows(const yh_conv_desc* d);                  // pixel slots of the grid (== statistics / fused-reduction slab rows); 0 = not eligible
+int yh_pt_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_len);
+
 // conv_wgp.hip: the patch form of the weight gradient behind yh_conv_wgrad (tile_k 40)
 int yh_wgp_ok(const yh_wgrad_desc* d);
 int yh_wgp_run(const yh_wgrad_desc* d, yh_stream stream);

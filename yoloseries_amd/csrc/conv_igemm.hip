@@ -2493,6 +2493,7 @@ static bool conv_desc_plannable(const yh_conv_desc* d) {
 extern "C" int yh_conv_stat_blocks(const yh_conv_desc* d) {
     if (!conv_desc_plannable(d)) return 0;
     if (d->algo == 8) { const int r8 = yh_p3_rows(d); if (r8 > 0) return r8; }
+    if (d->algo == 13) { const int r13 = yh_pt_rows(d); if (r13 > 0) return r13; }
     int gx, gy, bn;
     conv_grid(d, &gx, &gy, &bn);
     return gx;
@@ -2532,13 +2533,14 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
     }
     long M = (long)d->B * d->Ho * d->Wo;
     YH_CHECK_ARG(M < (1L << 31) - BM, "yh_conv_igemm: too many output pixels");
-    if (d->algo >= 7 && d->algo <= 12) {      // stride-2 data-gradient kernel (conv_dg2.hip) / 3x3 patch kernel (conv_p3.hip) / 80-channel halo kernel (conv_h80.hip) /
+    if (d->algo >= 7 && d->algo <= 13) {      // stride-2 data-gradient kernel (conv_dg2.hip) / 3x3 patch kernel (conv_p3.hip) / 80-channel halo kernel (conv_h80.hip) /
                                               // pointwise kernel (conv_pw.hip) where eligible, else the library default
         if (d->algo == 7 && yh_dg2_rows(d) > 0) return yh_dg2_run(d, stream, name_out, name_len);
         if (d->algo == 8 && yh_p3_rows(d) > 0) return yh_p3_run(d, stream, name_out, name_len);
         if (d->algo == 9 && yh_h80_rows(d) > 0) return yh_h80_run(d, stream, name_out, name_len);
         if (d->algo == 10 && yh_pw_rows(d) > 0) return yh_pw_run(d, stream, name_out, name_len);
         if (d->algo == 12 && yh_c80_rows(d) > 0) return yh_c80_run(d, stream, name_out, name_len);
+        if (d->algo == 13 && yh_pt_rows(d) > 0) return yh_pt_run(d, stream, name_out, name_len);
         yh_conv_desc d0 = *d;
         d0.algo = 0;
         return conv_run(&d0, stream, name_out, name_len);
@@ -2792,8 +2794,8 @@ extern "C" int yh_conv_bnr_rows(const yh_conv_desc* d)
     if (!conv_desc_plannable(d) || d->mode != YH_CONV_DGRAD || d->nseg != 1 || d->seg[0].C % 8 || d->seg[0].ups || d->N % 8) return 0;
     if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N || d->stats) return 0;
     if (conv_dbg_mask() & 16) return 0;
-    if (d->algo == 7 || d->algo == 8) {
-        const int r7 = d->algo == 7 ? yh_dg2_rows(d) : yh_p3_rows(d);
+    if (d->algo == 7 || d->algo == 8 || d->algo == 13) {
+        const int r7 = d->algo == 7 ? yh_dg2_rows(d) : (d->algo == 8 ? yh_p3_rows(d) : yh_pt_rows(d));
         if (r7 > 0) return r7;
         yh_conv_desc d0 = *d;
         d0.algo = 0;

@@ -150,7 +150,8 @@ _WGRAD_TK64 = {
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
 KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad10", "wgrad8"
 KEY_CONV_C80 = "conv10"        # inference 3x3 layers with 80 -> 160 channels: conv_c80_kernel (algo 12) joined their candidates in round 4
-TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_CONV_C80, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
+KEY_CONV_PT = "conv11"         # training 1x1 layers with 128 / 256 input channels: conv_pt_kernel (algo 13) joined their candidates in round 5
+TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_CONV_C80, KEY_CONV_PT, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
 # YH_SKIP_ALGOS=<n>[,<n>]: leave these kernel families (yh_conv_desc.algo) out of the per-layer timing — A/B runs of a new family on
 # one box (use a YH_TUNE_CACHE of its own and YH_TUNE_DEFAULTS=0 for the layers concerned)
@@ -602,7 +603,9 @@ class Program:
             return
         small3 = d.KH == 3 and d.stride == 1 and d.nseg == 1 and d.seg[0].C <= 128 and d.N <= 128 and kind != 'eval'
         c80 = kind == 'eval' and d.KH == 3 and d.nseg == 1 and d.seg[0].C == 80 and d.N == 160
-        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else ((KEY_CONV_C80 if c80 else KEY_CONV_EVAL) if kind == 'eval' else KEY_CONV))}:{kind}:" + ",".join(str(int(v)) for v in (
+        ctot = d.seg[0].C + (d.seg[1].C if d.nseg > 1 else 0)
+        pt = kind != 'eval' and d.KH == 1 and d.stride == 1 and ctot in (128, 256) and (d.nseg == 1 or d.seg[0].C == d.seg[1].C)
+        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else ((KEY_CONV_C80 if c80 else KEY_CONV_EVAL) if kind == 'eval' else (KEY_CONV_PT if pt else KEY_CONV)))}:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
             int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), 0))
@@ -628,13 +631,14 @@ class Program:
                 cands.append((1, tk, cap))
         d.tile_k = d.grid_cap = 0
         if os.environ.get("YH_CONV_V3", "1") != "0":
-            for algo in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12):
+            for algo in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13):
                 if str(algo) in SKIP_ALGOS:
                     continue
                 d.algo = algo
                 kn = self._kernel_name(d)
                 if ("conv_v3" in kn and algo < 5) or ("conv_halo_kernel" in kn and algo == 5) or ("conv_halo160" in kn and algo == 6) or \
-                        ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8) or ("conv_h80" in kn and algo == 9) or ("conv_pw" in kn and algo == 10) or ("conv_c80" in kn and algo == 12):
+                        ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8) or ("conv_h80" in kn and algo == 9) or ("conv_pw" in kn and algo == 10) or ("conv_c80" in kn and algo == 12) or \
+                        ("conv_pt" in kn and algo == 13):
                     cands.append((algo, 0, 0))
                     if algo < 5 and kn.endswith(", true>") and all(d.seg[i].C % 32 == 0 for i in range(d.nseg)):
                         cands.append((algo, 32, 0))    # ragged last channel block: 32-channel steps instead of 64 + tail
@@ -1401,7 +1405,7 @@ class Program:
             if fn is L.yh_bn_bwd_finalize:
                 coef_ptr = cmd[1][7]
                 out.append(('pair', [cmd, (L.yh_fill_u32, (coef_ptr, 0, 2 * cmd[1][2]), cmd[2], ('yh_fill_u32', 0, 0.0))], cmd[2], ('sync', 0, 0.0)))
-            elif fn is L.yh_bn_bwd_finalize_parts or fn is L.yh_bn_bwd_finalize_parts_split:
+            elif fn is L.yh_bn_bwd_finalize_parts:
                 parts, nparts = cmd[1][0], cmd[1][1]
                 fills = [(L.yh_fill_u32, (parts[i].coef, 0, 2 * int(parts[i].C)), cmd[2], ('yh_fill_u32', 0, 0.0)) for i in range(nparts)]
                 out.append(('pair', [cmd] + fills, cmd[2], ('sync', 0, 0.0)))
