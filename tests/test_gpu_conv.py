@@ -1130,6 +1130,8 @@ PT_CASES = [
     (1, 20, 12, 64, 64, 0, 1, 192),       # ... the second half; N = 1.5 groups
     (1, 40, 40, 256, 0, 0, 0, 255),       # Detect: 255 outputs (row pitch 256), bias
     (4, 40, 40, 128, 0, 0, 0, 128),       # 6 400 pixels: more tiles than one round of workgroups (persistent blocks walk several tiles)
+    (2, 20, 20, 512, 0, 0, 0, 256),       # 512 channels (stage 4 / YOLOv5l stage 3): the weight slice of a wave is 128 registers
+    (1, 20, 24, 256, 256, 1, 0, 512),     # YOLOv5l neck join: 256 upsampled + 256, four output-channel groups
 ]
 
 
@@ -1199,7 +1201,7 @@ def test_conv_pointwise_training_kernel(dev, B, H, W, C0, C1, ups0, ups1, N):
     torch.cuda.synchronize()
     _close(acc[..., 8:8 + N], (ref + bias).to(torch.bfloat16).float() + acc0[..., 8:8 + N].float(), 1e-2, 4e-2)
     assert (acc[..., :8] == 5.0).all() and (acc[..., 8 + Nr:] == 5.0).all()
-    if N % 8 or C1 or ups0 or ups1:
+    if N % 8 or C1 or ups0 or ups1 or C0 + C1 == 512:          # (512 channels: no fused-reduction form, csrc/conv_pt.hip pt_plan)
         return
     # (4) the data-gradient form of a 1x1 layer IS this GEMM (gy [M][Ct] x W^T): fused BatchNorm-backward reduction, plain store and
     # as the last writer of a gradient with earlier contributions
@@ -1233,7 +1235,7 @@ def test_conv_pointwise_training_kernel(dev, B, H, W, C0, C1, ups0, ups1, N):
 def test_conv_pointwise_training_kernel_eligibility(dev):
     """shapes the kernel does not take fall back to the library default (algo 13 ignored)"""
     from yoloseries_amd import hipk
-    for (C0, C1, k, N) in [(64, 0, 1, 64), (512, 0, 1, 256), (128, 64, 1, 128), (128, 0, 3, 128), (96, 0, 1, 96)]:
+    for (C0, C1, k, N) in [(64, 0, 1, 64), (1024, 0, 1, 256), (128, 64, 1, 128), (128, 0, 3, 128), (96, 0, 1, 96)]:
         B, H, W = 1, 8, 8
         segs = [hipk.full(_nhwc(B, H, W, C0, dev, 1))] + ([hipk.full(_nhwc(B, H, W, C1, dev, 2))] if C1 else [])
         w = torch.randn(N, C0 + C1, k, k, device=dev)

@@ -378,3 +378,18 @@ def test_fuse_conv_bn_matches_reference_fixture():
     assert not fused.weight.requires_grad and not fused.bias.requires_grad
     np.testing.assert_allclose(fused.weight.numpy(), g["fuse_w"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(fused.bias.numpy(), g["fuse_b"], rtol=1e-6, atol=1e-7)
+
+
+def test_conv_pt_kernel_has_no_register_spills(tmp_path):
+    """conv_pt_kernel counts its vector-memory instructions by hand (s_waitcnt vmcnt(N) with compile-time N): a register spill would add
+    scratch loads / stores the counts do not know about.  Every instantiation the library launches must compile without scratch."""
+    import subprocess
+    src = os.path.join(ROOT, "yoloseries_amd", "csrc", "conv_pt.hip")
+    out = tmp_path / "pt.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "--cuda-device-only", "-S",
+                    "-o", str(out), src], check=True, capture_output=True)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN\S*conv_pt_kernel\S*):.*?; ScratchSize: (\d+)", text, flags=re.S | re.M)
+    assert len(kernels) >= 20, len(kernels)
+    bad = [(k, n) for k, n in kernels if int(n) != 0]
+    assert not bad, bad

@@ -22,11 +22,12 @@ B = int(os.environ.get("BP_BATCH", 64))
 if which == "v5s":
     shapes = [("s2_cba12", 80, (128, 0, 0), 128), ("s2_cba3", 80, (64, 64, 0), 128), ("s3_b_cba1", 40, (128, 0, 0), 128),
               ("s3_cba12", 40, (256, 0, 0), 256), ("s3_cba3", 40, (128, 128, 0), 256), ("h2_conv", 40, (256, 0, 0), 128),
-              ("h2_cba12", 80, (128, 128, 1), 128), ("h3_cba12", 40, (128, 128, 0), 256), ("det_s", 80, (128, 0, 0), 255), ("det_m", 40, (256, 0, 0), 255)]
+              ("h2_cba12", 80, (128, 128, 1), 128), ("h3_cba12", 40, (128, 128, 0), 256), ("det_s", 80, (128, 0, 0), 255), ("det_m", 40, (256, 0, 0), 255),
+              ("s4_cba12", 20, (512, 0, 0), 512), ("s4_cba3", 20, (256, 256, 0), 512), ("h1_conv", 20, (512, 0, 0), 256), ("h1_cba12", 40, (256, 256, 1), 256)]
 else:
     shapes = [("s1_cba12", 160, (128, 0, 0), 128), ("s1_cba3", 160, (64, 64, 0), 128), ("s2_b_cba1", 80, (128, 0, 0), 128),
               ("s2_cba12", 80, (256, 0, 0), 256), ("s2_cba3", 80, (128, 128, 0), 256), ("s3_b_cba1", 40, (256, 0, 0), 256),
-              ("h2_conv", 40, (512, 0, 0), 256), ("h2_cba12", 80, (256, 256, 1), 256)]
+              ("s3_cba12", 40, (512, 0, 0), 512), ("s3_cba3", 40, (256, 256, 0), 512), ("h2_conv", 40, (512, 0, 0), 256), ("h2_cba12", 80, (256, 256, 1), 256)]
 if os.environ.get("BP_ONLY"):
     shapes = [sh for sh in shapes if sh[0] in os.environ["BP_ONLY"].split(",")]
 

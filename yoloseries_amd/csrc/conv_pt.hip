@@ -68,7 +68,7 @@ struct PtCfg {
     static constexpr int STAGE_BYTES = PT_TM * PT_CP * 2;                     // the output tile
     static constexpr int CONST_OFF = STAGE_OFF + 2 * STAGE_BYTES;
     static constexpr int SMEM = CONST_OFF + 3 * PT_TN * 4;
-    static_assert((CS0 == 128 || CS0 == 256 || CS0 == 64) && (CS1 == 0 || CS1 == CS0) && (CT == 128 || CT == 256), "segment widths");
+    static_assert((CS0 == 64 || CS0 == 128 || CS0 == 256 || CS0 == 512) && (CS1 == 0 || CS1 == CS0) && (CT == 128 || CT == 256 || CT == 512), "segment widths");
     static_assert(NI0 >= 1 && (CS1 == 0 || NI1 >= 1) && SMEM <= 160 * 1024, "LDS budget");
     static_assert(PT_NT * 16 * 4 <= PT_NBUF * A_BYTES, "the final reduction of EPI 3 runs in the pixel buffers");
 };
@@ -175,19 +175,15 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
     // ---- loader geometry.  Instruction h of this wave (h < NI0: segment 0, else segment 1) is instruction ii = h' * 4 + wave of its
     // sub-image and fills the rows ii * RPI .. + RPI of it; the lane writes chunk position q of its row and fetches the source chunk
     // q ^ swz(row)
-    int lrow[NAI];
-    unsigned lch[NAI];
-#pragma unroll
-    for (int h = 0; h < NAI; ++h) {
+    auto geom = [&](int h, int& row, unsigned& ch) {
         const bool s1 = h >= NI0;
         const int cs = s1 ? CS1 : CS0;
         const int chr = cs / 8, rpi = 1024 / (cs * 2);
         const int ii = (s1 ? h - NI0 : h) * 4 + wave;
-        const int row = ii * rpi + lane / chr;
+        row = ii * rpi + lane / chr;
         const int q = lane % chr;
-        lrow[h] = row;
-        lch[h] = (unsigned)((q ^ (s1 ? pt_swz<CS1 ? CS1 : 128>(row) : pt_swz<CS0>(row))) * 16);
-    }
+        ch = (unsigned)((q ^ (s1 ? pt_swz<CS1 ? CS1 : 128>(row) : pt_swz<CS0>(row))) * 16);
+    };
     const int HoWo = p.Ho * p.Wo;
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
     // A tile is addressed as (per-lane offset inside the tile, fixed for the whole launch) + (a SCALAR offset of the tile): a handful of
@@ -195,7 +191,11 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
     // per-lane path (rows past M carry an out-of-range offset: the transfer writes zeros).
     unsigned lvo[NAI];
 #pragma unroll
-    for (int h = 0; h < NAI; ++h) lvo[h] = (unsigned)lrow[h] * (unsigned)((h >= NI0 ? p.ld1 : p.ld0) * 2) + lch[h];
+    for (int h = 0; h < NAI; ++h) {
+        int row; unsigned ch;
+        geom(h, row, ch);
+        lvo[h] = (unsigned)row * (unsigned)((h >= NI0 ? p.ld1 : p.ld0) * 2) + ch;
+    }
     const bool anyups = (p.ups0 | p.ups1) != 0;
     auto issue_A = [&](int tl, int buf) {
         const int m0 = tl * TM;
@@ -212,13 +212,15 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
 #pragma unroll
         for (int h = 0; h < NAI; ++h) {
             const bool s1 = h >= NI0;
-            const int m = m0 + lrow[h];
+            int row; unsigned ch;
+            geom(h, row, ch);
+            const int m = m0 + row;
             unsigned px = (unsigned)m;
             if (s1 ? p.ups1 : p.ups0) {         // nearest-2x upsample: the source pixel of (img, y, x) is (img, y / 2, x / 2) of the half-size map
                 const int im = m / HoWo, rem = m - im * HoWo, yy = rem / p.Wo, xx = rem - yy * p.Wo;
                 px = (unsigned)((im * (p.Ho >> 1) + (yy >> 1)) * (p.Wo >> 1) + (xx >> 1));
             }
-            const unsigned v = (px * (unsigned)((s1 ? p.ld1 : p.ld0) * 2) + lch[h]) | ((m < p.M && m >= 0) ? 0u : PT_OOB);
+            const unsigned v = (px * (unsigned)((s1 ? p.ld1 : p.ld0) * 2) + ch) | ((m < p.M && m >= 0) ? 0u : PT_OOB);
             pt_dma(base + (s1 ? SUB0 : 0) + ((s1 ? h - NI0 : h) * 4 + wave) * 1024, v, s1 ? rs1 : rs0, 0u);
         }
     };
@@ -281,13 +283,9 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
     // fragment read offsets: row lane & 31 of the sub-image, chunk 2 ks + (lane >> 5)
     const int f0 = pt_swz<CS0>(r31), f1 = pt_swz<CS1 ? CS1 : 128>(r31);
 
-    float bs_[8], bq_[8], zs[8], zh[8];              // per-thread partial sums of its 8 channels (EPI 1: sum, sum of squares; EPI 3: dz, dz * z)
+    float bs_[8], bq_[8];                            // per-thread partial sums of its 8 channels (EPI 1: sum, sum of squares; EPI 3: dz, dz * z)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bs_[e] = 0.f; bq_[e] = 0.f; zs[e] = 1.f; zh[e] = 0.f; }
-    if (EPI == 3) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { zs[e] = sConst[cch * 8 + e]; zh[e] = sConst[TN + cch * 8 + e]; }
-    }
+    for (int e = 0; e < 8; ++e) { bs_[e] = 0.f; bq_[e] = 0.f; }
 
     // The two groups run the same rounds half a round apart: every s_barrier is barrier 1 (the tile's transfers have landed for the
     // whole group; its staging area is free) of one group and barrier 2 (its staging area is written; its pixel buffer is consumed)
@@ -311,21 +309,26 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
         if (k < K) {
             const unsigned char* const abase = smem + pb * A_BYTES;
             // ---- 32 pixels x this wave's 32 output channels: every pixel fragment of the tile is requested ahead of the MFMAs
-            bf16x8_t af[NKS];
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const bool s1 = ks * 16 >= CS0;
-                const int cl = 2 * (s1 ? ks - CS0 / 16 : ks) + kq;
-                af[ks] = s1 ? pt_lds16(abase + SUB0 + r31 * (CS1 * 2) + ((cl ^ f1) * 16))
-                            : pt_lds16(abase + r31 * (CS0 * 2) + ((cl ^ f0) * 16));
-            }
             // operands swapped (D = W X^T): a lane holds ONE pixel (lane & 31) and the channels (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
             // of the wave's 32 — four runs of four consecutive channels: 8-byte staging stores
             f32x16_t acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            constexpr int KC = NKS > 16 ? 8 : NKS;           // fragments in registers at a time (512 channels: the weight slice alone is 128 registers)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[ks]), af[ks], acc, 0, 0, 0);
+            for (int k0 = 0; k0 < NKS; k0 += KC) {
+                bf16x8_t af[KC];
+#pragma unroll
+                for (int u = 0; u < KC; ++u) {
+                    const int ks = k0 + u;
+                    const bool s1 = ks * 16 >= CS0;
+                    const int cl = 2 * (s1 ? ks - CS0 / 16 : ks) + kq;
+                    af[u] = s1 ? pt_lds16(abase + SUB0 + r31 * (CS1 * 2) + ((cl ^ f1) * 16))
+                               : pt_lds16(abase + r31 * (CS0 * 2) + ((cl ^ f0) * 16));
+                }
+#pragma unroll
+                for (int u = 0; u < KC; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[k0 + u]), af[u], acc, 0, 0, 0);
+            }
             PT_STAMP(3);
             // ---- accumulators -> staging (bf16, row-major [pixel][channel])
 #pragma unroll
@@ -397,6 +400,11 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
                 }
                 unpack8(pt_u4(cur.a[it]), z);
                 if (oo != PT_OOB) {
+                    float zs[8], zh[8];                  // scale | shift of the producer's BatchNorm for this thread's 8 channels
+                    *reinterpret_cast<float4*>(zs) = *reinterpret_cast<const float4*>(sConst + cch * 8);
+                    *reinterpret_cast<float4*>(zs + 4) = *reinterpret_cast<const float4*>(sConst + cch * 8 + 4);
+                    *reinterpret_cast<float4*>(zh) = *reinterpret_cast<const float4*>(sConst + TN + cch * 8);
+                    *reinterpret_cast<float4*>(zh + 4) = *reinterpret_cast<const float4*>(sConst + TN + cch * 8 + 4);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float a = z[e] * zs[e] + zh[e];
@@ -447,7 +455,7 @@ bool pt_plan(const yh_conv_desc* d, PtPlan* pl)
     if (!d || (d->nseg != 1 && d->nseg != 2)) return false;
     if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->Ho != d->Hi || d->Wo != d->Wi) return false;
     const int C0 = d->seg[0].C, C1 = d->nseg == 2 ? d->seg[1].C : 0;
-    if (!((C1 == 0 && (C0 == 128 || C0 == 256)) || (C1 == C0 && (C0 == 64 || C0 == 128)))) return false;
+    if (!((C1 == 0 && (C0 == 128 || C0 == 256 || C0 == 512)) || (C1 == C0 && (C0 == 64 || C0 == 128 || C0 == 256)))) return false;
     if (d->N <= 0 || d->Npad < d->N || d->Npad % 128) return false;
     const unsigned long M = (unsigned long)d->B * d->Ho * d->Wo;
     if (M == 0 || M >= (1ul << 31) - (1ul << 20)) return false;          // (tile indices of the ring's dummies past the end stay in range)
@@ -472,6 +480,7 @@ bool pt_plan(const yh_conv_desc* d, PtPlan* pl)
     const bool generic_na = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res;
     const bool generic = generic_na || d->accumulate;
     if (generic && d->stats) return false;
+    if (Ct == 512 && d->bnr_part) return false;          // 512 channels: the weight slice alone is 128 registers — the fused-reduction epilogue does not fit beside it
     if (d->bnr_part && (generic_na || d->stats || d->mode != YH_CONV_DGRAD || d->N % 8 || !d->bnr_z || !d->bnr_ws || d->bnr_C < d->N || d->bnr_ldz % 8)) return false;
     const unsigned long Nr = (unsigned long)(d->N + 7) / 8 * 8;
     const unsigned long n0r = Nr;
@@ -540,23 +549,24 @@ int yh_pt_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
 #define YH_LAUNCH_PT(A_, B_)                                                                                            \
     do {                                                                                                                \
         constexpr int sm = PtCfg<A_, B_>::SMEM;                                                                          \
+        constexpr int E3 = (A_) + (B_) == 512 ? 0 : 3;      /* not instantiated for 512 channels (pt_plan) */            \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
             (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
             (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
             (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, E3>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
             attr_set = true;                                                                                            \
         }                                                                                                               \
         switch (pl.epi) {                                                                                               \
         case 0: conv_pt_kernel<A_, B_, 0><<<grid, blk, sm, st>>>(pl.k); break;                                          \
         case 1: conv_pt_kernel<A_, B_, 1><<<grid, blk, sm, st>>>(pl.k); break;                                          \
         case 2: conv_pt_kernel<A_, B_, 2><<<grid, blk, sm, st>>>(pl.k); break;                                          \
-        default: conv_pt_kernel<A_, B_, 3><<<grid, blk, sm, st>>>(pl.k); break;                                         \
+        default: conv_pt_kernel<A_, B_, E3><<<grid, blk, sm, st>>>(pl.k); break;                                        \
         }                                                                                                               \
     } while (0)
-    if (pl.cs1 == 0) { if (pl.cs0 == 128) YH_LAUNCH_PT(128, 0); else YH_LAUNCH_PT(256, 0); }
-    else             { if (pl.cs0 == 64) YH_LAUNCH_PT(64, 64); else YH_LAUNCH_PT(128, 128); }
+    if (pl.cs1 == 0) { if (pl.cs0 == 128) YH_LAUNCH_PT(128, 0); else if (pl.cs0 == 256) YH_LAUNCH_PT(256, 0); else YH_LAUNCH_PT(512, 0); }
+    else             { if (pl.cs0 == 64) YH_LAUNCH_PT(64, 64); else if (pl.cs0 == 128) YH_LAUNCH_PT(128, 128); else YH_LAUNCH_PT(256, 256); }
 #undef YH_LAUNCH_PT
     YH_CHECK_LAUNCH("yh_conv_igemm(pt)");
     return YH_OK;

@@ -150,7 +150,7 @@ _WGRAD_TK64 = {
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
 KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad10", "wgrad8"
 KEY_CONV_C80 = "conv10"        # inference 3x3 layers with 80 -> 160 channels: conv_c80_kernel (algo 12) joined their candidates in round 4
-KEY_CONV_PT = "conv11"         # training 1x1 layers with 128 / 256 input channels: conv_pt_kernel (algo 13) joined their candidates in round 5
+KEY_CONV_PT = "conv11"         # training 1x1 layers with 128 / 256 / 512 input channels: conv_pt_kernel (algo 13) joined their candidates in round 5
 TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_CONV_C80, KEY_CONV_PT, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
 # YH_SKIP_ALGOS=<n>[,<n>]: leave these kernel families (yh_conv_desc.algo) out of the per-layer timing — A/B runs of a new family on
@@ -604,7 +604,7 @@ class Program:
         small3 = d.KH == 3 and d.stride == 1 and d.nseg == 1 and d.seg[0].C <= 128 and d.N <= 128 and kind != 'eval'
         c80 = kind == 'eval' and d.KH == 3 and d.nseg == 1 and d.seg[0].C == 80 and d.N == 160
         ctot = d.seg[0].C + (d.seg[1].C if d.nseg > 1 else 0)
-        pt = kind != 'eval' and d.KH == 1 and d.stride == 1 and ctot in (128, 256) and (d.nseg == 1 or d.seg[0].C == d.seg[1].C)
+        pt = kind != 'eval' and d.KH == 1 and d.stride == 1 and ctot in (128, 256, 512) and (d.nseg == 1 or d.seg[0].C == d.seg[1].C)
         key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else ((KEY_CONV_C80 if c80 else KEY_CONV_EVAL) if kind == 'eval' else (KEY_CONV_PT if pt else KEY_CONV)))}:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
