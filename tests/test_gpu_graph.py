@@ -82,7 +82,7 @@ def test_graph_replay_matches_eager_deterministic(dev, monkeypatch):
     stem backward are not eligible with a workspace) — so that eager and replay can be held to 1e-3 over ALL steps: a replay that
     drops or mis-orders a kernel (a stale learning-rate scalar, a missed EMA update) cannot hide inside the atomics' drift"""
     from yoloseries_amd import engine
-    monkeypatch.setattr(engine, "WG_WS_BYTES", 256 << 20)
+    monkeypatch.setattr(engine.flags, "WG_WS_BYTES", 256 << 20)
     runs = {}
     for graph in (False, True):
         model, opt, ema, stepper = _setup(dev, graph)

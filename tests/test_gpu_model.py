@@ -471,8 +471,8 @@ def test_program_executor_matches_per_launch_calls(dev):
     x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(5)).to(dev)
     t = torch.from_numpy(synth_targets(2, 128, 80, 8, seed=6, min_boxes=4)).to(dev)
     for use in (False, True):
-        old = engine.USE_EXEC
-        engine.USE_EXEC = use
+        old = engine.flags.USE_EXEC
+        engine.flags.USE_EXEC = use
         try:
             torch.manual_seed(0)
             m = models.YOLOV5Small(3, 80).to(dev).train()
@@ -484,7 +484,7 @@ def test_program_executor_matches_per_launch_calls(dev):
                 ev = [o.float().cpu() for o in m(x)]
             res[use] = ([o.detach().float().cpu() for o in outs], g.cpu(), ev)
         finally:
-            engine.USE_EXEC = old
+            engine.flags.USE_EXEC = old
     (o0, g0, e0), (o1, g1, e1) = res[False], res[True]
     for a, b in zip(o0 + e0, o1 + e1):
         assert torch.equal(a, b)

@@ -24,12 +24,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _table():
     with open(os.path.join(ROOT, "yoloseries_amd", "tune_defaults.json")) as f:
         t = json.load(f)
-    from yoloseries_amd.engine import KEY_CONV, KEY_CONV_P3, KEY_CONV_S2D, KEY_WGRAD
+    from yoloseries_amd.engine import KEY_CONV, KEY_CONV_P3, KEY_CONV_PT, KEY_CONV_S2D, KEY_WGRAD
     conv, wgrad = [], []
     for k, v in sorted(t.items()):
         parts = k.split(":")
         f = [int(x) for x in parts[-1].split(",")]
-        if parts[0] in (KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3) and parts[1] in ("fwd", "dgrad"):
+        if parts[0] in (KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_PT) and parts[1] in ("fwd", "dgrad"):
             conv.append((k, f, v))
         elif parts[0] in (KEY_WGRAD, KEY_WGRAD + "f"):
             wgrad.append((k, f, v, parts[0].endswith("f")))

@@ -331,7 +331,8 @@ def test_shipped_tuning_table_matches_the_engine_key_versions():
     changes: its keys carry the same version prefixes the engine asks for"""
     import json
     from yoloseries_amd import engine
-    path = os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), "tune_defaults.json")
+    path = engine.TUNE_DEFAULTS_PATH
+    assert os.path.dirname(path) == os.path.dirname(os.path.dirname(os.path.abspath(engine.__file__)))
     table = json.load(open(path))
     prefixes = {k.split(":", 1)[0] for k in table}
     assert prefixes <= engine.TUNE_KEY_VERSIONS and engine.KEY_CONV in prefixes, (prefixes, engine.TUNE_KEY_VERSIONS)
