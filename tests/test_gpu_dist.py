@@ -98,6 +98,25 @@ def _worker(rank, world, port, q, size="small"):
     dist.destroy_process_group()
 
 
+def _collect(q, procs, n, limit=400):
+    """the workers' results; a worker that died without reporting fails the test at once (a crashed rank would otherwise leave its
+    peer in a collective and this process waiting on the queue)"""
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=5))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > limit:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError(f"worker exit codes {dead or 'none'} after {time.time() - t0:.0f} s without a result")
+    return out
+
+
 @pytest.mark.parametrize("size", ["small", "large"])
 def test_overlapped_bucket_allreduce_two_ranks(dev, size):
     """`large`: BASELINE config #4's model (YOLOv5l, models/normal/yolov5l.py:16-44: 177 MiB of fp32 gradients in the packed arena,
@@ -108,7 +127,7 @@ def test_overlapped_bucket_allreduce_two_ranks(dev, size):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, size)) for r in range(2)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=600) for _ in range(2)]
+    out = _collect(q, procs, 2)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

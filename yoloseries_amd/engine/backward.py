@@ -10,7 +10,7 @@ from .. import hipk
 from .._lib import (BnPart, ConvDesc, YH_BN_MAX_PARTS, WgradDesc, YH_CMD_EVENT_RECORD, YH_CMD_STREAM_WAIT, YH_ACT_NONE, YH_CONV_DGRAD,
                     YoloHipError, check)
 from ..hipk import Slice
-from . import flags
+from . import flags as _flags
 from .executor import CompiledCmds
 from .flags import ABL_SKIP, FUSE_STEM_BWD, HEAD_COLSUM_SIDE, MERGE_PARTS, NGZ
 from .graph import ConvOp, PoolOp, Ref, _rup, plan_grad_buckets, sppf_chain
@@ -84,7 +84,7 @@ class BackwardMixin:
         self.wgrad_tuned = {}
         # workspace of the weight gradients' split-M partial tiles (plain stores + a deterministic reduce instead of fp32
         # atomics; YH_WGRAD_PARTIAL=0: atomics).  One buffer serves every launch: they all run on one stream, in order.
-        self.wg_ws = torch.empty(flags.WG_WS_BYTES // 4, dtype=torch.float32, device=self.dev) if flags.WG_WS_BYTES > 0 else None
+        self.wg_ws = torch.empty(_flags.WG_WS_BYTES // 4, dtype=torch.float32, device=self.dev) if _flags.WG_WS_BYTES > 0 else None
 
         writes_seen = {}
 
@@ -482,7 +482,7 @@ class BackwardMixin:
             self._ev_gz.record(main)               # packed arena zeroed, head gradients in place
             side.wait_event(self._ev_gz)
             pending = [False] * NGZ
-        if prof is None and flags.USE_EXEC:
+        if prof is None and _flags.USE_EXEC:
             # replay the compiled command array (yh_exec): one call per bucket segment instead of one ctypes call per launch
             key = ('bwd', two, bucket_hook is not None, frozen)
             comp = self._compiled.get(key)

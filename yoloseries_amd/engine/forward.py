@@ -7,7 +7,7 @@ import torch
 
 from .. import hipk
 from .._lib import BnFoldItem, BnPart, ConvDesc, YH_BN_MAX_PARTS, YH_ACT_NONE, YH_ACT_SILU, YH_CONV_FWD, YoloHipError, check
-from . import flags
+from . import flags as _flags
 from .executor import CompiledCmds
 from .flags import ABL_SKIP, MERGE_PARTS
 from .graph import ConvOp, PoolOp, Ref, sppf_chain
@@ -248,7 +248,7 @@ class ForwardMixin:
     def _run(self, cmds):
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         prof = self.profile
-        if prof is None and flags.USE_EXEC:
+        if prof is None and _flags.USE_EXEC:
             key = 'train' if cmds is self.cmd_train else ('frozen' if cmds is getattr(self, "cmd_frozen", None) else 'eval')
             cc = self._compiled.get(key)
             if cc is None or cc.source is not cmds:
