@@ -55,26 +55,21 @@ def _host_threads():
     return max(1, min(cores, 16))
 
 
-def cpu_baseline(budget_s=14.0, batch=4, img=640):
-    """torch-CPU / NumPy fp32 port (oracle/) of the same path on a bounded sample at B=4 (BASELINE config #1), both legs of
-    BASELINE.md section 4: (fwd + loss + bwd + SGD) and (decode + candidate filter + class-aware NMS on the synthetic NMS stress
-    heads), each 1 warm-up + the median of up to 5 runs inside the time budget."""
-    from oracle import postproc as opp
+def _cpu_train_leg(batch, img, budget_s, max_steps):
+    """(median seconds per step, steps timed) of the torch-CPU fp32 oracle's train step at `batch`: 1 warm-up, then up to `max_steps`
+    timed steps inside the budget (at least one)"""
     from oracle.v5loss import V5LossOracle
     from oracle.v5net import V5NetOracle
     from yoloseries_amd import models
-    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_nms_heads, synth_targets
-    cores = _host_threads()
-    torch.set_num_threads(cores)
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
     torch.manual_seed(0)
     net = V5NetOracle(models.YOLOV5Small(3, 80).state_dict(), train=True)
-    hyp = make_hyp("cpu", img, batch)
-    lossf = V5LossOracle(COCO_ANCHORS, hyp)
+    lossf = V5LossOracle(COCO_ANCHORS, make_hyp("cpu", img, batch))
     x = torch.rand(batch, 3, img, img, generator=torch.Generator().manual_seed(0))
     t = synth_targets(batch, img, 80, 20, seed=1)
     times = []
     t_begin = time.time()
-    for it in range(6):
+    for it in range(max_steps + 1):
         t0 = time.time()
         out = lossf(net(x), t)
         out["tot_loss"].backward()
@@ -83,8 +78,22 @@ def cpu_baseline(budget_s=14.0, batch=4, img=640):
         if it >= 1 and time.time() - t_begin > budget_s:
             break
     steady = times[1:] if len(times) > 1 else times
+    return float(np.median(steady)), len(steady)
+
+
+def cpu_baseline(budget_s=14.0, batch=64, img=640):
+    """torch-CPU / NumPy fp32 port (oracle/) of the same path on a bounded sample, both legs of BASELINE.md section 4:
+    (fwd + loss + bwd + SGD) at the judged batch (64; 1 warm-up + up to 3 steps) and at BASELINE config #1's batch 4 (`batch4`), and
+    (decode + candidate filter + class-aware NMS on the synthetic NMS stress heads), each the median of its timed runs."""
+    from oracle import postproc as opp
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_nms_heads
+    cores = _host_threads()
+    torch.set_num_threads(cores)
+    sec4, nst4 = _cpu_train_leg(4, img, 0.25 * budget_s, 5)
+    sec, nst = _cpu_train_leg(batch, img, 0.75 * budget_s, 2) if batch != 4 else (sec4, nst4)
+    nbatch = 4
     # decode + filter + NMS (NumPy fp32, one thread: the reference's evaluator is a per-image Python / numba loop)
-    heads = synth_nms_heads(batch, img, 80, 3, seed=2, wh_shift=1.2)
+    heads = synth_nms_heads(nbatch, img, 80, 3, seed=2, wh_shift=1.2)
     ntimes, kept = [], 0
     t_begin = time.time()
     for it in range(6):
@@ -93,15 +102,16 @@ def cpu_baseline(budget_s=14.0, batch=4, img=640):
         res = opp.postprocess_v5(dec, 0.001, 0.001, 0.65)
         ntimes.append(time.time() - t0)
         kept = sum(0 if r is None else len(r) for r in res)
-        if it >= 1 and time.time() - t_begin > 0.6 * budget_s:
+        if it >= 1 and time.time() - t_begin > 0.4 * budget_s:
             break
     nsteady = ntimes[1:] if len(ntimes) > 1 else ntimes
-    return {"value": round(batch / float(np.median(steady)), 3), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"median of {len(steady)} train steps (fwd+loss+bwd+SGD) of YOLOv5s at batch {batch}, {img}x{img}, "
+    return {"value": round(batch / sec, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"median of {nst} train steps (fwd+loss+bwd+SGD) of YOLOv5s at batch {batch}, {img}x{img}, "
             f"torch-CPU fp32 oracle, after 1 warm-up",
-            "decode_nms": {"value": round(batch / float(np.median(nsteady)), 3), "unit": "images/sec", "cores": 1,
-                           "sample": f"median of {len(nsteady)} runs of decode + filter(conf 0.001) + class-aware NMS(0.65) on {batch} synthetic "
-                           f"head sets at {img}x{img} (~1 % of the anchors are candidates, {kept // batch} boxes kept per image), NumPy fp32 oracle"}}
+            "batch4": {"value": round(4 / sec4, 3), "unit": "images/sec", "sample": f"the same step at batch 4 (BASELINE configs[0]), median of {nst4}"},
+            "decode_nms": {"value": round(nbatch / float(np.median(nsteady)), 3), "unit": "images/sec", "cores": 1,
+                           "sample": f"median of {len(nsteady)} runs of decode + filter(conf 0.001) + class-aware NMS(0.65) on {nbatch} synthetic "
+                           f"head sets at {img}x{img} (~1 % of the anchors are candidates, {kept // nbatch} boxes kept per image), NumPy fp32 oracle"}}
 
 
 def parse_args(argv=None):
@@ -234,8 +244,12 @@ def worker(args):
 
         # a random-init net yields ~no detections: NMS throughput is measured on synthetic head tensors:
         # ~1 % of the anchors pass conf 0.001, 50 clusters of overlapping boxes per image
-        nb = min(B, 16)
-        heads = [torch.from_numpy(h).to(dev) for h in synth_nms_heads(nb, img, 80, 3, seed=2, wh_shift=1.2)]
+        # all B images of the batch, synthesised 16 at a time with a seed per chunk to bound the host memory
+        nb = B
+        heads = None
+        for c0 in range(0, nb, 16):
+            part = [torch.from_numpy(h).to(dev) for h in synth_nms_heads(min(16, nb - c0), img, 80, 3, seed=2 + c0 // 16, wh_shift=1.2)]
+            heads = part if heads is None else [torch.cat([a, b]) for a, b in zip(heads, part)]
         for _ in range(2):
             res = ev._nms_from_heads(heads)
         torch.cuda.synchronize()

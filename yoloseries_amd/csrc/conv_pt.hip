@@ -1,27 +1,33 @@
 // Pointwise (1x1 / stride 1 / pad 0) convolution for the TRAINING step: C3's cba1|cba2 / cba3, the bottlenecks' conv_bn_act_1, the
-// neck's 1x1 layers and the Detect convs (utils/layer_tools.py:90-114, 152-169, 454-470), forward and data gradient, with 128 or 256
-// input channels in all — one segment, or a virtual concat of two equal halves (C3's cba3, the neck joins) either of which may be
-// read through the nearest-2x upsample.  These layers move 64-128 FLOP per byte: they are bound by HBM, and on the implicit-GEMM ring
-// kernels (conv_v3_kernel: 128 x 128 tiles, two ring stages for the 2..4 k-steps of a tile, the ring drained at every tile's
-// epilogue) the 40 x 40 / 20 x 20 layers ran at 2.0-3.3 TB/s — a tile paid its pipeline fill and its epilogue with nothing of its
-// own in flight.  Here, as in conv_pw_kernel (inference, YOLOv5x widths), the reduction is so short that a tile has
-// NO k loop over memory:
+// neck's 1x1 layers and the Detect convs (utils/layer_tools.py:90-114, 152-169, 454-470), forward and data gradient, with 128, 256
+// or 512 input channels in all — one segment, or a virtual concat of two equal halves (C3's cba3, the neck joins) either of which
+// may be read through the nearest-2x upsample.  These layers move 64-128 FLOP per byte: they are bound by HBM, and on the
+// implicit-GEMM ring kernels (conv_v3_kernel: 128 x 128 tiles, two ring stages for the 2..4 k-steps of a tile, the ring drained at
+// every tile's epilogue) the 40 x 40 / 20 x 20 layers ran at 2.0-3.3 TB/s — a tile paid its pipeline fill and its epilogue with
+// nothing of its own in flight.  Here, as in conv_pw_kernel (inference, YOLOv5x widths), the reduction is so short
+// that a tile has NO k loop over memory:
 //
-//   * a block (4 waves) walks 32-pixel tiles for its output-channel group (128 channels); a tile's input channels arrive by LDS-DMA
-//     as ONE piece per segment (unpadded rows; 16-byte chunks XOR-swizzled with the pixel row on the SOURCE side of the DMA and
-//     again on the fragment reads: conflict-free ds_read_b128) into a ring of FOUR tile buffers: while tile i is multiplied and
-//     stored, tiles i+1 and i+2 are in flight and i+3 is requested as soon as i's buffer is free (48 KiB in flight per CU at 256
-//     channels).  The waits are counted: s_waitcnt vmcnt(N) with N = the vector-memory instructions issued behind the tile's
-//     transfers — every store of the epilogue is a buffer instruction with a range-checked offset, issued unconditionally, so N is
-//     a compile-time constant — and the ring never drains;
-//   * the 128 x C weight tile of the block's output-channel group stays in LDS for the whole launch;
-//   * wave w multiplies the 32 pixels by its 32 output channels: C / 16 v_mfma_f32_32x32x16_bf16, one A and one B fragment read
-//     each, no barrier inside the tile;
-//   * the accumulator layout (a lane holds ONE output channel, 16 pixels) makes the per-channel BatchNorm partial sums (EPI 1)
-//     two registers per lane for the whole launch; the tile is staged through the consumed pixel buffer and leaves as whole
-//     16-byte chunks; the fused BatchNorm-backward reduction of a data gradient (EPI 3: z requested before the staging barrier)
-//     and the generic epilogue (EPI 2: bias / folded BN / SiLU / residual / accumulate / split destination) work on those chunks.
-// The output-channel groups of a pixel tile are consecutive workgroups of one XCD (ids b, b + 8, ...): they walk the same tiles at
+//   * a workgroup is TWO groups of four waves that walk the 32-pixel tiles of the workgroup's slot alternately (group g: tiles g,
+//     g + 2, ...), half a round apart: every s_barrier of the workgroup is the "tile arrived" barrier of one group and the "staging
+//     written" barrier of the other, so while one group multiplies the other stores and requests — the matrix and the memory halves
+//     of a round overlap inside one CU without a second workgroup's LDS;
+//   * a tile's input channels arrive by LDS-DMA as one piece per segment (unpadded rows; 16-byte chunks XOR-swizzled with the pixel
+//     row on the SOURCE side of the DMA and again on the fragment reads: conflict-free ds_read_b128) into a ring of FOUR tile buffers,
+//     two per group: while a group's tile i is multiplied its tile i + 2 is in flight and i + 4 is requested as soon as i's buffer
+//     is free.  The waits are counted: s_waitcnt vmcnt(N) with N = the vector-memory instructions issued behind the tile's
+//     transfers — every load and store of the loop is a buffer instruction with a range-checked offset, issued unconditionally
+//     (inline asm: see pt_dma below), so N is a compile-time constant — and the ring never drains;
+//   * the 128 x C weight slice of the workgroup's output-channel group lives in REGISTERS for the whole launch (C / 16 fragments of
+//     four registers per wave: 32 output channels x C); the operands of the MFMA are swapped — the weights are the A operand, the
+//     pixels the B operand — so a lane of the accumulator holds FOUR CONSECUTIVE OUTPUT CHANNELS of one pixel: the tile goes to the
+//     group's staging area as 8-byte stores and leaves as whole 16-byte chunks;
+//   * wave w multiplies the 32 pixels by its 32 output channels: C / 16 v_mfma_f32_32x32x16_bf16 with one fragment read each;
+//   * epilogues work on the staged chunks: EPI 1 the per-channel BatchNorm partial sums (two registers per thread for the whole
+//     launch, reduced once at the end into the slab row of the workgroup), EPI 2 bias / folded BN / SiLU / residual / accumulate,
+//     EPI 3 the fused BatchNorm-backward reduction of a data gradient (z and the residual are requested one tile ahead, in two
+//     register sets used alternately — the loop is unrolled by two so no set is ever copied).  EPI 3 is not built for 512 input
+//     channels (128 weight registers + the operand sets spill; pt_plan declines, tests/test_host_logic.py checks the binary).
+// The output-channel groups of a pixel slot are consecutive workgroups of one XCD (ids b, b + 8, ...): they walk the same tiles at
 // the same time and the second read of a tile comes from that XCD's L2.  Chosen per layer by the engine's timing
 // (yh_conv_desc.algo 13); the same arithmetic as the ring kernels (fp32 accumulation over the channels in the same order).
 #include "common.h"
