@@ -32,10 +32,13 @@ S=$(find $OUT/b64 -name "*kernel_stats.csv" | head -1); cp "$S" profiles/${TAG}_
 T=$(find $OUT/b64 -name "*kernel_trace.csv" | head -1)
 python3 tools/step_trace.py "$T" > profiles/${TAG}_step_trace.txt
 python3 tools/step_overlap.py "$T" > profiles/${TAG}_step_overlap.txt
+python3 tools/foreign_launches.py "$T" > profiles/${TAG}_foreign_launches.txt
 rm -rf $OUT/serial $OUT/b64
 pmc_passes "" train:small:64:640 3
 python3 bench.py --steps 20 --warmup 5 > profiles/${TAG}_bench_default.json 2> $OUT/bench_default.err
 YH_BENCH_LAYERS=400 python3 bench.py --steps 10 --no-cpu-baseline > /dev/null 2> profiles/${TAG}_layers_v5s_train_b64.txt
+# the data-parallel path's own cost at one GPU: communicator, bucket hooks and finishers kept for a single rank (utils/dist.py)
+YH_FORCE_DP=1 python3 bench.py --steps 20 --warmup 5 $NOB > profiles/${TAG}_bench_force_dp.json 2> $OUT/bench_force_dp.err
 if [ -z "$QUICK" ]; then
   # the other BASELINE configs at one GPU: YOLOXs train, YOLOv5l train, YOLOv5x inference at 1280^2 (batch 128, per-layer table)
   python3 bench.py --workload yolox --steps 3 --warmup 2 $NOB > /dev/null 2>&1
@@ -44,6 +47,8 @@ if [ -z "$QUICK" ]; then
   python3 bench.py --model large --steps 3 --warmup 2 $NOB > /dev/null 2>&1
   pmc_passes _train_large_64_640 train:large:64:640 2 --model large
   python3 bench.py --model large --no-cpu-baseline > profiles/${TAG}_bench_v5l.json 2> $OUT/bench_v5l.err
+  YH_FORCE_DP=1 python3 bench.py --model large $NOB > profiles/${TAG}_bench_v5l_force_dp.json 2> $OUT/bench_v5l_force_dp.err
+  YH_BENCH_LAYERS=600 python3 bench.py --model large --steps 6 --warmup 3 --no-cpu-baseline > /dev/null 2> profiles/${TAG}_layers_v5l_train_b64.txt
   python3 bench.py --workload infer --model xlarge --img 1280 --batch 128 --steps 2 --warmup 1 $NOB > /dev/null 2>&1
   pmc_passes _infer_xlarge_128_1280 infer:xlarge:128:1280 1 --workload infer --model xlarge --img 1280 --batch 128
   YH_BENCH_LAYERS=200 python3 bench.py --workload infer --model xlarge --img 1280 --batch 128 --steps 6 --warmup 3 --no-cpu-baseline > profiles/${TAG}_bench_infer_v5x_1280_b128.json 2> profiles/${TAG}_layers_infer_v5x_1280_b128.txt
