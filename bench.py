@@ -205,10 +205,13 @@ def worker(args):
         os.environ.setdefault("WORLD_SIZE", "1")
     own_group = (world > 1 or force_dp) and not dist.is_initialized()     # launch() initialises the group of self-started ranks
     if own_group:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        from yoloseries_amd.utils.dist import quiet_stdout
+        with quiet_stdout():               # RCCL prints its version banner on stdout: stdout is for the one JSON line
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+                dist.barrier()
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
 
     from yoloseries_amd import models
     from yoloseries_amd.loss import YOLOV5Loss
@@ -311,7 +314,7 @@ def worker(args):
         lr = 0.000625 * B                       # basic_lr_per_img x per-rank batch (train_yolov5.py:184)
         opt = FlatSGD(model, lr=lr, momentum=0.937, weight_decay=1e-4, nesterov=True)
         ema = ExponentialMovingAverageModel(model)
-        dp = DataParallelGrads(model) if (world > 1 or force_dp) else None
+        dp = DataParallelGrads(model, overlap=os.environ.get("YH_DP_OVERLAP", "1") != "0") if (world > 1 or force_dp) else None
 
         def step():
             # YOLOXLoss converts the target boxes to xywh IN PLACE like the reference (loss/yolox_loss.py:70-75): every step

@@ -10,6 +10,7 @@ from .. import hipk
 from .._lib import (BnPart, ConvDesc, YH_BN_MAX_PARTS, WgradDesc, YH_CMD_EVENT_RECORD, YH_CMD_STREAM_WAIT, YH_ACT_NONE, YH_CONV_DGRAD,
                     YoloHipError, check)
 from ..hipk import Slice
+from ..streams import side_stream
 from . import flags as _flags
 from .executor import CompiledCmds
 from .flags import ABL_SKIP, FUSE_STEM_BWD, HEAD_COLSUM_SIDE, MERGE_PARTS, NGZ
@@ -471,8 +472,8 @@ class BackwardMixin:
         two = self.two_streams
         if two:
             if getattr(self, "_side", None) is None:
-                # YH_SIDE_PRIO: priority of the weight-gradient stream (ROCm: -1 high, 0 normal, 1 low)
-                self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("YH_SIDE_PRIO", "0")))
+                # a stream PROBED to run beside the compute stream (streams.py: a fresh stream may share its hardware queue)
+                self._side = side_stream(self.dev)
                 self._ev_gz = torch.cuda.Event()
                 self._ev_wg = [torch.cuda.Event() for _ in range(NGZ)]
                 self._ev_all = torch.cuda.Event()

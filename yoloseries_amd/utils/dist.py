@@ -15,11 +15,29 @@ import torch
 import torch.distributed as dist
 
 __all__ = ['get_rank', 'get_world_size', 'get_local_rank', 'get_local_size', 'get_num_devices', 'synchronize', 'is_main_process',
-           'all_reduce_norm', 'DataParallelGrads', 'allreduce_flat_mean']
+           'all_reduce_norm', 'DataParallelGrads', 'allreduce_flat_mean', 'quiet_stdout']
 
 
 def _on():
     return dist.is_available() and dist.is_initialized()
+
+
+class quiet_stdout:
+    """`with quiet_stdout():` sends file descriptor 1 to stderr for the duration: RCCL prints a version banner on stdout when a
+    process's first communicator comes up, and a driver that prints a machine-readable line (bench.py) wants stdout to itself"""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *a):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
 
 
 def get_world_size():
@@ -140,6 +158,8 @@ class DataParallelGrads:
         single = world == 1 and not os.environ.get("YH_FORCE_DP")
         if (not self.enabled) or (self._local_acc is not None) or single or part.numel() == 0:
             return None
+        if part.is_cuda and dist.get_backend(self.group) == "nccl" and os.environ.get("YH_DP_COMM_STREAM", "1") != "0":
+            return self._bucket_on_comm_stream(part)
         if self.bucket_dtype is not None and self.bucket_dtype != part.dtype:
             low = part.to(self.bucket_dtype)
             work = dist.all_reduce(low, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -157,6 +177,32 @@ class DataParallelGrads:
         def finish():
             work.wait()
             part.div_(world)
+        return finish
+
+    def _bucket_on_comm_stream(self, part):
+        """RCCL: the bucket's all-reduce (ncclAvg) issued as a SYNCHRONOUS collective on a stream of our own choosing — torch runs
+        a collective with async_op=False on the current stream — instead of ProcessGroupNCCL's internal stream.  Which hardware
+        queue that internal stream shares is not ours to pick: on the compute stream's queue the collective, which waits for
+        the weight-gradient stream, would stall the whole backward behind it (yoloseries_amd/streams.py).  `comm_stream` is probed to
+        run beside both; it waits for the caller's stream (the engine calls from the weight-gradient stream's context, which
+        it has ordered behind the compute stream), the finisher makes the compute stream wait for the exchange."""
+        from ..streams import comm_stream
+        dev = part.device
+        comm = comm_stream(dev)
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        comm.wait_event(ready)
+        with torch.cuda.stream(comm):
+            if self.bucket_dtype is not None and self.bucket_dtype != part.dtype:
+                low = part.to(self.bucket_dtype)
+                dist.all_reduce(low, op=dist.ReduceOp.AVG, group=self.group)
+                part.copy_(low)
+            else:
+                dist.all_reduce(part, op=dist.ReduceOp.AVG, group=self.group)
+            done.record(comm)
+
+        def finish():
+            torch.cuda.current_stream(dev).wait_event(done)
         return finish
 
     def reset(self):

@@ -53,7 +53,8 @@ def _distributed_worker(local_rank, main_func, world_size, num_gpus_per_machine,
         torch.cuda.set_device(local_rank)
         kwargs["device_id"] = torch.device("cuda", local_rank)
     try:
-        dist.init_process_group(backend=backend, init_method=dist_url, world_size=world_size, rank=global_rank, timeout=timeout, **kwargs)
+        with comm.quiet_stdout():          # RCCL's version banner goes to stderr
+            dist.init_process_group(backend=backend, init_method=dist_url, world_size=world_size, rank=global_rank, timeout=timeout, **kwargs)
     except Exception as err:
         print(f"Process group URL: {dist_url} {err}")
         raise
