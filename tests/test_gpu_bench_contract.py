@@ -28,3 +28,16 @@ def test_bench_json_contract(dev):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in ro, k
     assert ro["bound"] in ("hbm", "mfma") and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+
+
+def test_bench_stdout_is_one_json_line_on_the_data_parallel_path(dev):
+    """YH_FORCE_DP=1: the RCCL communicator comes up (its version banner must not land on stdout) and the step runs with the bucket
+    hooks; the line stays the only thing on stdout — what the driver parses for N > 1"""
+    env = dict(os.environ, YH_FORCE_DP="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
+                        "--no-roofline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:500]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0

@@ -193,6 +193,13 @@ def _rccl_worker(q):
     all_reduce_norm(model)
     torch.cuda.synchronize()
     res["backend"] = dist.get_backend()
+    # the streams the step ran on really run beside the compute stream although a process group exists (yoloseries_amd/streams.py)
+    from yoloseries_amd import streams
+    big, tiny = torch.empty(1 << 30, dtype=torch.uint8, device=dev), torch.empty(256, dtype=torch.uint8, device=dev)
+    main, side, comm = torch.cuda.default_stream(dev), streams.side_stream(dev), streams.comm_stream(dev)
+    res["side_beside_main"] = streams._runs_beside(side, [main], big, tiny)
+    res["comm_beside_both"] = streams._runs_beside(comm, [main, side], big, tiny)
+    res["main_beside_main"] = streams._runs_beside(main, [main], big, tiny)          # the probe itself: a stream is not beside itself
     q.put(res)
     dist.destroy_process_group()
 
@@ -211,6 +218,7 @@ def test_rccl_single_rank_bucket_path(dev):
     assert res["err_fp32"] < 1e-3, res                       # sum over one rank / 1 == the plain gradient (atomics noise only)
     assert res["err_bf16"] < 2e-2, res                       # bf16 buckets: one rounding of every element
     assert res["nosync_fp32"] and res["nosync_bf16"], res
+    assert res["side_beside_main"] and res["comm_beside_both"] and not res["main_beside_main"], res
 
 
 def test_bench_gpus2_real_step_two_ranks_one_gpu(dev):
