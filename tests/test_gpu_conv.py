@@ -963,7 +963,8 @@ def test_conv_stem_kernel(dev, Cout, B, H, W):
     assert (obuf[..., :8] == 3.0).all() and (obuf[..., 8 + Cout:] == 3.0).all()
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 24, 24, 160, 160), (1, 40, 40, 128, 320), (3, 17, 33, 96, 160), (1, 20, 20, 64, 480)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 24, 24, 160, 160), (1, 40, 40, 128, 320), (3, 17, 33, 96, 160), (1, 20, 20, 64, 480),
+                                              (2, 80, 80, 320, 320), (1, 160, 160, 160, 160), (2, 32, 48, 32 + 64 * 3, 160), (1, 16, 16, 64, 160)])
 def test_conv_halo160_kernel(dev, B, H, W, Cin, Cout):
     """the 160-wide halo kernel (algo 6: 3x3 / s1, N a multiple of 160, 16x16x32 MFMA tiles of 64 pixels x 80 channels; inference
     epilogues): plain store, folded BatchNorm + SiLU + residual with a split destination, and the data gradient — whole and

@@ -1273,7 +1273,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
 // by the patch row index on the source side of the DMA (as in conv_v3); the patch of the next channel block is prefetched
 // in six parts behind the taps 0..5 of the current one; weight tiles go through a 3-stage ring.  MFMA rows that are not an
 // output pixel of the tile (ragged tiles) read a zero line, so their accumulators are exact zeros for the statistics.
-struct HaloGeom { int TH, TW, PW, NP, tiles_x, tiles_y, gx, gy, rowmajor; };
+struct HaloGeom { int TH, TW, PW, NP, tiles_x, tiles_y, gx, gy, rowmajor;
+                  unsigned long long* stamps; };   // diagnostics (yh_halo_set_stamps): [workgroup][wave][8] cycle sums of the workgroup's 2nd tile
+
+static unsigned long long* g_halo_stamps = nullptr;
 
 // Block -> (persistent tile slot bx, output-channel tile by) of the halo kernels, launched as ONE row of gx * gy workgroups.  The gy
 // channel tiles of a pixel tile stage the SAME input patch: as grid rows (by = blockIdx.y) their linear ids are gx apart, i.e. they
@@ -1715,24 +1718,52 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const ConvK p, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifndef YH_H160_STG
+#define YH_H160_STG 3          // weight-ring stages of conv_halo160_kernel (A/B builds: -DYH_H160_STG=4 -DYH_H160_ROWS=304)
+#endif
+#ifndef YH_H160_SPLIT_ISSUE
+#define YH_H160_SPLIT_ISSUE 1
+#endif
+#ifndef YH_H160_ROWS
+#define YH_H160_ROWS 328       // rows of one patch buffer
+#endif
 // 160-wide variant of the halo kernel for the YOLOv5x widths (N = 160, 320, ...): the 128-wide tiles above compute 256
 // channels for 160.  Same structure (2-D pixel tile, patch staged once per 64-channel block and double buffered, nine taps =
 // nine k-steps, 4-stage weight ring fed by LDS-DMA), but the wave tile is 64 pixels x 80 channels on
 // v_mfma_f32_16x16x32_bf16 (4 x 5 tiles of 16 x 16, nine 16-byte fragment reads per twenty MFMAs) so that 4 x 2 waves cover
-// 256 x 160 exactly.  The 80 KB weight ring leaves 2 x 304 patch rows (conv_halo_geom with that budget: 14 x 17 ... pixel
-// tiles).  Inference epilogues only (EPI 0 plain, EPI 2 bias / folded BN + SiLU / residual / split destination): YOLOv5x is
+// 256 x 160 exactly.  A THREE-stage weight ring (60 KB) leaves 2 x 328 patch rows: the 18 x 18 patch of a 16 x 16 pixel tile fits,
+// which tiles the 160 x 160 / 80 x 80 maps of YOLOv5x at 1280^2 without a ragged edge (round 5; the four-stage ring left
+// 304 rows -> 23 x 10 tiles, 0.89 / 0.83 of the MFMA rows useful).
+// Inference epilogues only (EPI 0 plain, EPI 2 bias / folded BN + SiLU / residual / split destination): YOLOv5x is
 // not a training configuration of this build.  Operands swapped as above (D = W x X^T): a lane holds one pixel and four
 // consecutive channels per accumulator.
+struct H160True { static constexpr bool value = true; };
+struct H160False { static constexpr bool value = false; };
+typedef unsigned int h160_u32x4 __attribute__((ext_vector_type(4)));
+// a 16-byte LDS read the CALLER waits for (h160_wait_frags) before the first use
+template <int OFF> __device__ __forceinline__ h160_u32x4 h160_lds16(unsigned addr) {
+    h160_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// s_waitcnt lgkmcnt(0) tied to the nine fragment registers it makes valid: their uses cannot be scheduled ahead of it
+__device__ __forceinline__ void h160_wait_frags(h160_u32x4 (&xf)[4], h160_u32x4 (&wf)[5]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]) :: "memory");
+}
+__device__ __forceinline__ void h160_wait_frags2(h160_u32x4 (&xf)[4], h160_u32x4 (&wf)[5], f32x4_t& last) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(last) :: "memory");
+}
 template <int EPI, bool TL>
 __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, const HaloGeom hg)
 {
-    constexpr int BN = 160, BMT = 256, WN = 2, BKT = 64, STG = 4;
+    constexpr int BN = 160, BMT = 256, WN = 2, BKT = 64, STG = YH_H160_STG;
     constexpr int NWV = 8, NT = 512;
     constexpr int TMR = 4, TNC = 5;                  // 16-pixel / 16-channel tiles per wave (64 x 80)
     constexpr int ROWB = BKT * 2, CHR = 8, RPI = 8;
     // BN / RPI = 20 weight-tile DMA instructions per k-step: 3 for waves 0..3, 2 for waves 4..7
-    constexpr int NPW = 5;                           // patch DMA instructions per wave and channel block (<= 5*8*8 = 320 rows)
-    constexpr int PATCH_ROWS = 304;
+    constexpr int PATCH_ROWS = YH_H160_ROWS;          // multiple of 8: a DMA instruction writes 8 rows
+    constexpr int NPW = (PATCH_ROWS / 8 + NWV - 1) / NWV;   // patch DMA instructions per wave and channel block (one per tap step: <= 9)
+    static_assert(PATCH_ROWS % 8 == 0 && NPW <= 9 && STG >= 3 && STG <= 4, "patch parts ride on the tap steps");
     constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;   // 38912
     constexpr int BST_BYTES = BN * ROWB;             // 20480
     constexpr int ZERO_OFF = 2 * PATCH_BYTES + STG * BST_BYTES;
@@ -1743,6 +1774,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
     float* sConst = reinterpret_cast<float*>(smem + MAIN_BYTES);            // [3][BN]: bias | scale | shift
     int* sPix = reinterpret_cast<int*>(smem + MAIN_BYTES + 3 * BN * 4);     // [BMT] output pixel of each tile row, -1 = none
 
@@ -1755,7 +1787,6 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
     halo_block_map(hg, bx, by);
     const int n0 = by * BN;
     const int ncb = TL ? (p.Ctot + BKT - 1) / BKT : p.Ctot / BKT;
-    const int tailn = TL ? (p.Ctot % BKT) / 32 : BKT / 32;   // 32-channel sub-steps of the last channel block (TL: C % 32 == 0 needed)
     const int H = d.Ho, W = d.Wo;
     const int TH = hg.TH, TW = hg.TW, PW = hg.PW, NP = hg.NP;
     const int tiles_per_img = hg.tiles_x * hg.tiles_y;
@@ -1825,16 +1856,17 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
     };
 
     int tile = bx;
-    unsigned voffP[NPW], voffN[NPW];
+    unsigned voffP[NPW];             // patch offsets of the tile whose patch parts are being requested: this tile's; from its last
+                                     // channel block on, the next tile's (the current ones are dead by then)
     int slot = 0, islot = STG - 1, pb = 0;
     if (tile < ntiles) {
         patch_offsets(tile, voffP);
 #pragma unroll
         for (int part = 0; part < NPW; ++part) issue_patch_part(voffP, part, 0, 0);
         issue_W(0, 0, 0);
-        issue_W(1, 0, 1);                             // nine taps per channel block: steps 0..2 are taps 0..2 of block 0
-        issue_W(2, 0, 2);
-        if (wave < 4) { YH_VMCNT(3); } else { YH_VMCNT(2); }   // patch + the weight tiles of steps 0, 1 landed; the third stays in flight
+        issue_W(1, 0, 1);                             // nine taps per channel block: steps 0..STG-2 are taps 0.. of block 0
+        if (STG == 4) issue_W(2, 0, 2);
+        if (wave < 4) { YH_VMCNT(3); } else { YH_VMCNT(2); }   // patch + all weight tiles but the last one issued have landed
     }
     for (; tile < ntiles; tile += hg.gx) {
         const bool has_next = tile + hg.gx < ntiles;
@@ -1865,19 +1897,29 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
         int prev_group = 0;
-        for (int cblk = 0; cblk < ncb; ++cblk) {
+        h160_u32x4 xfA[TMR], wfA[TNC], xfB[TMR], wfB[TNC];
+        bool pendB = false;                           // wave-uniform: a second sub-step waits in xfB / wfB
+        const bool stamp = hg.stamps != nullptr && tile == bx + hg.gx;        // wave-uniform
+        unsigned long long tq0 = 0, tq1, tq2, s_wait = 0, s_issue = 0, s_mfma = 0, t_begin = 0;
+        if (stamp) t_begin = __builtin_amdgcn_s_memtime();
+        // one 64-channel block = nine tap steps.  TWO: the block has both 32-channel sub-steps (all but the tail block of a TL
+        // kernel, whose channel count ends in a half block) — a compile-time property of the step's code: with the pipeline
+        // state in run-time flags the compiler fenced every step's reads and MFMAs into separate regions
+        auto do_block = [&](auto two_tag, const int cblk) {
+            constexpr bool TWO = decltype(two_tag)::value;
             const bool last_blk = cblk + 1 == ncb;
-            const int ksn = (TL && last_blk) ? tailn : BKT / 32;
-            if (last_blk && has_next) patch_offsets(tile + hg.gx, voffN);
+            if (last_blk && has_next) patch_offsets(tile + hg.gx, voffP);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int kt = cblk * 9 + tap;
                 // all DMA groups except the one issued at the previous step must have landed (step 0: waited before the tile)
+                if (stamp) tq0 = __builtin_amdgcn_s_memtime();
                 if (kt > 0) YH_VMCNT_SW(prev_group);
                 __builtin_amdgcn_s_barrier();
+                if (stamp) { tq1 = __builtin_amdgcn_s_memtime(); s_wait += tq1 - tq0; }
                 prev_group = 0;
-                {
-                    // weight tile of step kt + 3 (wrapping into the next tile's stream)
+                auto issue_step = [&]() {
+                    // weight tile of step kt + STG - 1 (wrapping into the next tile's stream)
                     const int tapB = (tap + STG - 1) % 9;
                     const int cblkB = cblk + ((tap + STG - 1) >= 9 ? 1 : 0);
                     if (cblkB < ncb || has_next) {
@@ -1886,9 +1928,15 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
                     }
                     if (tap < NPW && !(YH_CONV_ABLATE & 512)) {
                         if (!last_blk) prev_group += issue_patch_part(voffP, tap, cblk + 1, pb ^ 1);
-                        else if (has_next) prev_group += issue_patch_part(voffN, tap, 0, pb ^ 1);
+                        else if (has_next) prev_group += issue_patch_part(voffP, tap, 0, pb ^ 1);
                     }
-                }
+                };
+                // The two waves of a SIMD (w and w + 4) come out of the barrier together: waves 0..3 request the step's transfers
+                // first, waves 4..7 after their first sub-step, so one of the pair issues MFMAs while the other one issues transfers
+                // (stamps: the transfers of a step cost ~390 cycles of issue during which the SIMD ran no MFMA)
+                const bool issue_first = !YH_H160_SPLIT_ISSUE || wave < 4;
+                if (issue_first) issue_step();
+                if (stamp) { tq2 = __builtin_amdgcn_s_memtime(); s_issue += tq2 - tq1; }
                 const int kh = tap / 3, kw = tap % 3;
                 int tapoff = dgrad ? (2 - kh) * PW + (2 - kw) : kh * PW + kw;            // scalar
                 asm volatile("" : "+s"(tapoff));
@@ -1900,30 +1948,64 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
                     abase[i] = inv[i] ? ZERO_OFF : pb * PATCH_BYTES + pr * ROWB;
                     afx[i] = inv[i] ? -1 : swz_f<CHR>(pr);
                 }
-#pragma unroll
-                for (int ks = 0; ks < BKT / 32; ++ks) {
-                    if (TL && ks >= ksn) continue;
-                    bf16x8_t xf[TMR], wf[TNC];
+                // Software pipeline over the sub-steps (round 5; stamps showed two exposed LDS round trips per step — both waves of a
+                // SIMD leave the barrier together and waited for their fragments at the same time): the fragments of this step's
+                // FIRST sub-step are requested, the MFMAs of the PREVIOUS step's second sub-step (fragments already in registers: its
+                // ring slot may be refilled by now) run while they arrive, then the second sub-step's fragments are requested behind
+                // the first sub-step's MFMAs and wait in registers for the next step.
+                // The fragment reads are inline asm, invisible to the compiler's s_waitcnt bookkeeping (it answered every read that
+                // crosses a loop iteration with lgkmcnt(0) right behind it); the waits are the explicit ones below, tied to the
+                // registers they make valid.
+                auto read_frags = [&](int ks, h160_u32x4 (&xf)[TMR], h160_u32x4 (&wf)[TNC]) {
+                    const unsigned wb = lds0 + (unsigned)(sbase + rdW[ks]);
+                    wf[0] = h160_lds16<0>(wb); wf[1] = h160_lds16<16 * ROWB>(wb); wf[2] = h160_lds16<32 * ROWB>(wb);
+                    wf[3] = h160_lds16<48 * ROWB>(wb); wf[4] = h160_lds16<64 * ROWB>(wb);
 #pragma unroll
                     for (int i = 0; i < TMR; ++i) {
                         const int off = afx[i] < 0 ? (kq << 4) : (((ks * 4 + kq) ^ afx[i]) << 4);
-                        xf[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + abase[i] + off));
+                        xf[i] = h160_lds16<0>(lds0 + (unsigned)(abase[i] + off));
                     }
+                };
+                auto mfma_row = [&](int i, const h160_u32x4 (&xf)[TMR], const h160_u32x4 (&wf)[TNC]) {
 #pragma unroll
                     for (int j = 0; j < TNC; ++j)
-                        wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(smem + sbase + rdW[ks] + j * (16 * ROWB)));
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j]), __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][j], 0, 0, 0);
+                };
+                read_frags(0, xfA, wfA);
+                // a pending second sub-step: inside a block the previous step's (TWO), at a block's first step what the flag says
+                if (tap == 0 ? pendB : TWO) {
 #pragma unroll
-                    for (int i = 0; i < TMR; ++i)
-#pragma unroll
-                        for (int j = 0; j < TNC; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TMR; ++i) mfma_row(i, xfB, wfB);
                 }
+                if (!issue_first) issue_step();
+                h160_wait_frags2(xfA, wfA, acc[TMR - 1][TNC - 1]);            // arrived during the MFMAs above (a tile's first step: exposed once)
+                mfma_row(0, xfA, wfA);
+                if (TWO) read_frags(1, xfB, wfB);
+#pragma unroll
+                for (int i = 1; i < TMR; ++i) mfma_row(i, xfA, wfA);
+                // the second sub-step's fragments land behind those 15 MFMAs, before the next barrier lets the slot be refilled
+                if (TWO) h160_wait_frags2(xfB, wfB, acc[TMR - 1][TNC - 1]);
+                if (tap == 8) pendB = TWO;
+                // the second sub-step's fragments have landed (behind 20 MFMAs) before the next barrier lets the slot be refilled
+                if (stamp) s_mfma += __builtin_amdgcn_s_memtime() - tq2;
                 slot = slot + 1 == STG ? 0 : slot + 1;
                 islot = islot + 1 == STG ? 0 : islot + 1;
             }
             pb ^= 1;
+        };
+        const int nfull = TL ? ncb - 1 : ncb;         // TL: the channel count ends in a half block (C % 64 == 32)
+        for (int cblk = 0; cblk < nfull; ++cblk) do_block(H160True{}, cblk);
+        if (TL) do_block(H160False{}, ncb - 1);
+        if (pendB) {
+#pragma unroll
+            for (int i = 0; i < TMR; ++i)
+#pragma unroll
+                for (int j = 0; j < TNC; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfB[j]), __builtin_bit_cast(bf16x8_t, xfB[i]), acc[i][j], 0, 0, 0);
         }
-        // the next tile's patch and first two weight tiles must have landed before its step 0 (the third stays in flight);
+        unsigned long long t_loop = 0, t_act = 0;
+        if (stamp) t_loop = __builtin_amdgcn_s_memtime();
+        // the next tile's patch and all its weight tiles issued so far but the last must have landed before its step 0;
         // the epilogue works in the patch buffer the next tile does NOT use
         if (has_next) { if (wave < 4) { YH_VMCNT(3); } else { YH_VMCNT(2); } } else { YH_VMCNT(0); }
         uint16_t* sC = reinterpret_cast<uint16_t*>(smem + (pb ^ 1) * PATCH_BYTES);
@@ -1947,6 +2029,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
                 }
             }
         }
+        if (stamp) t_act = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
         for (int ph = 0; ph < 4; ++ph) {
             YH_LDS_BARRIER();                         // previous phase's readers done (ph 0: every wave is out of the k loop)
@@ -2000,12 +2083,16 @@ __global__ __launch_bounds__(512, 1) void conv_halo160_kernel(const ConvK p, con
             }
         }
         YH_LDS_BARRIER();                             // epilogue buffer and pixel table free for the next tile
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) voffP[i] = voffN[i];
+        if (stamp && lane == 0) {
+            unsigned long long* o = hg.stamps + ((size_t)blockIdx.x * NWV + wave) * 8;
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            o[0] = s_wait; o[1] = s_issue; o[2] = s_mfma; o[3] = t_loop - t_begin; o[4] = t_act - t_loop; o[5] = t_end - t_act; o[6] = t_end - t_begin; o[7] = 1;
+        }
     }
 }
 
-constexpr size_t conv_halo160_smem_bytes() { return 2 * 304 * 128 + 4 * 160 * 128 + 128 + 3 * 160 * 4 + 256 * 4; }
+constexpr size_t conv_halo160_smem_bytes() { return 2 * YH_H160_ROWS * 128 + YH_H160_STG * 160 * 128 + 128 + 3 * 160 * 4 + 256 * 4; }
+static_assert(conv_halo160_smem_bytes() <= 160 * 1024, "LDS budget of conv_halo160_kernel");
 
 template <int BN>
 constexpr size_t conv_halo_smem_bytes() {
@@ -2016,7 +2103,7 @@ constexpr size_t conv_halo_smem_bytes() {
 // chosen to waste the fewest MFMA rows (ragged tiles and TH*TW < 256)
 bool conv_halo_geom_search(int H, int W, int max_rows, HaloGeom* g);
 // the search below is ~200 divisions: its result per map size is kept (the planner runs for every launch).
-// max_rows: patch rows one buffer holds (352 with the 64- / 128-channel weight ring, 304 next to the 160-channel one)
+// max_rows: patch rows one buffer holds (352 with the 64- / 128-channel weight ring, 324 next to the 160-channel one)
 bool conv_halo_geom(int H, int W, HaloGeom* g, int max_rows = 352)
 {
     struct Memo { int H, W, R; bool ok; HaloGeom g; };
@@ -2393,7 +2480,7 @@ bool conv_halo160_ok(const yh_conv_desc* d, HaloGeom* g)
     if (!conv_v2_ok(d)) return false;
     if ((long)d->B * d->Ho * d->Wo >= (1L << 31)) return false;
     HaloGeom gg;
-    if (!conv_halo_geom(d->Ho, d->Wo, &gg, 304)) return false;
+    if (!conv_halo_geom(d->Ho, d->Wo, &gg, YH_H160_ROWS == 328 ? 324 : YH_H160_ROWS)) return false;
     if (g) *g = gg;
     return true;
 }
@@ -2643,6 +2730,7 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         hipStream_t sth = (hipStream_t)stream;
         static const int rowmajor = [] { const char* e = getenv("YH_HALO_MAP"); return (e && atoi(e) == 0) ? 1 : 0; }();
         hgeo.gx = gx; hgeo.gy = gy; hgeo.rowmajor = (rowmajor || gy == 1) ? 1 : 0;
+        hgeo.stamps = g_halo_stamps;
         const dim3 gridh(gx * gy), blkh(512);              // one row of workgroups: halo_block_map
         const size_t sm = conv_halo160_smem_bytes();
         static bool attr_set = false;
@@ -2668,6 +2756,7 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         // statistics / data gradients) -> the XCD-major order only under the inference epilogue
         static const int rowmajor = [] { const char* e = getenv("YH_HALO_MAP"); return (e && atoi(e) == 0) ? 1 : 0; }();
         hgeo.gx = gx; hgeo.gy = gy; hgeo.rowmajor = (rowmajor || gy == 1 || epi != 2) ? 1 : 0;
+        hgeo.stamps = nullptr;
         const dim3 gridh(gx * gy), blkh(512);              // one row of workgroups: halo_block_map
 #define YH_LAUNCH_HALO(BN_, TL_)                                                                                     \
         do {                                                                                                         \
@@ -2826,6 +2915,9 @@ extern "C" int yh_conv_kernel_name(const yh_conv_desc* d, char* buf, int buflen)
     YH_CHECK_ARG(buf && buflen >= 64, "yh_conv_kernel_name: buffer too small");
     return conv_run(d, nullptr, buf, buflen);
 }
+
+/* diagnostics: a device buffer of grid x 8 x 8 uint64 that receives cycle sums of every workgroup's 2nd tile in conv_halo160_kernel (NULL: off) */
+extern "C" void yh_halo_set_stamps(void* p) { g_halo_stamps = (unsigned long long*)p; }
 
 #ifdef YH_CONV_STAMPS
 extern "C" int yh_debug_read_stamps(long long* host_out32)

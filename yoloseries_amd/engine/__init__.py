@@ -27,7 +27,7 @@ from .flags import BN_EPS_DEFAULT
 from .graph import Builder, ConvOp, ParamPack, PoolOp, Ref, TBuf, bn_of, plan_grad_buckets, sppf_chain
 from .module import HipModuleMixin
 from .program import Program
-from .tune import (KEY_CONV, KEY_CONV_C80, KEY_CONV_EVAL, KEY_CONV_P3, KEY_CONV_PT, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS, TUNE_DEFAULTS_PATH,
+from .tune import (KEY_CONV, KEY_CONV_C80, KEY_CONV_EVAL, KEY_CONV_H160, KEY_CONV_P3, KEY_CONV_PT, KEY_CONV_S2D, KEY_WGRAD, KEY_WGRAD_WS, TUNE_DEFAULTS_PATH,
                    TUNE_KEY_VERSIONS, tuning_source)
 
 __all__ = ['Builder', 'ConvOp', 'PoolOp', 'Ref', 'TBuf', 'ParamPack', 'Program', 'HipModuleMixin', 'CompiledCmds', 'bn_of', 'plan_grad_buckets',
