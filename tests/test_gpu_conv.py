@@ -1233,6 +1233,45 @@ def test_conv_pointwise_training_kernel(dev, B, H, W, C0, C1, ups0, ups1, N):
         assert torch.allclose(got[1], (dz * zz).sum(0), rtol=2e-3, atol=2e-3 * (dz * zz).abs().sum(0).max().item())
 
 
+@pytest.mark.parametrize("B,H,W,N", [(2, 20, 20, 320), (1, 17, 23, 160), (3, 40, 40, 320)])
+def test_conv_pointwise_kernel_320_channels_inference(dev, B, H, W, N):
+    """conv_pt_kernel with 320 input channels (YOLOv5x's bottlenecks at 1280 x 1280: rows of 640 bytes, which straddle the 1-KiB
+    transfers and put two rows into a bank period) — the inference forms: plain store, folded BatchNorm + SiLU + residual; the
+    training forms are not built for it (statistics fall back to the default kernel)"""
+    from yoloseries_amd import hipk
+    g = torch.Generator().manual_seed(900 + N + H)
+    nan = float("nan")
+    buf = torch.full((B, H, W, 320 + 16), nan, dtype=torch.bfloat16, device=dev)
+    buf[..., 8:328] = _nhwc(B, H, W, 320, dev, 910)
+    segs = [hipk.Slice(buf, 8, 320)]
+    w = (torch.randn(N, 320, 1, 1, generator=g) / 320 ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    ref = F.conv2d(_nchw(buf[..., 8:328]), w).permute(0, 2, 3, 1)
+    out = torch.full((B, H, W, N + 16), 5.0, dtype=torch.bfloat16, device=dev)
+    d = hipk.conv_desc(segs, hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, N, hipk.Slice(out, 8, N))
+    d.algo = 13
+    assert "conv_pt_kernel<320, 0, 0>" in _kname(d), _kname(d)
+    hipk.conv_launch(d)
+    torch.cuda.synchronize()
+    _close(out[..., 8:8 + N], ref, 8e-3, 2e-2)
+    assert (out[..., :8] == 5.0).all() and (out[..., 8 + N:] == 5.0).all()
+    scale, shift = (torch.rand(N, generator=g) + 0.5).to(dev), torch.randn(N, generator=g).to(dev)
+    res = _nhwc(B, H, W, N, dev, 920)
+    out.fill_(5.0)
+    d2 = hipk.conv_desc(segs, hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, N, hipk.Slice(out, 8, N), scale=scale, shift=shift,
+                        act=hipk.YH_ACT_SILU, res=hipk.full(res))
+    d2.algo = 13
+    assert "conv_pt_kernel<320, 0, 2>" in _kname(d2), _kname(d2)
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    _close(out[..., 8:8 + N], F.silu(ref * scale + shift).to(torch.bfloat16).float() + res.float(), 1e-2, 4e-2)
+    assert (out[..., :8] == 5.0).all() and (out[..., 8 + N:] == 5.0).all()
+    stats = torch.zeros(4096, 2, wp.shape[0], device=dev)
+    d3 = hipk.conv_desc(segs, hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, N, hipk.Slice(out, 8, N))
+    d3.algo, d3.stats = 13, stats.data_ptr()
+    assert "conv_pt_kernel" not in _kname(d3), _kname(d3)
+
+
 def test_conv_pointwise_training_kernel_eligibility(dev):
     """shapes the kernel does not take fall back to the library default (algo 13 ignored)"""
     from yoloseries_amd import hipk

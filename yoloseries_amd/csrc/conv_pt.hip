@@ -61,7 +61,7 @@ struct PtK {
 };
 
 // swizzle term of a row: XORed into the chunk index (rows of 128 B: two rows per 256-byte bank period)
-template <int CS> __device__ __forceinline__ int pt_swz(int row) { return CS == 64 ? ((row >> 1) & 7) : (row & 15); }
+template <int CS> __device__ __forceinline__ int pt_swz(int row) { return (CS * 2) % 256 ? ((row >> 1) & 7) : (row & 15); }
 
 template <int CS0, int CS1>
 struct PtCfg {
@@ -74,7 +74,8 @@ struct PtCfg {
     static constexpr int STAGE_BYTES = PT_TM * PT_CP * 2;                     // the output tile
     static constexpr int CONST_OFF = STAGE_OFF + 2 * STAGE_BYTES;
     static constexpr int SMEM = CONST_OFF + 3 * PT_TN * 4;
-    static_assert((CS0 == 64 || CS0 == 128 || CS0 == 256 || CS0 == 512) && (CS1 == 0 || CS1 == CS0) && (CT == 128 || CT == 256 || CT == 512), "segment widths");
+    static_assert((CS0 == 64 || CS0 == 128 || CS0 == 256 || CS0 == 512 || (CS0 == 320 && CS1 == 0)) && (CS1 == 0 || CS1 == CS0) && (CT == 128 || CT == 256 || CT == 512 || CT == 320), "segment widths");
+    static_assert((CS0 * 2) % 128 == 0 && (PT_TM * CS0 * 2) % 4096 == 0, "whole 16-byte chunk groups of 8 per row; whole transfers per wave");
     static_assert(NI0 >= 1 && (CS1 == 0 || NI1 >= 1) && SMEM <= 160 * 1024, "LDS budget");
     static_assert(PT_NT * 16 * 4 <= PT_NBUF * A_BYTES, "the final reduction of EPI 3 runs in the pixel buffers");
 };
@@ -184,10 +185,11 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
     auto geom = [&](int h, int& row, unsigned& ch) {
         const bool s1 = h >= NI0;
         const int cs = s1 ? CS1 : CS0;
-        const int chr = cs / 8, rpi = 1024 / (cs * 2);
+        const int chr = cs / 8;                                   // 16-byte chunks per row
         const int ii = (s1 ? h - NI0 : h) * 4 + wave;
-        row = ii * rpi + lane / chr;
-        const int q = lane % chr;
+        const int g = ii * 64 + lane;                             // chunk g of the sub-image: a transfer is 64 consecutive chunks
+        row = g / chr;                                            // (rows of 640 B — 320 channels — straddle transfers)
+        const int q = g - row * chr;
         ch = (unsigned)((q ^ (s1 ? pt_swz<CS1 ? CS1 : 128>(row) : pt_swz<CS0>(row))) * 16);
     };
     const int HoWo = p.Ho * p.Wo;
@@ -320,7 +322,8 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
             f32x16_t acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            constexpr int KC = NKS > 16 ? 8 : NKS;           // fragments in registers at a time (512 channels: the weight slice alone is 128 registers)
+            constexpr int KC = NKS > 16 ? (NKS % 8 ? 10 : 8) : NKS;   // fragments in registers at a time (512 channels: the weight slice alone is 128 registers)
+            static_assert(NKS % KC == 0, "whole fragment groups");
 #pragma unroll
             for (int k0 = 0; k0 < NKS; k0 += KC) {
                 bf16x8_t af[KC];
@@ -461,7 +464,9 @@ bool pt_plan(const yh_conv_desc* d, PtPlan* pl)
     if (!d || (d->nseg != 1 && d->nseg != 2)) return false;
     if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->Ho != d->Hi || d->Wo != d->Wi) return false;
     const int C0 = d->seg[0].C, C1 = d->nseg == 2 ? d->seg[1].C : 0;
-    if (!((C1 == 0 && (C0 == 128 || C0 == 256 || C0 == 512)) || (C1 == C0 && (C0 == 64 || C0 == 128 || C0 == 256)))) return false;
+    // 320 channels (YOLOv5x's bottlenecks at 1280^2): inference forms only (plain / generic epilogue)
+    const bool c320 = C1 == 0 && C0 == 320 && !d->stats && !d->bnr_part;
+    if (!(c320 || (C1 == 0 && (C0 == 128 || C0 == 256 || C0 == 512)) || (C1 == C0 && (C0 == 64 || C0 == 128 || C0 == 256)))) return false;
     if (d->N <= 0 || d->Npad < d->N || d->Npad % 128) return false;
     const unsigned long M = (unsigned long)d->B * d->Ho * d->Wo;
     if (M == 0 || M >= (1ul << 31) - (1ul << 20)) return false;          // (tile indices of the ring's dummies past the end stay in range)
@@ -571,7 +576,18 @@ int yh_pt_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
         default: conv_pt_kernel<A_, B_, E3><<<grid, blk, sm, st>>>(pl.k); break;                                        \
         }                                                                                                               \
     } while (0)
-    if (pl.cs1 == 0) { if (pl.cs0 == 128) YH_LAUNCH_PT(128, 0); else if (pl.cs0 == 256) YH_LAUNCH_PT(256, 0); else YH_LAUNCH_PT(512, 0); }
+    if (pl.cs1 == 0 && pl.cs0 == 320) {
+        constexpr int sm = PtCfg<320, 0>::SMEM;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<320, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<320, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+            attr_set = true;
+        }
+        if (pl.epi == 2) conv_pt_kernel<320, 0, 2><<<grid, blk, sm, st>>>(pl.k);
+        else             conv_pt_kernel<320, 0, 0><<<grid, blk, sm, st>>>(pl.k);
+    }
+    else if (pl.cs1 == 0) { if (pl.cs0 == 128) YH_LAUNCH_PT(128, 0); else if (pl.cs0 == 256) YH_LAUNCH_PT(256, 0); else YH_LAUNCH_PT(512, 0); }
     else             { if (pl.cs0 == 64) YH_LAUNCH_PT(64, 64); else if (pl.cs0 == 128) YH_LAUNCH_PT(128, 128); else YH_LAUNCH_PT(256, 256); }
 #undef YH_LAUNCH_PT
     YH_CHECK_LAUNCH("yh_conv_igemm(pt)");

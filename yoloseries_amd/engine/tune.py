@@ -105,7 +105,7 @@ _WGRAD_TK64 = {
 # joined their candidates in round 3), and so do weight gradients that leave through the partial-tile workspace.
 KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad10", "wgrad8"
 KEY_CONV_C80 = "conv10"        # inference 3x3 layers with 80 -> 160 channels: conv_c80_kernel (algo 12) joined their candidates in round 4
-KEY_CONV_PT = "conv11"         # training 1x1 layers with 128 / 256 / 512 input channels: conv_pt_kernel (algo 13) joined their candidates in round 5
+KEY_CONV_PT = "conv11"         # 1x1 layers conv_pt_kernel (algo 13) takes: training with 128 / 256 / 512 input channels, inference with 320 (round 5)
 KEY_CONV_H160 = "conv12"       # inference 3x3 / stride-1 layers with N a multiple of 160: conv_halo160_kernel (algo 6) re-timed in round 5 (16 x 16 tiles)
 TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_CONV_C80, KEY_CONV_PT, KEY_CONV_H160, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
@@ -125,7 +125,8 @@ class TunerMixin:
         h160 = kind == 'eval' and d.KH == 3 and d.stride == 1 and d.nseg == 1 and d.N % 160 == 0 and d.seg[0].C >= 64 and d.seg[0].C % 32 == 0
         ctot = d.seg[0].C + (d.seg[1].C if d.nseg > 1 else 0)
         pt = kind != 'eval' and d.KH == 1 and d.stride == 1 and ctot in (128, 256, 512) and (d.nseg == 1 or d.seg[0].C == d.seg[1].C)
-        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else ((KEY_CONV_C80 if c80 else (KEY_CONV_H160 if h160 else KEY_CONV_EVAL)) if kind == 'eval' else (KEY_CONV_PT if pt else KEY_CONV)))}:{kind}:" + ",".join(str(int(v)) for v in (
+        pte = kind == 'eval' and d.KH == 1 and d.stride == 1 and d.nseg == 1 and ctot == 320 and d.nsplit >= d.N     # conv_pt_kernel's inference form
+        key = f"{KEY_CONV_S2D if d.mode == YH_CONV_DGRAD and d.stride == 2 else (KEY_CONV_P3 if small3 else ((KEY_CONV_C80 if c80 else (KEY_CONV_H160 if h160 else (KEY_CONV_PT if pte else KEY_CONV_EVAL))) if kind == 'eval' else (KEY_CONV_PT if pt else KEY_CONV)))}:{kind}:" + ",".join(str(int(v)) for v in (
             d.mode, d.B, d.Ho, d.Wo, d.Hi, d.Wi, d.KH, d.stride, d.pad, d.N, d.nseg, d.seg[0].C, d.seg[0].ld, d.seg[0].ups,
             d.seg[1].C if d.nseg > 1 else 0, d.seg[1].ups if d.nseg > 1 else 0, d.ld0, d.nsplit, d.accumulate, int(bool(d.stats or stats_ok)),
             int(bool(d.res)), d.act, int(bool(d.bias)), int(bool(d.scale)), int(bool(d.bnr_part)), 0))
