@@ -13,7 +13,7 @@ from ..hipk import Slice
 from ..streams import side_stream
 from . import flags as _flags
 from .executor import CompiledCmds
-from .flags import ABL_SKIP, FUSE_STEM_BWD, HEAD_COLSUM_SIDE, MERGE_PARTS, NGZ
+from .flags import ABL_SKIP, FUSE_STEM_BWD, HEAD_COLSUM_SIDE, MERGE_PARTS
 from .graph import ConvOp, PoolOp, Ref, _rup, plan_grad_buckets, sppf_chain
 from .tune import _tune_cache_save
 
@@ -73,7 +73,11 @@ class BackwardMixin:
         # layer's gz): consecutive layers alternate between two gz buffers so that a layer's wgrad may still be
         # reading its gz while the next layer's BN backward writes the other one
         self.two_streams = os.environ.get("YH_BWD_STREAMS", "1") != "0"
-        self.gy_ring = [self.gy_scratch] + ([torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev) for _ in range(NGZ - 1)] if self.two_streams else [self.gy_scratch] * (NGZ - 1))
+        # grouped weight gradients (flags.WGS_GROUP): the members' gz buffers are pinned until the group's launch, also on one stream
+        grp_max = min(_flags.WGS_GROUP, L.yh_conv_wgrad_group_max()) if _flags.WG_WS_BYTES == 0 else 0
+        grp_on = grp_max >= 2
+        NGZ = self.ngz = max(_flags.NGZ, _flags.WGS_GROUP_CBA + 3) if grp_on else _flags.NGZ
+        self.gy_ring = [self.gy_scratch] + ([torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev) for _ in range(NGZ - 1)] if (self.two_streams or grp_on) else [self.gy_scratch] * (NGZ - 1))
         n_cba = 0
         self.part_scratch = torch.zeros(1024 * 2 * 2048, dtype=torch.float32, device=self.dev)
         # partial sums of the head layers' bias gradients (column sums of the head gradients): these run on the SIDE stream (they feed
@@ -86,6 +90,32 @@ class BackwardMixin:
         # workspace of the weight gradients' split-M partial tiles (plain stores + a deterministic reduce instead of fp32
         # atomics; YH_WGRAD_PARTIAL=0: atomics).  One buffer serves every launch: they all run on one stream, in order.
         self.wg_ws = torch.empty(_flags.WG_WS_BYTES // 4, dtype=torch.float32, device=self.dev) if _flags.WG_WS_BYTES > 0 else None
+
+        # ---- grouped weight gradients: launches of the wave-private form are collected and leave together (yh_conv_wgrad_group)
+        group = {'items': [], 'slots': [], 'flops': 0.0}
+        held_marks = []
+
+        def flush_group():
+            """emit the collected weight gradients (one group launch; a single member as the plain launch it was) and the
+            gradient-arena marks held back behind them"""
+            items = group['items']
+            if items:
+                cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
+                if len(items) == 1:
+                    op_, wd_, meta_ = items[0]
+                    cmds.append(('wgrad', op_, wd_, meta_))
+                else:
+                    descs = [it[1] for it in items]
+                    arr = hipk.wgrad_group_array(descs)
+                    self._keep.append(arr)
+                    assert L.yh_conv_wgrad_group_ok(arr, len(descs), _flags.WGS_GROUP_WG) == 1
+                    cmds.append(('wgrad_group', [it[0] for it in items], (arr, descs),
+                                 ('conv_wgs_group_kernel', sum(it[2][1] for it in items), sum(it[2][2] for it in items))))
+                cmds.append(('wg_end', list(group['slots']) or None, None, ('sync', 0, 0.0)))
+            for gloc in held_marks:
+                marks.append((len(cmds), gloc))
+            group['items'], group['slots'], group['flops'] = [], [], 0.0
+            del held_marks[:]
 
         writes_seen = {}
 
@@ -181,6 +211,8 @@ class BackwardMixin:
             gys = self.gy_scratch
             if op.kind == 'cba':
                 gys = self.gy_ring[n_cba % NGZ]
+                if (n_cba % NGZ) in group['slots']:
+                    flush_group()                # never reached with the ring sized for a group: a pinned buffer is not overwritten
                 cmds.append(('gz_begin', n_cba % NGZ, None, ('sync', 0, 0.0)))       # main stream: wait until this gz buffer's last wgrad is done
                 n_cba += 1
             if op.kind == 'plain':
@@ -257,8 +289,6 @@ class BackwardMixin:
             # critical chain (it waits for the finalize behind the last data gradient): it stays on the main stream, beside the side
             # stream's last weight gradient instead of behind it
             on_main = op.kind == 'cba' and fused_stem
-            if not on_main:
-                cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
             def wgrad_desc_for(sg, coff_k):
                 wd = WgradDesc()
                 wd.gy = gys.data_ptr() if op.kind == 'cba' else 0
@@ -278,6 +308,7 @@ class BackwardMixin:
                     wd.partial, wd.partial_bytes = self.wg_ws.data_ptr(), self.wg_ws.numel() * 4
                 return wd
             coff_k = 0
+            launches = []
             for si, sg in enumerate(op.segs):
                 wd = wgrad_desc_for(sg, coff_k)
                 ntile = L.yh_conv_wgrad_tiles(gyN, op.k * op.k * sg.C)
@@ -287,13 +318,37 @@ class BackwardMixin:
                 self._keep.append(wd)
                 if on_main:
                     self._wgrad_on_main.add(id(wd))
-                cmds.append(('wgrad', op, wd, (self._wgrad_name(L, wd), 2.0 * M * op.N * kcols,
-                                               2.0 * M * gy_ld * (2 if wd.bn_z else 1) + nbytes_x)))
+                launches.append((op, wd, (self._wgrad_name(L, wd), 2.0 * M * op.N * kcols,
+                                          2.0 * M * gy_ld * (2 if wd.bn_z else 1) + nbytes_x)))
                 coff_k += sg.C
-            if not on_main:
-                cmds.append(('wg_end', (n_cba - 1) % NGZ if op.kind == 'cba' else None, None, ('sync', 0, 0.0)))
-            # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
-            marks.append((len(cmds), pk.gloc[op.name]))
+            slot = (n_cba - 1) % NGZ if op.kind == 'cba' else None
+            # Launches of the wave-private form join the pending group (its launch waits for the LAST member's gz; the members' gz
+            # buffers stay pinned); everything else leaves now.  Marks of the gradient arena are held back while a group is pending:
+            # a bucket is complete only when the weight gradients in front of it have been enqueued.
+            groupable = grp_on and not on_main and all(wd.tile_k == 129 and L.yh_conv_wgrad_wave_tiles(C.byref(wd)) > 0 for _o, wd, _m in launches)
+            if groupable:
+                ncba = len(group['slots']) + (1 if slot is not None else 0)
+                if len(group['items']) + len(launches) > grp_max or ncba > _flags.WGS_GROUP_CBA:
+                    flush_group()
+                group['items'] += launches
+                if slot is not None:
+                    group['slots'].append(slot)
+                group['flops'] += sum(m[1] for _o, _w, m in launches)
+                held_marks.append(pk.gloc[op.name])
+                if group['flops'] >= _flags.WGS_GROUP_GFLOP * 1e9 or len(group['items']) >= grp_max:
+                    flush_group()
+            else:
+                if not on_main:
+                    cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
+                for ln in launches:
+                    cmds.append(('wgrad',) + ln)
+                if not on_main:
+                    cmds.append(('wg_end', [slot] if slot is not None else None, None, ('sync', 0, 0.0)))
+                # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
+                if group['items']:
+                    held_marks.append(pk.gloc[op.name])
+                else:
+                    marks.append((len(cmds), pk.gloc[op.name]))
             # dgrad per segment
             for si, sg in enumerate(op.segs):
                 if not sg.buf.needs_grad:
@@ -344,6 +399,7 @@ class BackwardMixin:
                         d.bnr_part = slab.data_ptr()
                         self.bnr_fused[(po.name, ppi)] = (slab, rows)
                     cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C, self._conv_bytes(d))))
+        flush_group()
         self.cmd_bwd = cmds
         self.cmd_bwd_frozen = None
         self.bwd_buckets = plan_grad_buckets(marks, pk.gsize, int(os.environ.get("YH_DP_BUCKETS", "4")))
@@ -390,7 +446,7 @@ class BackwardMixin:
         cc = CompiledCmds(L, 2 * len(cmd_bwd) + 8 + 4 * sum(1 for c in cmd_bwd if c[0] == 'pair'))
         cc.source = cmd_bwd
         breaks, patches = [], []
-        pending = [False] * NGZ
+        pending = [None] * self.ngz       # per gz buffer: index of the event its last weight-gradient launch recorded
         if two:
             for ev in [self._ev_gz] + self._ev_wg:        # materialise the raw event handles
                 ev.record(self._side)
@@ -406,17 +462,19 @@ class BackwardMixin:
                     cc.call(sub[0], sub[1], 0, sub[2])
                 continue
             if fn == 'gz_begin':
-                if two and pending[cmd[1]]:
-                    cc.event(YH_CMD_STREAM_WAIT, ev_wg[cmd[1]], 0)
-                    pending[cmd[1]] = False
+                if two and pending[cmd[1]] is not None:
+                    e = pending[cmd[1]]
+                    cc.event(YH_CMD_STREAM_WAIT, ev_wg[e], 0)
+                    pending = [None if q == e else q for q in pending]     # the buffers of one group share an event
             elif fn == 'wg_begin':
                 if two:
                     cc.event(YH_CMD_EVENT_RECORD, ev_gz, 0)
                     cc.event(YH_CMD_STREAM_WAIT, ev_gz, 1)
             elif fn == 'wg_end':
-                if two and cmd[1] is not None:
-                    cc.event(YH_CMD_EVENT_RECORD, ev_wg[cmd[1]], 1)
-                    pending[cmd[1]] = True
+                if two and cmd[1]:
+                    cc.event(YH_CMD_EVENT_RECORD, ev_wg[cmd[1][0]], 1)
+                    for slot in cmd[1]:
+                        pending[slot] = cmd[1][0]
             elif fn == 'head_colsum':
                 _, op, boff, _m = cmd
                 if boff is not None:
@@ -430,6 +488,14 @@ class BackwardMixin:
                 cc.call(L.yh_conv_wgrad, (wd,), 1 if two and id(wd) not in self._wgrad_on_main else 0, op.name)
                 if op.kind == 'plain':
                     patches.append(('wgrad', wd, op.name, -1))
+            elif fn == 'wgrad_group':
+                _, ops_, (arr, descs), _m = cmd
+                if "wgrad" in ABL_SKIP:
+                    continue
+                cc.call(L.yh_conv_wgrad_group, (arr, len(descs), _flags.WGS_GROUP_WG), 1 if two else 0, f"{ops_[0].name} +{len(descs) - 1}")
+                for op_, wd in zip(ops_, descs):
+                    if op_.kind == 'plain':      # the group reads its descriptors when it is launched: patched in place
+                        patches.append(('wgrad', wd, op_.name, -1))
             elif fn == 'dgrad':
                 _, op, d, _m = cmd
                 cc.call(L.yh_conv_igemm, (d,), 0, op.name)
@@ -475,14 +541,14 @@ class BackwardMixin:
                 # a stream PROBED to run beside the compute stream (streams.py: a fresh stream may share its hardware queue)
                 self._side = side_stream(self.dev)
                 self._ev_gz = torch.cuda.Event()
-                self._ev_wg = [torch.cuda.Event() for _ in range(NGZ)]
+                self._ev_wg = [torch.cuda.Event() for _ in range(self.ngz)]
                 self._ev_all = torch.cuda.Event()
             main = torch.cuda.current_stream()
             side = self._side
             st_side = C.c_void_p(side.cuda_stream)
             self._ev_gz.record(main)               # packed arena zeroed, head gradients in place
             side.wait_event(self._ev_gz)
-            pending = [False] * NGZ
+            pending = [None] * self.ngz
         if prof is None and _flags.USE_EXEC:
             # replay the compiled command array (yh_exec): one call per bucket segment instead of one ctypes call per launch
             key = ('bwd', two, bucket_hook is not None, frozen)
@@ -525,9 +591,10 @@ class BackwardMixin:
                         check(rc, f"{sub[0].__name__} bwd [{sub[2]}]")
                 continue
             if fn == 'gz_begin':
-                if two and pending[cmd[1]]:
-                    main.wait_event(self._ev_wg[cmd[1]])
-                    pending[cmd[1]] = False
+                if two and pending[cmd[1]] is not None:
+                    e = pending[cmd[1]]
+                    main.wait_event(self._ev_wg[e])
+                    pending = [None if q == e else q for q in pending]
                 continue
             if fn == 'wg_begin':
                 if two:
@@ -535,12 +602,13 @@ class BackwardMixin:
                     side.wait_event(self._ev_gz)
                 continue
             if fn == 'wg_end':
-                if two:
-                    if cmd[1] is not None:
-                        self._ev_wg[cmd[1]].record(side)
-                        pending[cmd[1]] = True
+                if two and cmd[1]:
+                    self._ev_wg[cmd[1][0]].record(side)
+                    for slot in cmd[1]:
+                        pending[slot] = cmd[1][0]
                 continue
-            on_side = two and ((fn == 'wgrad' and id(cmd[2]) not in self._wgrad_on_main) or (fn == 'head_colsum' and self._head_on_side(cmd[1], two)))
+            on_side = two and ((fn == 'wgrad' and id(cmd[2]) not in self._wgrad_on_main) or fn == 'wgrad_group' or
+                               (fn == 'head_colsum' and self._head_on_side(cmd[1], two)))
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(side if on_side else None)
@@ -559,6 +627,14 @@ class BackwardMixin:
                 rc = L.yh_conv_wgrad(C.byref(wd), st_side if on_side else st)
                 if rc:
                     check(rc, f"yh_conv_wgrad [{op.name}]")
+            elif fn == 'wgrad_group':
+                _, ops_, (arr, descs), _m = cmd
+                for op_, wd in zip(ops_, descs):
+                    if op_.kind == 'plain':
+                        wd.gy = heads[op_.name].data_ptr()
+                rc = L.yh_conv_wgrad_group(arr, len(descs), _flags.WGS_GROUP_WG, st_side if on_side else st)
+                if rc:
+                    check(rc, f"yh_conv_wgrad_group [{ops_[0].name}]")
             elif fn == 'dgrad':
                 _, op, d, _m = cmd
                 if op.kind == 'plain':
@@ -573,7 +649,8 @@ class BackwardMixin:
                     check(rc, f"{fn.__name__} bwd [{name}]")
             if prof is not None:
                 e1.record(side if on_side else None)
-                prof.setdefault(cmd[3] + (cmd[1].name if hasattr(cmd[1], 'name') else cmd[2],), []).append((e0, e1))
+                label = f"{cmd[1][0].name} +{len(cmd[1]) - 1}" if fn == 'wgrad_group' else (cmd[1].name if hasattr(cmd[1], 'name') else cmd[2])
+                prof.setdefault(cmd[3] + (label,), []).append((e0, e1))
         while nb < len(buckets):
             finishers.append(self._bucket_ready(bucket_hook, buckets[nb], main if two else None, side if two else None))
             nb += 1
