@@ -106,7 +106,7 @@ _WGRAD_TK64 = {
 KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_WGRAD, KEY_WGRAD_WS = "conv6", "conv7", "conv8", "conv9", "wgrad10", "wgrad8"
 KEY_CONV_C80 = "conv10"        # inference 3x3 layers with 80 -> 160 channels: conv_c80_kernel (algo 12) joined their candidates in round 4
 KEY_CONV_PT = "conv11"         # 1x1 layers conv_pt_kernel (algo 13) takes: training with 128 / 256 / 512 input channels, inference with 320 (round 5)
-KEY_CONV_H160 = "conv12"       # inference 3x3 / stride-1 layers with N a multiple of 160: conv_halo160_kernel (algo 6) re-timed in round 5 (16 x 16 tiles)
+KEY_CONV_H160 = "conv14"       # inference 3x3 / stride-1 layers with N a multiple of 160: re-timed against the FINAL conv_halo160_kernel of round 5 (16 x 16 tiles, pipelined sub-steps): it now takes every one of them, also the 640-channel layers the conv12 entries had left on conv_halo_kernel
 TUNE_KEY_VERSIONS = frozenset((KEY_CONV, KEY_CONV_S2D, KEY_CONV_P3, KEY_CONV_EVAL, KEY_CONV_C80, KEY_CONV_PT, KEY_CONV_H160, KEY_WGRAD, KEY_WGRAD_WS, KEY_WGRAD + "f", KEY_WGRAD_WS + "f"))
 
 
