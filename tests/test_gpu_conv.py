@@ -1197,6 +1197,32 @@ def test_conv_input_beyond_two_gib_stays_on_the_lds_dma_kernel(dev, case):
     _close(out[i:i + 1], ref, 1e-2, 4e-2)
 
 
+@pytest.mark.parametrize("H,C0,N", [(40, 256, 128), (80, 128, 128), (80, 256, 256)])
+def test_conv_pointwise_store_hazard_screen(dev, H, C0, N):
+    """conv_pt_kernel at the judged batch (64): eight launches of a plain 1x1 data gradient into NaN-filled outputs, other kernels in
+    between, every element against an fp32 matmul.  Regression screen of the store hazard of round 5: a VALU write of the first data
+    register directly behind a 16-byte buffer store with a scalar offset reached the last lanes of every 16-lane row of that store —
+    a box- and timing-dependent handful of wrong chunks per launch (8 of 12 launches on the box that showed it; csrc/conv_pt.hip
+    pt_bstore, tools/pt_race.py)."""
+    from yoloseries_amd import hipk
+    B = 64
+    g = torch.Generator(device=dev).manual_seed(900 + H + C0 + N)
+    gy = torch.randn(B, H, H, C0, generator=g, device=dev).to(torch.bfloat16)
+    w = (torch.randn(C0, N, 1, 1, device=dev, generator=g) / C0 ** 0.5).to(torch.bfloat16).float()
+    wp = hipk.pack_weight_dgrad(w)
+    ref = (gy.float().reshape(-1, C0) @ w.reshape(C0, N)).reshape(B, H, H, N)
+    for r in range(8):
+        out = torch.full((B, H, H, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        d = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, H, H, H, 1, 1, 0, wp, N, hipk.full(out))
+        d.algo = 13
+        assert f"conv_pt_kernel<{C0}, 0, 0>" in _kname(d)
+        junk = torch.randn(2048, 2048, device=dev) @ torch.randn(2048, 256, device=dev)      # noqa: F841  other bytes in LDS and the caches
+        hipk.conv_launch(d)
+        torch.cuda.synchronize()
+        bad = ~((out.float() - ref).abs() <= 4e-2 + 1e-2 * ref.abs())
+        assert not bad.any(), f"launch {r}: {int(bad.sum())} elements wrong, first rows {torch.nonzero(bad.reshape(-1, N).any(1)).flatten()[:4].tolist()}"
+
+
 PT_CASES = [
     # B, H, W, C0, C1, ups0, ups1, N: conv_pt_kernel (algo 13) — 1x1 layers of the training step with 128 / 256 input channels
     (2, 20, 20, 128, 0, 0, 0, 128),       # bottleneck conv_bn_act_1 (40 x 40 class), 800 pixels = 25 tiles

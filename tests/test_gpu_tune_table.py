@@ -63,13 +63,18 @@ def test_shipped_table_covers_the_training_workloads():
     assert all(f[1] == 64 for _, f, _ in conv) and all(f[6] == 64 for _, f, _, _ in wgrad)
 
 
-def test_conv_entries_at_judged_shapes(dev):
+NCHUNK = 8          # the walk is cut into chunks: a chunk is a test of its own (progress on the console, bounded time per test)
+
+
+@pytest.mark.parametrize("chunk", range(NCHUNK))
+def test_conv_entries_at_judged_shapes(dev, chunk):
     from yoloseries_amd import hipk
     from yoloseries_amd._lib import ConvDesc, YH_CONV_DGRAD, check, lib
     L = lib()
     conv, _ = _table()
     fams = {}
-    for ki, (key, f, (tile_k, grid_cap, algo)) in enumerate(_share(conv)):
+    items = list(enumerate(_share(conv)))
+    for ki, (key, f, (tile_k, grid_cap, algo)) in items[chunk::NCHUNK]:
         (mode, B, Ho, Wo, Hi, Wi, k, stride, pad, N, nseg, C0, ld0s, ups0, C1, ups1, ldo, nsplit, accumulate, stats, res, act, bias, scale,
          bnr, acc_rows) = f
         assert not res and not act and not bias and not scale and not acc_rows and nsplit == N, key
@@ -118,10 +123,18 @@ def test_conv_entries_at_judged_shapes(dev):
         check(L.yh_conv_kernel_name(C.byref(d), name, 96), "yh_conv_kernel_name")
         fams[name.value.decode().split("<")[0]] = fams.get(name.value.decode().split("<")[0], 0) + 1
         check(L.yh_conv_igemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), f"yh_conv_igemm [{key}]")
-        # fp32 torch reference of the same op
-        if mode == YH_CONV_DGRAD:
+        # fp32 torch reference of the same op (1x1 layers: the same contraction as one fp32 matmul — no per-shape convolution search)
+        if mode == YH_CONV_DGRAD and k == 1 and stride == 1 and pad == 0:
+            ref = (xs[0][..., :C0].float().reshape(-1, C0) @ w.reshape(C0, N)).reshape(B, Ho, Wo, N)
+        elif mode == YH_CONV_DGRAD:
             gy = xs[0][..., :C0].float().permute(0, 3, 1, 2)
             ref = torch.nn.grad.conv2d_input((B, N, Ho, Wo), w, gy, stride=stride, padding=pad).permute(0, 2, 3, 1)
+        elif k == 1 and stride == 1 and pad == 0:
+            parts = []
+            for si in range(nseg):
+                x = xs[si][..., :segC[si]].float()
+                parts.append(x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2) if segups[si] else x)
+            ref = (torch.cat(parts, 3).reshape(-1, Ctot) @ w.reshape(N, Ctot).t()).reshape(B, Ho, Wo, N)
         else:
             parts = []
             for si in range(nseg):
@@ -133,36 +146,42 @@ def test_conv_entries_at_judged_shapes(dev):
         torch.cuda.synchronize()
         _close(out[..., :N], ref, 1e-2, 4e-2, key)
         assert torch.equal(out[..., N:], out0[..., N:]), f"{key}: wrote outside its channel slice"
-        o = out[..., :N].float().reshape(-1, N).double()
+        o = out[..., :N].float().reshape(-1, N)
+        S = lambda v: v.sum(0, dtype=torch.float64)          # noqa: E731  column sums accumulated in fp64
         if stats:
             # BatchNorm partial sums: some families sum the fp32 accumulators, others the stored (bf16-rounded) values — both are within
             # the rounding noise of the stored tensor: per element <= 2^-9 |v|, random sign, i.e. a random walk of 2^-9 sqrt(sum v^2)
             # (six sigma allowed); the sum of squares carries 2 v e
             s1, s2 = st[:, 0, :N].double().sum(0), st[:, 1, :N].double().sum(0)
-            n1 = 2.0 ** -9 * (o * o).sum(0).sqrt() * 3.5 + 1e-2
-            n2 = 2.0 ** -8 * (o ** 4).sum(0).sqrt() * 3.5 + 1e-2
-            assert ((s1 - o.sum(0)).abs() <= n1 + 1e-5 * o.abs().sum(0)).all(), f"{key}: sum {(s1 - o.sum(0)).abs().max().item():.4g} vs noise bound {n1.max().item():.4g}"
-            assert ((s2 - (o * o).sum(0)).abs() <= n2 + 1e-5 * (o * o).sum(0)).all(), f"{key}: sum of squares {(s2 - (o * o).sum(0)).abs().max().item():.4g} vs {n2.max().item():.4g}"
+            o2 = o * o
+            so, so2 = S(o), S(o2)
+            n1 = 2.0 ** -9 * so2.sqrt() * 3.5 + 1e-2
+            n2 = 2.0 ** -8 * S(o2 * o2).sqrt() * 3.5 + 1e-2
+            assert ((s1 - so).abs() <= n1 + 1e-5 * S(o.abs())).all(), f"{key}: sum {(s1 - so).abs().max().item():.4g} vs noise bound {n1.max().item():.4g}"
+            assert ((s2 - so2).abs() <= n2 + 1e-5 * so2).all(), f"{key}: sum of squares {(s2 - so2).abs().max().item():.4g} vs {n2.max().item():.4g}"
+            del o2
         if bnr:
-            zz = z.float().reshape(-1, N).double()
-            a = zz * ws[:N].double() + ws[N:].double()
+            zz = z.float().reshape(-1, N)
+            a = zz * ws[:N] + ws[N:]
             sg = torch.sigmoid(a)
             dz = o * (sg * (1 + a * (1 - sg)))
             got = slab.double().sum(0)
-            assert torch.allclose(got[0], dz.sum(0), rtol=2e-3, atol=2e-3 * dz.abs().sum(0).max().item()), key
-            assert torch.allclose(got[1], (dz * zz).sum(0), rtol=2e-3, atol=2e-3 * (dz * zz).abs().sum(0).max().item()), key
+            assert torch.allclose(got[0], S(dz), rtol=2e-3, atol=2e-3 * S(dz.abs()).max().item()), key
+            assert torch.allclose(got[1], S(dz * zz), rtol=2e-3, atol=2e-3 * S((dz * zz).abs()).max().item()), key
+            del zz, a, sg, dz
         del out, out0, ref, xs, segs, w, wp, st, slab, z, ws
     print("kernel families exercised:", dict(sorted(fams.items())))
-    assert len(fams) >= 5
+    assert len(fams) >= 4
 
 
-def test_wgrad_entries_at_judged_shapes(dev):
+@pytest.mark.parametrize("chunk", range(2))
+def test_wgrad_entries_at_judged_shapes(dev, chunk):
     from yoloseries_amd import hipk
     from yoloseries_amd._lib import check, lib
     L = lib()
     _, wgrad = _table()
     fams = {}
-    for ki, (key, f, (splits, tile_k), fused) in enumerate(_share(wgrad)):
+    for ki, (key, f, (splits, tile_k), fused) in list(enumerate(_share(wgrad)))[chunk::2]:
         N, ldg, C0, ld0, ups, Ctot, B, Ho, Wo, Hi, Wi, k, stride, pad = f
         seed = 5000 + 11 * ki
         M = B * Ho * Wo
@@ -191,11 +210,18 @@ def test_wgrad_entries_at_judged_shapes(dev):
         name = Program_wgrad_name(L, d)
         fams[name.split("<")[0]] = fams.get(name.split("<")[0], 0) + 1
         check(L.yh_conv_wgrad(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), f"yh_conv_wgrad [{key}]")
-        xin = x[..., :C0].float().permute(0, 3, 1, 2)
-        if ups:
-            xin = F.interpolate(xin, scale_factor=2, mode="nearest")
-        rw = torch.nn.grad.conv2d_weight(xin, (N, C0, k, k), gz_ref.permute(0, 3, 1, 2), stride=stride, padding=pad)
-        rw = rw.permute(0, 2, 3, 1)                          # [N][kh][kw][C0]
+        if k == 1 and stride == 1 and pad == 0:
+            xf = x[..., :C0].float()
+            if ups:
+                xf = xf.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+            rw = (gz_ref.reshape(-1, N).t() @ xf.reshape(-1, C0)).reshape(N, 1, 1, C0)
+            xin = xf
+        else:
+            xin = x[..., :C0].float().permute(0, 3, 1, 2)
+            if ups:
+                xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+            rw = torch.nn.grad.conv2d_weight(xin, (N, C0, k, k), gz_ref.permute(0, 3, 1, 2), stride=stride, padding=pad)
+            rw = rw.permute(0, 2, 3, 1)                          # [N][kh][kw][C0]
         torch.cuda.synchronize()
         got = dw.view(N, k, k, Ctot)
         _close(got[..., coff:], rw, 1e-2, 1e-2 * rw.abs().max().item(), key)

@@ -105,9 +105,15 @@ template <int N> __device__ __forceinline__ void pt_wait(pt_u32x4& a, pt_u32x4& 
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 __device__ __forceinline__ uint4 pt_u4(const pt_u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
+// A 16-byte store with a SCALAR tile offset.  Inline asm with its own wait states: behind the builtin form the compiler placed a
+// VALU write of the first data register directly behind the store (its hazard table exempts buffer stores of more than 64 bits
+// whose soffset is an SGPR from the wait state in front of a write to their data registers), and on gfx950 the store then picked up
+// the NEW value in the last lanes of every 16-lane row of its first dword: a box- and timing-dependent handful of wrong output
+// chunks (4 rows x 2 channels of four chunks; found by tests/test_gpu_tune_table.py, screened with tools/pt_race.py).  The store
+// stays an unconditional vector-memory instruction of the loop: the hand-counted waits include it (NST).
 __device__ __forceinline__ void pt_bstore(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, uint4 v) {
     const pt_u32x4 w = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(w, rs, voff, soff, 0);
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(w), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
 // EPI 0: plain store, 1: + BatchNorm partial sums, 2: generic epilogue, 3: data gradient + fused BatchNorm-backward reduction
