@@ -174,6 +174,93 @@ def test_conv_entries_at_judged_shapes(dev, chunk):
     assert len(fams) >= 4
 
 
+def _eval_entries():
+    with open(os.path.join(ROOT, "yoloseries_amd", "tune_defaults.json")) as f:
+        t = json.load(f)
+    ev = []
+    for k, v in sorted(t.items()):
+        parts = k.split(":")
+        if len(parts) == 3 and parts[1] == "eval":
+            ev.append((k, [int(x) for x in parts[2].split(",")], v))
+    # every entry of the judged inference configuration (YOLOv5x at 1280 x 1280, batch 128), a quarter of the others (batch 32 / 64)
+    big = [e for e in ev if e[1][1] == 128]
+    rest = [e for e in ev if e[1][1] != 128]
+    random.Random(20261005).shuffle(rest)
+    return big + rest[:len(rest) // 4]
+
+
+NCHUNK_EVAL = 6
+
+
+@pytest.mark.parametrize("chunk", range(NCHUNK_EVAL))
+def test_eval_entries_at_judged_shapes(dev, chunk):
+    """the INFERENCE entries of the shipped table (folded BatchNorm + SiLU epilogue, residual, split destination, outputs as channel
+    slices of wider buffers, two-segment / upsampled inputs) at their own shapes with the kernel family / tile the table names —
+    all of YOLOv5x at 1280 x 1280, batch 128 (conv_halo160 / h80 / c80 / pw / pt / stem kernels), a quarter of the rest — against
+    fp32 torch, the reference taken 16 images at a time"""
+    from yoloseries_amd import hipk
+    from yoloseries_amd._lib import YH_ACT_SILU, check, lib
+    L = lib()
+    fams = {}
+    for ki, (key, f, (tile_k, grid_cap, algo)) in list(enumerate(_eval_entries()))[chunk::NCHUNK_EVAL]:
+        (mode, B, Ho, Wo, Hi, Wi, k, stride, pad, N, nseg, C0, ld0s, ups0, C1, ups1, ldo, nsplit, accumulate, stats, res, act, bias, scale,
+         bnr, _z) = f
+        assert mode == 0 and not stats and not bnr and not accumulate and not bias and act == 1 and scale == 1, key
+        seed = 9000 + 13 * ki
+        g = torch.Generator(device=dev).manual_seed(seed)
+        segC, segups = [C0, C1][:nseg], [ups0, ups1][:nseg]
+        segs, xs = [], []
+        for si in range(nseg):
+            h, w_ = Hi >> segups[si], Wi >> segups[si]
+            ld = ld0s if si == 0 else segC[si]
+            buf = torch.randn(B, h, w_, ld, generator=g, device=dev).to(torch.bfloat16)
+            segs.append(hipk.Slice(buf, 0, segC[si], segups[si]))
+            xs.append(buf)
+        Ctot = sum(segC)
+        w = (torch.randn(N, Ctot, k, k, device=dev, generator=g) / (Ctot * k * k) ** 0.5).to(torch.bfloat16).float()
+        wp = hipk.pack_weight_fwd(w)
+        sc = torch.rand(N, generator=g, device=dev) + 0.5
+        sh = torch.randn(N, generator=g, device=dev) * 0.5
+        n0 = min(nsplit, N)
+        out0 = torch.full((B, Ho, Wo, ldo), 3.0, dtype=torch.bfloat16, device=dev)
+        out1 = torch.full((B, Ho, Wo, N - n0 + 8), 3.0, dtype=torch.bfloat16, device=dev) if n0 < N else None
+        rs = torch.randn(B, Ho, Wo, n0, generator=g, device=dev).to(torch.bfloat16) if res else None
+        d = hipk.conv_desc(segs, 0, B, Ho, Wo, Hi, Wi, k, stride, pad, wp, N, hipk.Slice(out0, 0, n0), nsplit=n0,
+                           out1=hipk.Slice(out1, 0, N - n0) if out1 is not None else None, scale=sc, shift=sh, act=YH_ACT_SILU,
+                           res=hipk.full(rs) if rs is not None else None)
+        d.tile_k, d.grid_cap, d.algo = tile_k, grid_cap, algo
+        name = C.create_string_buffer(96)
+        check(L.yh_conv_kernel_name(C.byref(d), name, 96), "yh_conv_kernel_name")
+        fams[name.value.decode().split("<")[0]] = fams.get(name.value.decode().split("<")[0], 0) + 1
+        check(L.yh_conv_igemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), f"yh_conv_igemm [{key}]")
+        torch.cuda.synchronize()
+        for b0 in range(0, B, 16):
+            b1 = min(B, b0 + 16)
+            if k == 1 and stride == 1 and pad == 0:
+                parts = []
+                for si in range(nseg):
+                    x = xs[si][b0:b1, ..., :segC[si]].float()
+                    parts.append(x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2) if segups[si] else x)
+                ref = (torch.cat(parts, 3).reshape(-1, Ctot) @ w.reshape(N, Ctot).t()).reshape(b1 - b0, Ho, Wo, N)
+            else:
+                parts = []
+                for si in range(nseg):
+                    x = xs[si][b0:b1, ..., :segC[si]].float().permute(0, 3, 1, 2)
+                    parts.append(F.interpolate(x, scale_factor=2, mode="nearest") if segups[si] else x)
+                ref = F.conv2d(torch.cat(parts, 1), w, None, stride=stride, padding=pad).permute(0, 2, 3, 1)
+            ref = F.silu(ref * sc + sh)
+            if rs is not None:
+                ref[..., :n0] += rs[b0:b1].float()
+            _close(out0[b0:b1, ..., :n0], ref[..., :n0], 1e-2, 4e-2, key)
+            if out1 is not None:
+                _close(out1[b0:b1, ..., :N - n0], ref[..., n0:], 1e-2, 4e-2, key + " (second destination)")
+            del ref, parts
+        assert (out0[..., n0:] == 3.0).all(), f"{key}: wrote outside its channel slice"
+        assert out1 is None or (out1[..., N - n0:] == 3.0).all(), f"{key}: wrote outside the second destination's slice"
+        del out0, out1, rs, xs, segs, w, wp
+    print("kernel families exercised:", dict(sorted(fams.items())))
+
+
 @pytest.mark.parametrize("chunk", range(2))
 def test_wgrad_entries_at_judged_shapes(dev, chunk):
     from yoloseries_amd import hipk
