@@ -2,7 +2,8 @@
 """Race screen of every conv entry of the shipped launch-parameter table at its own shape: REPS launches each into NaN-filled outputs
 (other kernels in between), every launch compared BIT FOR BIT with the first — the forward / data-gradient / inference kernels are
 deterministic, so any difference is a synchronisation error (a missing wait, a hazard), whatever a reference would say.  The
-statistics / fused-reduction slabs are compared too.  usage: race_screen.py [reps] [key substring]"""
+statistics / fused-reduction slabs are compared too; the weight-gradient entries (fp32 atomics) launch to launch within 1e-3 of
+the largest element.  usage: race_screen.py [reps] [key substring]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -86,10 +87,44 @@ def screen(reps=6, sub="", verbose=True):
                 print(f"DIFF {name} {key}: {diffs}", flush=True)
         if verbose and ki % 50 == 49:
             print(f"... {ki + 1} of {len(keys)} entries, {len(bad_entries)} with differences", flush=True)
+    # ---- weight gradients: fp32 atomics — not bit-reproducible — so launch to launch within 1e-3 of the largest element
+    from yoloseries_amd.engine import Program
+    wkeys = [k for k in sorted(t) if k.startswith("wgrad") and sub in k]
+    for ki, key in enumerate(wkeys):
+        N, ldg, C0, ld0, ups, Ctot, B, Ho, Wo, Hi, Wi, k, stride, pad = [int(x) for x in key.split(":")[-1].split(",")]
+        if key.split(":")[0].endswith("f"):
+            continue                               # the stem's fused form needs the BatchNorm operands (tests/test_gpu_tune_table.py)
+        splits, tile_k = t[key]
+        g = torch.Generator(device=dev).manual_seed(8000 + ki)
+        x = torch.randn(B, Hi >> ups, Wi >> ups, ld0, generator=g, device=dev).to(torch.bfloat16)
+        gy = (torch.randn(B, Ho, Wo, ldg, generator=g, device=dev) * 0.25).to(torch.bfloat16)
+        first, diffs, name = None, [], ""
+        for r in range(reps):
+            dw = torch.zeros(N, k * k * Ctot, device=dev)
+            d = hipk.wgrad_desc(hipk.Slice(gy, 0, N), N, hipk.Slice(x, 0, C0, ups), Ctot - C0, Ctot, B, Ho, Wo, Hi, Wi, k, stride, pad, dw, splits)
+            d.tile_k = tile_k
+            if r == 0:
+                name = Program._wgrad_name(L, d)
+                fams[name.split("<")[0]] = fams.get(name.split("<")[0], 0) + 1
+            junk = torch.randn(1024, 1024, device=dev) @ torch.randn(1024, 256, device=dev)      # noqa: F841
+            check(L.yh_conv_wgrad(C.byref(d), st()), key)
+            torch.cuda.synchronize()
+            if first is None:
+                first = dw.clone()
+                if not torch.isfinite(dw).all():
+                    diffs.append(("non-finite in first launch", int((~torch.isfinite(dw)).sum())))
+            else:
+                err = (dw - first).abs().max().item()
+                if not err <= 1e-3 * first.abs().max().item():
+                    diffs.append((r, err))
+        if diffs:
+            bad_entries.append((key, name, diffs))
+            if verbose:
+                print(f"DIFF {name} {key}: {diffs}", flush=True)
     if verbose:
         print("kernel families:", dict(sorted(fams.items())))
-        print(f"{len(keys)} entries x {reps} launches: {len(bad_entries)} entries with launch-to-launch differences")
-    return len(keys), bad_entries, fams
+        print(f"{len(keys)} conv + {len(wkeys)} weight-gradient entries x {reps} launches: {len(bad_entries)} entries with launch-to-launch differences")
+    return len(keys) + len(wkeys), bad_entries, fams
 
 
 if __name__ == "__main__":
