@@ -3,7 +3,7 @@
 (other kernels in between), every launch compared BIT FOR BIT with the first — the forward / data-gradient / inference kernels are
 deterministic, so any difference is a synchronisation error (a missing wait, a hazard), whatever a reference would say.  The
 statistics / fused-reduction slabs are compared too; the weight-gradient entries (fp32 atomics) launch to launch within 1e-3 of
-the largest element.  usage: race_screen.py [reps] [key substring]"""
+the largest element.  YH_RACE_BESIDE=1: every launch next to a busy second stream.  usage: race_screen.py [reps] [key substring]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,10 +11,24 @@ from yoloseries_amd import hipk
 from yoloseries_amd._lib import YH_ACT_SILU, YH_CONV_DGRAD, check, lib
 
 
-def screen(reps=6, sub="", verbose=True):
+def screen(reps=6, sub="", verbose=True, beside=False):
     """-> (entries walked, [(key, kernel, differences)]): see the module docstring"""
     dev = torch.device("cuda:0")
     L = lib()
+    # beside=True: every screened launch runs next to a stream of memory-bound copies and matmuls on a second stream (the conditions
+    # of the two-stream step: other waves on the CUs, a busy vector-memory path), not alone on the chip
+    side = torch.cuda.Stream(device=dev) if beside else None
+    big = torch.empty(1 << 28, dtype=torch.uint8, device=dev) if beside else None
+    mm = (torch.randn(2048, 2048, device=dev), torch.randn(2048, 2048, device=dev)) if beside else None
+
+    def busy():
+        if side is None:
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                big[:1 << 27].copy_(big[1 << 27:])
+                mm[0] @ mm[1]
     t = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "yoloseries_amd", "tune_defaults.json")))
     keys = [k for k in sorted(t) if k.startswith("conv") and k.split(":")[1] in ("fwd", "dgrad", "eval") and sub in k]
     nan = float("nan")
@@ -68,6 +82,7 @@ def screen(reps=6, sub="", verbose=True):
                 nb = C.create_string_buffer(96); L.yh_conv_kernel_name(C.byref(d), nb, 96); name = nb.value.decode()
                 fams[name.split("<")[0]] = fams.get(name.split("<")[0], 0) + 1
             junk = torch.randn(1024, 1024, device=dev) @ torch.randn(1024, 256, device=dev)      # noqa: F841
+            busy()
             check(L.yh_conv_igemm(C.byref(d), st()), key)
             torch.cuda.synchronize()
             cur = [out0[..., :n0].view(torch.int16)] + ([out1[..., :N - n0].view(torch.int16)] if out1 is not None else []) + \
@@ -107,6 +122,7 @@ def screen(reps=6, sub="", verbose=True):
                 name = Program._wgrad_name(L, d)
                 fams[name.split("<")[0]] = fams.get(name.split("<")[0], 0) + 1
             junk = torch.randn(1024, 1024, device=dev) @ torch.randn(1024, 256, device=dev)      # noqa: F841
+            busy()
             check(L.yh_conv_wgrad(C.byref(d), st()), key)
             torch.cuda.synchronize()
             if first is None:
@@ -128,5 +144,5 @@ def screen(reps=6, sub="", verbose=True):
 
 
 if __name__ == "__main__":
-    screen(int(sys.argv[1]) if len(sys.argv) > 1 else 6, sys.argv[2] if len(sys.argv) > 2 else "")
+    screen(int(sys.argv[1]) if len(sys.argv) > 1 else 6, sys.argv[2] if len(sys.argv) > 2 else "", beside=os.environ.get("YH_RACE_BESIDE") == "1")
 
