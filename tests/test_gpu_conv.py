@@ -1294,17 +1294,39 @@ def test_conv_pointwise_training_kernel(dev, B, H, W, C0, C1, ups0, ups1, N):
     assert ((stats[:, 0, :N].double().sum(0) - o.sum(0)).abs() <= 1e-3 + 1e-5 * o.abs().sum(0)).all()
     assert ((stats[:, 1, :N].double().sum(0) - (o ** 2).sum(0)).abs() <= 1e-3 + 1e-5 * (o ** 2).sum(0)).all()
     assert (stats[:, :, N:] == 0).all()
-    # (3) bias (Detect) / accumulate onto an existing tensor (generic epilogue)
+    # (3) bias (Detect: EPI 2, no operand from memory) ...
     bias = torch.randn(N, generator=g).to(dev)
+    outb = torch.full((B, H, W, ldo), 5.0, dtype=torch.bfloat16, device=dev)
+    d2 = desc(outb, bias=bias)
+    assert f"conv_pt_kernel<{C0}, {C1}, 2>" in _kname(d2)
+    hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    _close(outb[..., 8:8 + N], ref + bias, 1e-2, 4e-2)
+    assert (outb[..., :8] == 5.0).all() and (outb[..., 8 + Nr:] == 5.0).all()
+    # ... and bias + accumulate onto an existing tensor (EPI 4: the earlier contents arrive by LDS-DMA in the wave's operand slots;
+    # 512 channels in all leave no LDS for the slots: the kernel declines and yh_conv_igemm takes another family)
     acc0 = torch.full((B, H, W, ldo), 5.0, dtype=torch.bfloat16, device=dev)
     acc0[..., 8:8 + N] = _nhwc(B, H, W, N, dev, 320)
     acc = acc0.clone()
     d3 = desc(acc, bias=bias, accumulate=1)
-    assert f"conv_pt_kernel<{C0}, {C1}, 2>" in _kname(d3)
+    if C0 + C1 == 512:
+        assert "conv_pt_kernel" not in _kname(d3)
+    else:
+        assert f"conv_pt_kernel<{C0}, {C1}, 4>" in _kname(d3)
     hipk.conv_launch(d3)
     torch.cuda.synchronize()
     _close(acc[..., 8:8 + N], (ref + bias).to(torch.bfloat16).float() + acc0[..., 8:8 + N].float(), 1e-2, 4e-2)
     assert (acc[..., :8] == 5.0).all() and (acc[..., 8 + Nr:] == 5.0).all()
+    # ... and with a residual (EPI 4: the residual in the slots)
+    if C0 + C1 != 512:
+        rs = _nhwc(B, H, W, Nr, dev, 325)
+        outr = torch.full((B, H, W, ldo), 5.0, dtype=torch.bfloat16, device=dev)
+        d5 = desc(outr, bias=bias, res=hipk.full(rs))
+        assert f"conv_pt_kernel<{C0}, {C1}, 4>" in _kname(d5)
+        hipk.conv_launch(d5)
+        torch.cuda.synchronize()
+        _close(outr[..., 8:8 + N], (ref + bias) + rs[..., :N].float(), 1e-2, 4e-2)
+        assert (outr[..., :8] == 5.0).all() and (outr[..., 8 + Nr:] == 5.0).all()
     if N % 8 or C1 or ups0 or ups1 or C0 + C1 == 512:          # (512 channels: no fused-reduction form, csrc/conv_pt.hip pt_plan)
         return
     # (4) the data-gradient form of a 1x1 layer IS this GEMM (gy [M][Ct] x W^T): fused BatchNorm-backward reduction, plain store and
@@ -1362,10 +1384,20 @@ def test_conv_pointwise_kernel_320_channels_inference(dev, B, H, W, N):
     res = _nhwc(B, H, W, N, dev, 920)
     out.fill_(5.0)
     d2 = hipk.conv_desc(segs, hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, N, hipk.Slice(out, 8, N), scale=scale, shift=shift,
-                        act=hipk.YH_ACT_SILU, res=hipk.full(res))
+                        act=hipk.YH_ACT_SILU)
     d2.algo = 13
     assert "conv_pt_kernel<320, 0, 2>" in _kname(d2), _kname(d2)
     hipk.conv_launch(d2)
+    torch.cuda.synchronize()
+    _close(out[..., 8:8 + N], F.silu(ref * scale + shift), 1e-2, 4e-2)
+    assert (out[..., :8] == 5.0).all() and (out[..., 8 + N:] == 5.0).all()
+    # with a residual the 320-channel form declines (no LDS left for the operand slots): another family takes the layer, same result
+    out.fill_(5.0)
+    d2r = hipk.conv_desc(segs, hipk.YH_CONV_FWD, B, H, W, H, W, 1, 1, 0, wp, N, hipk.Slice(out, 8, N), scale=scale, shift=shift,
+                         act=hipk.YH_ACT_SILU, res=hipk.full(res))
+    d2r.algo = 13
+    assert "conv_pt_kernel" not in _kname(d2r), _kname(d2r)
+    hipk.conv_launch(d2r)
     torch.cuda.synchronize()
     _close(out[..., 8:8 + N], F.silu(ref * scale + shift).to(torch.bfloat16).float() + res.float(), 1e-2, 4e-2)
     assert (out[..., :8] == 5.0).all() and (out[..., 8 + N:] == 5.0).all()

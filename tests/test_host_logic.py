@@ -394,3 +394,8 @@ def test_conv_pt_kernel_has_no_register_spills(tmp_path):
     assert len(kernels) >= 20, len(kernels)
     bad = [(k, n) for k, n in kernels if int(n) != 0]
     assert not bad, bad
+    # nothing in flight may be held in a register the compiler knows as a C value: every inline-asm load of this file is an LDS-DMA
+    # transfer (round 5: operands loaded into registers by asm and "tied" to their wait were copied by the compiler in front of it)
+    asm_loads = re.findall(r";;#ASMSTART\n((?:(?!;;#ASMEND).)*?buffer_load_dword\S*[^\n]*)", text, flags=re.S)
+    assert asm_loads and all(ln.strip().endswith(" lds") for blk in asm_loads for ln in blk.split("\n") if "buffer_load" in ln), \
+        [ln for blk in asm_loads for ln in blk.split("\n") if "buffer_load" in ln and not ln.strip().endswith(" lds")][:3]

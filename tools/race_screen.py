@@ -92,9 +92,10 @@ def screen(reps=6, sub="", verbose=True, beside=False):
                 if torch.isnan(out0[..., :n0].float()).any():
                     diffs.append(("nan in first launch", int(torch.isnan(out0[..., :n0].float()).sum())))
             else:
-                for a, b in zip(first, cur):
+                for ti, (a, b) in enumerate(zip(first, cur)):
                     if not torch.equal(a, b):
-                        diffs.append((r, int((a != b).sum())))
+                        ne = torch.nonzero((a != b).reshape(-1)).flatten()
+                        diffs.append((r, f"tensor {ti} of {len(cur)} ({tuple(a.shape)})", int(ne.numel()), ne[:8].tolist()))
                         break
         if diffs:
             bad_entries.append((key, name, diffs))

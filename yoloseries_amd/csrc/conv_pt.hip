@@ -23,10 +23,15 @@
 //     group's staging area as 8-byte stores and leaves as whole 16-byte chunks;
 //   * wave w multiplies the 32 pixels by its 32 output channels: C / 16 v_mfma_f32_32x32x16_bf16 with one fragment read each;
 //   * epilogues work on the staged chunks: EPI 1 the per-channel BatchNorm partial sums (two registers per thread for the whole
-//     launch, reduced once at the end into the slab row of the workgroup), EPI 2 bias / folded BN / SiLU / residual / accumulate,
-//     EPI 3 the fused BatchNorm-backward reduction of a data gradient (z and the residual are requested one tile ahead, in two
-//     register sets used alternately — the loop is unrolled by two so no set is ever copied).  EPI 3 is not built for 512 input
-//     channels (128 weight registers + the operand sets spill; pt_plan declines, tests/test_host_logic.py checks the binary).
+//     launch, reduced once at the end into the slab row of the workgroup), EPI 2 bias / folded BN / SiLU, EPI 4 the same with a
+//     residual and / or an accumulating store, EPI 3 the fused BatchNorm-backward reduction of a data gradient.  The operands
+//     EPI 3 / 4 take from memory (z, the residual, the output's earlier contents) are requested one tile ahead BY LDS-DMA into a
+//     slot of the requesting wave (every lane fetches the 16 bytes its own thread will consume, two slot sets used alternately)
+//     and read back behind the wave's own counted wait.  They are never held in registers while in flight: the first form loaded
+//     them into registers by inline asm and tied the wait to those registers — and the compiler, free to copy a value it
+//     believes defined, copied them to other registers IN FRONT of the wait in one branch of the loop (round 5: one slab row of
+//     the fused reduction differed in 1 of ~60 launches on some boxes; tools/race_screen.py).  EPI 3 / 4 are not built for 512 and
+//     320 input channels (no LDS left for the slots; pt_plan declines).
 // The output-channel groups of a pixel slot are consecutive workgroups of one XCD (ids b, b + 8, ...): they walk the same tiles at
 // the same time and the second read of a tile comes from that XCD's L2.  Chosen per layer by the engine's timing
 // (yh_conv_desc.algo 13); the same arithmetic as the ring kernels (fp32 accumulation over the channels in the same order).
@@ -73,11 +78,15 @@ struct PtCfg {
     static constexpr int STAGE_OFF = PT_NBUF * A_BYTES;
     static constexpr int STAGE_BYTES = PT_TM * PT_CP * 2;                     // the output tile
     static constexpr int CONST_OFF = STAGE_OFF + 2 * STAGE_BYTES;
-    static constexpr int SMEM = CONST_OFF + 3 * PT_TN * 4;
+    static constexpr int OPS_OFF = CONST_OFF + 3 * PT_TN * 4;                 // EPI 3 / 4: [wave 0..7][set 0..1][4 transfers of 1 KiB]
+    static constexpr int OPS_BYTES = 8 * 2 * 4 * 1024;
+    static constexpr int SMEM = OPS_OFF;                                      // without / with (SMEM_OPS) the operand slots
+    static constexpr int SMEM_OPS = OPS_OFF + OPS_BYTES;
     static_assert((CS0 == 64 || CS0 == 128 || CS0 == 256 || CS0 == 512 || (CS0 == 320 && CS1 == 0)) && (CS1 == 0 || CS1 == CS0) && (CT == 128 || CT == 256 || CT == 512 || CT == 320), "segment widths");
     static_assert((CS0 * 2) % 128 == 0 && (PT_TM * CS0 * 2) % 4096 == 0, "whole 16-byte chunk groups of 8 per row; whole transfers per wave");
     static_assert(NI0 >= 1 && (CS1 == 0 || NI1 >= 1) && SMEM <= 160 * 1024, "LDS budget");
     static_assert(PT_NT * 16 * 4 <= PT_NBUF * A_BYTES, "the final reduction of EPI 3 runs in the pixel buffers");
+    static constexpr bool OPS_FIT = SMEM_OPS <= 160 * 1024;
 };
 
 __device__ __forceinline__ bf16x8_t pt_lds16(const unsigned char* p) {
@@ -94,16 +103,6 @@ typedef unsigned int pt_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void pt_dma(unsigned lds, unsigned voff, const __amdgpu_buffer_rsrc_t rs, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
-// a 16-byte load into registers whose arrival the CALLER waits for (pt_wait) before the first use
-__device__ __forceinline__ pt_u32x4 pt_aload(const __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-    pt_u32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
-    return v;
-}
-// s_waitcnt vmcnt(N) tied to the registers it makes valid: their uses cannot be scheduled ahead of it
-template <int N> __device__ __forceinline__ void pt_wait(pt_u32x4& a, pt_u32x4& b, pt_u32x4& c, pt_u32x4& d) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
 __device__ __forceinline__ uint4 pt_u4(const pt_u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
 // A 16-byte store with a SCALAR tile offset.  Inline asm with its own wait states: behind the builtin form the compiler placed a
 // VALU write of the first data register directly behind the store (its hazard table exempts buffer stores of more than 64 bits
@@ -116,7 +115,8 @@ __device__ __forceinline__ void pt_bstore(const __amdgpu_buffer_rsrc_t rs, unsig
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(w), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
-// EPI 0: plain store, 1: + BatchNorm partial sums, 2: generic epilogue, 3: data gradient + fused BatchNorm-backward reduction
+// EPI 0: plain store, 1: + BatchNorm partial sums, 2: bias / folded BN / SiLU, 3: data gradient + fused BatchNorm-backward reduction,
+// 4: as 2 with a residual and / or an accumulating store (operands from memory)
 template <int CS0, int CS1, int EPI>
 __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
 {
@@ -130,7 +130,9 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
     // per output chunk for EPI 2 / 3), [wait for this tile's operand loads] the output stores (NST).  A wait for X is
     // vmcnt(number of instructions issued behind X): completion is in issue order.
     constexpr int NST = NOI;
-    constexpr int NLD = EPI >= 2 ? 2 * NOI : 0;
+    constexpr bool OPS = EPI == 3 || EPI == 4;
+    constexpr bool GEN = EPI == 2 || EPI == 4;
+    constexpr int NLD = OPS ? 2 * NOI : 0;
     static_assert(NOI == 2 && NBUF == 4, "thread -> (row, chunk) map of the store phase; two groups x two ring buffers");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
     const int J = (K + 1) >> 1;
 
     // per-channel constants first: their loads are consumed here, ahead of every transfer (a later wait for them would drain the ring)
-    if (EPI == 2) {
+    if (GEN) {
         for (int i = t; i < 3 * TN; i += PT_NT) {
             const int which = i / TN, c = i - which * TN;
             const float* src = which == 0 ? p.bias : (which == 1 ? p.scale : p.shift);
@@ -261,16 +263,22 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
     };
     // scalar byte offset of a tile's first row (a tile past the end: 0 — every lane is out of range there and the product could wrap)
     auto tile_so = [&](int tl, unsigned ld2) -> unsigned { return tl < p.ntiles ? (unsigned)(tl * TM) * ld2 : 0u; };
-    // epilogue operands from memory per output chunk: a = z (EPI 3) / the residual (EPI 2), o = the output's earlier contents
-    // (accumulate).  An operand that is not in use is still requested, with an out-of-range offset (zeros, no memory access): NLD constant
-    struct Ops { pt_u32x4 a[NOI], o[NOI]; };
-    auto load_ops = [&](int tl, Ops& q) {
-        if (EPI < 2) return;
+    // epilogue operands from memory per output chunk: a = z (EPI 3) / the residual (EPI 4), o = the output's earlier contents
+    // (accumulate), by LDS-DMA into the wave's slot set `set`: transfer 2 it (a) and 2 it + 1 (o) of the set, every lane the 16 bytes
+    // its own thread consumes.  An operand that is not in use is still requested, with an out-of-range offset (zeros, no memory
+    // access): NLD is a constant.
+    const unsigned ops0 = lds0 + G::OPS_OFF + wave8 * (2 * 4 * 1024);
+    auto load_ops = [&](int tl, int set) {
+        if (!OPS) return;
 #pragma unroll
         for (int it = 0; it < NOI; ++it) {
-            q.a[it] = pt_aload(EPI == 3 ? rsz : rsr, tile_off(tl, it, ac[it]), tile_so(tl, a_ld2));
-            q.o[it] = pt_aload(rso0, p.accumulate ? tile_off(tl, it, oc[it]) : PT_OOB, tile_so(tl, (unsigned)(p.ldo0 * 2)));
+            pt_dma(ops0 + (set * 4 + 2 * it) * 1024, tile_off(tl, it, ac[it]), EPI == 3 ? rsz : rsr, tile_so(tl, a_ld2));
+            pt_dma(ops0 + (set * 4 + 2 * it + 1) * 1024, p.accumulate ? tile_off(tl, it, oc[it]) : PT_OOB, rso0, tile_so(tl, (unsigned)(p.ldo0 * 2)));
         }
+    };
+    // the thread's own 16 bytes of transfer `slot` of a set (read only behind the wave's wait for that set's transfers)
+    auto ops_rd = [&](int set, int slot) -> uint4 {
+        return *reinterpret_cast<const uint4*>(smem + G::OPS_OFF + wave8 * (2 * 4 * 1024) + (set * 4 + slot) * 1024 + lane * 16);
     };
     auto tile_of = [&](int k) -> int { return bx + k * p.gx; };
 
@@ -282,16 +290,14 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
     {
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
         const unsigned wv = (unsigned)(((n0 + wave * 32 + r31) * CT + kq * 8) * 2);
+        // ordinary (compiler-visible) loads: the compiler waits for them where they are first used — in front of the loop, beside the
+        // first tiles' transfers, once per workgroup
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) wreg[ks] = pt_aload(rsw, wv + ks * 32, 0u);
+        for (int ks = 0; ks < NKS; ++ks) wreg[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wv + ks * 32, 0, 0);
     }
     issue_A(tile_of(grp), grp);
     issue_A(tile_of(grp + 2), grp + 2);
-    Ops opsA, opsB;                   // epilogue operands of the tile in work / of the group's next one: two register sets used in turn
-    load_ops(tile_of(grp), opsA);
-    static_assert(NKS % 4 == 0, "waits in groups of four");
-#pragma unroll
-    for (int ks = 0; ks < NKS; ks += 4) pt_wait<2 * NAI + NLD>(wreg[ks], wreg[ks + 1], wreg[ks + 2], wreg[ks + 3]);
+    load_ops(tile_of(grp), 0);        // epilogue operands of the group's first tile: slot set 0 (tile j of the group: set j & 1)
     YH_LDS_BARRIER();                 // sConst published
 
     // fragment read offsets: row lane & 31 of the sub-image, chunk 2 ks + (lane >> 5)
@@ -308,7 +314,8 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
     if (grp == 1) YH_LDS_BARRIER();
     int j = 0;
 #define PT_STAMP(I) do { if (p.stamps && j == 4 && lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave8) * 8 + (I)] = __builtin_amdgcn_s_memtime(); } while (0)
-    auto one_tile = [&](Ops& cur, Ops& nxt) {
+    auto one_tile = [&]() {
+        const int cset = j & 1;
         const int k = grp + 2 * j;
         const int tile = tile_of(k);
         const int pb = k & (NBUF - 1);
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int c = wave * 32 + 8 * g4 + 4 * kq;
                 float v[4] = {acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]};
-                if (EPI == 2) {
+                if (GEN) {
                     const float4 cb = *reinterpret_cast<const float4*>(sConst + c), cs = *reinterpret_cast<const float4*>(sConst + TN + c),
                                  ct = *reinterpret_cast<const float4*>(sConst + 2 * TN + c);
                     v[0] = (v[0] + cb.x) * cs.x + ct.x; v[1] = (v[1] + cb.y) * cs.y + ct.y;
@@ -364,10 +371,14 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
         YH_LDS_BARRIER();
         PT_STAMP(5);
         issue_A(tile_of(k + 4), pb);                 // the group's tile after next, into the buffer just consumed (past the end: a dummy of zeros)
-        load_ops(tile_of(k + 2), nxt);
-        if (EPI >= 2) {                              // this tile's operands: behind them the previous tile's stores and this round's NAI + NLD
-            if (j == 0) pt_wait<NAI + NLD>(cur.a[0], cur.a[1], cur.o[0], cur.o[1]);
-            else        pt_wait<NST + NAI + NLD>(cur.a[0], cur.a[1], cur.o[0], cur.o[1]);
+        load_ops(tile_of(k + 2), cset ^ 1);
+        uint4 opa[NOI], opo[NOI];
+        if (OPS) {
+            // this tile's operands have landed: behind them were issued (at least) this round's NAI + NLD transfers — from the
+            // second round on also the previous tile's stores, which the one count simply waits for as well
+            YH_VMCNT(NAI + NLD);
+#pragma unroll
+            for (int it = 0; it < NOI; ++it) { opa[it] = ops_rd(cset, 2 * it); opo[it] = ops_rd(cset, 2 * it + 1); }
         }
         PT_STAMP(6);
         // ---- whole 16-byte chunks to memory (a round without a tile: every offset is out of range, the stores still count)
@@ -382,18 +393,18 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { bs_[e] += f[e]; bq_[e] += f[e] * f[e]; }
             }
-            if (EPI == 2) {
+            if (EPI == 4) {
                 const bool addres = p.res != nullptr;
                 if (addres || p.accumulate) {
                     float f[8];
                     unpack8(v, f);
                     if (addres) {
-                        float g2[8]; unpack8(pt_u4(cur.a[it]), g2);
+                        float g2[8]; unpack8(opa[it], g2);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] += g2[e];
                     }
                     if (p.accumulate) {
-                        float g2[8]; unpack8(pt_u4(cur.o[it]), g2);
+                        float g2[8]; unpack8(opo[it], g2);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[e] += g2[e];
                     }
@@ -407,13 +418,13 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
                     // last writer of a gradient with several contributions: add the earlier ones (bf16, as the generic epilogue does) and
                     // take the BatchNorm-backward sums over the rounded total
                     float g0[8];
-                    unpack8(pt_u4(cur.o[it]), g0);
+                    unpack8(opo[it], g0);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) g[e] += g0[e];
                     v = pack8(g);
                     unpack8(v, g);
                 }
-                unpack8(pt_u4(cur.a[it]), z);
+                unpack8(opa[it], z);
                 if (oo != PT_OOB) {
                     float zs[8], zh[8];                  // scale | shift of the producer's BatchNorm for this thread's 8 channels
                     *reinterpret_cast<float4*>(zs) = *reinterpret_cast<const float4*>(sConst + cch * 8);
@@ -435,12 +446,7 @@ __global__ __launch_bounds__(PT_NT, 1) void conv_pt_kernel(const PtK p)
         ++j;
     };
 #undef PT_STAMP
-    while (true) {
-        one_tile(opsA, opsB);
-        if (j >= J) break;
-        one_tile(opsB, opsA);
-        if (j >= J) break;
-    }
+    while (j < J) one_tile();
     if (grp == 0) YH_LDS_BARRIER();
 
     // ---- the partial sums of the workgroup: the two groups hold the same channels (EPI 1) / chunks (EPI 3)
@@ -497,7 +503,9 @@ bool pt_plan(const yh_conv_desc* d, PtPlan* pl)
     const bool generic_na = d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res;
     const bool generic = generic_na || d->accumulate;
     if (generic && d->stats) return false;
-    if (Ct == 512 && d->bnr_part) return false;          // 512 channels: the weight slice alone is 128 registers — the fused-reduction epilogue does not fit beside it
+    // 512 / 320 channels: no LDS left for the operand slots of the epilogues that read memory (fused reduction, residual, accumulate);
+    // at 512 the weight slice alone is 128 registers
+    if ((Ct == 512 || Ct == 320) && (d->bnr_part || d->res || d->accumulate)) return false;
     if (d->bnr_part && (generic_na || d->stats || d->mode != YH_CONV_DGRAD || d->N % 8 || !d->bnr_z || !d->bnr_ws || d->bnr_C < d->N || d->bnr_ldz % 8)) return false;
     const unsigned long Nr = (unsigned long)(d->N + 7) / 8 * 8;
     const unsigned long n0r = Nr;
@@ -524,7 +532,7 @@ bool pt_plan(const yh_conv_desc* d, PtPlan* pl)
     k.ntiles = (int)((M + PT_TM - 1) / PT_TM);
     k.gy = (d->N + PT_TN - 1) / PT_TN;
     pl->cs0 = C0; pl->cs1 = C1;
-    pl->epi = d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0));
+    pl->epi = d->bnr_part ? 3 : ((d->res || d->accumulate) ? 4 : (generic ? 2 : (d->stats ? 1 : 0)));
     // persistent blocks: one resident round (one workgroup of eight waves per CU), pixel slots in multiples of 8
     int cap = (256 / k.gy) & ~7;
     if (cap < 8) cap = 8;
@@ -565,21 +573,27 @@ int yh_pt_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
     const dim3 grid(pl.grid), blk(PT_NT);
 #define YH_LAUNCH_PT(A_, B_)                                                                                            \
     do {                                                                                                                \
-        constexpr int sm = PtCfg<A_, B_>::SMEM;                                                                          \
-        constexpr int E3 = (A_) + (B_) == 512 ? 0 : 3;      /* not instantiated for 512 channels (pt_plan) */            \
+        constexpr int sm = PtCfg<A_, B_>::SMEM, smo = PtCfg<A_, B_>::SMEM_OPS;                                           \
+        constexpr bool OK_ = PtCfg<A_, B_>::OPS_FIT;        /* 512 channels: the forms with memory operands are not built (pt_plan) */ \
+        constexpr int E3 = OK_ ? 3 : 0, E4 = OK_ ? 4 : 2;                                                                \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
             (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
             (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
             (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, E3>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            if (OK_) {                                                                                                  \
+                (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, E3>, hipFuncAttributeMaxDynamicSharedMemorySize, smo); \
+                (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, E4>, hipFuncAttributeMaxDynamicSharedMemorySize, smo); \
+            }                                                                                                           \
             attr_set = true;                                                                                            \
         }                                                                                                               \
+        YH_CHECK_ARG(OK_ || pl.epi < 3, "yh_conv_igemm(pt): no operand slots for this width");                          \
         switch (pl.epi) {                                                                                               \
         case 0: conv_pt_kernel<A_, B_, 0><<<grid, blk, sm, st>>>(pl.k); break;                                          \
         case 1: conv_pt_kernel<A_, B_, 1><<<grid, blk, sm, st>>>(pl.k); break;                                          \
         case 2: conv_pt_kernel<A_, B_, 2><<<grid, blk, sm, st>>>(pl.k); break;                                          \
-        default: conv_pt_kernel<A_, B_, E3><<<grid, blk, sm, st>>>(pl.k); break;                                        \
+        case 3: conv_pt_kernel<A_, B_, E3><<<grid, blk, smo, st>>>(pl.k); break;                                        \
+        default: conv_pt_kernel<A_, B_, E4><<<grid, blk, smo, st>>>(pl.k); break;                                       \
         }                                                                                                               \
     } while (0)
     if (pl.cs1 == 0 && pl.cs0 == 320) {
@@ -590,6 +604,7 @@ int yh_pt_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
             (void)hipFuncSetAttribute((const void*)conv_pt_kernel<320, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
             attr_set = true;
         }
+        YH_CHECK_ARG(pl.epi == 0 || pl.epi == 2, "yh_conv_igemm(pt): 320 channels: plain / bias-BN-SiLU epilogues only");
         if (pl.epi == 2) conv_pt_kernel<320, 0, 2><<<grid, blk, sm, st>>>(pl.k);
         else             conv_pt_kernel<320, 0, 0><<<grid, blk, sm, st>>>(pl.k);
     }
