@@ -381,6 +381,60 @@ def test_fuse_conv_bn_matches_reference_fixture():
     np.testing.assert_allclose(fused.bias.numpy(), g["fuse_b"], rtol=1e-6, atol=1e-7)
 
 
+def _asm_pending_reads(text):
+    """compiler-generated instructions that read a register an inline-asm load (ds_read / buffer_load into registers) has written,
+    in front of the next inline-asm s_waitcnt of the load's counter: [(kernel, line, instruction)]"""
+    def regs(tok):
+        out = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1)) if m.group(1) else {int(m.group(3))}
+        return out
+    hits, in_asm, pend, kern = [], False, {}, ""
+    for i, ln in enumerate(text.split("\n")):
+        t = ln.strip()
+        if re.match(r"^_Z\w+:", ln):
+            kern, pend = ln.split(":")[0], {}
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not ln.startswith("\t") or t.startswith((".", ";")):
+            continue
+        if in_asm:
+            m = re.match(r"(ds_read\w*|buffer_load_dword\w*)\s+(\S+),", t)
+            if m and not t.endswith(" lds"):
+                for r in regs(m[2]):
+                    pend[r] = "lgkm" if m[1].startswith("ds_") else "vm"
+            if t.startswith("s_waitcnt"):
+                pend = {r: c for r, c in pend.items() if not ((c == "lgkm" and "lgkmcnt" in t) or (c == "vm" and "vmcnt" in t))}
+        elif pend:
+            parts = t.split(None, 1)
+            if len(parts) == 2 and parts[0].startswith(("v_", "ds_", "buffer_", "global_")):
+                ops = parts[1].split(",")
+                srcs = parts[1] if parts[0].startswith(("buffer_store", "global_store", "ds_write", "v_cmp")) else ",".join(ops[1:])
+                if regs(srcs) & set(pend):
+                    hits.append((kern, i, t))
+    return hits
+
+
+def test_inline_asm_loads_are_not_read_before_their_wait(tmp_path):
+    """conv_halo160_kernel requests its fragments by inline-asm ds_read and waits for them by an inline-asm s_waitcnt tied to the
+    destination registers.  The compiler believes those registers defined at the ds_read: should it ever copy or use one in front
+    of the wait (it did exactly that to conv_pt_kernel's operand loads in round 5), the copy holds stale bytes.  The generated
+    code of every kernel of conv_igemm.hip is scanned: no compiler-generated instruction reads such a register before the wait."""
+    import subprocess
+    src = os.path.join(ROOT, "yoloseries_amd", "csrc", "conv_igemm.hip")
+    out = tmp_path / "igemm.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "--cuda-device-only", "-S",
+                    "-o", str(out), src], check=True, capture_output=True)
+    text = out.read_text()
+    assert "conv_halo160_kernel" in text and len(re.findall(r";;#ASMSTART\n\s*ds_read_b128", text)) >= 10
+    hits = _asm_pending_reads(text)
+    assert not hits, hits[:5]
+
+
 def test_conv_pt_kernel_has_no_register_spills(tmp_path):
     """conv_pt_kernel counts its vector-memory instructions by hand (s_waitcnt vmcnt(N) with compile-time N): a register spill would add
     scratch loads / stores the counts do not know about.  Every instantiation the library launches must compile without scratch."""
