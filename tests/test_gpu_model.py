@@ -491,6 +491,64 @@ def test_program_executor_matches_per_launch_calls(dev):
     assert (g1 - g0).abs().max() <= 1e-4 * g0.abs().max()
 
 
+@pytest.mark.parametrize("name", ["v5s", "v5l", "yolox"])
+def test_step_deterministic_parts_bit_identical_at_judged_shape(dev, name):
+    """Forward and the backward's main chain are deterministic (fixed-order reductions; only the weight gradients use fp32 atomics):
+    at the judged shape (batch 64, 640 x 640, the shipped launch parameters) five forward + backward passes of one model on one
+    input give bit-identical head outputs, loss and BatchNorm weight / bias gradients — those depend on every data-gradient, every
+    BatchNorm-backward pass and every fused reduction of the chain, so a synchronisation error anywhere in it shows here on any
+    box (round 5: conv_pt_kernel's fused reduction differed in ~1 of 60 launches on some boxes)."""
+    from yoloseries_amd import models
+    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
+    import bench
+    B, img = 64, 640
+    torch.manual_seed(0)
+    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(11)).to(dev)
+    t = torch.from_numpy(synth_targets(B, img, 80, 12, seed=12, min_boxes=2)).to(dev)
+    if name in ("v5s", "v5l"):
+        from yoloseries_amd.loss import YOLOV5Loss
+        m = (models.YOLOV5Small if name == "v5s" else models.YOLOV5Large)(3, 80).to(dev).train()
+        # (a fresh loss object per pass: YOLOV5Loss carries the running `balances` of the stages from call to call)
+        make_loss = lambda: YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), bench.make_hyp(dev, img, B))      # noqa: E731
+    else:
+        from yoloseries_amd.loss import YOLOXLoss
+        m = models.YOLOXSmall(1, 3, 80).to(dev).train()
+        make_loss = lambda: YOLOXLoss(dict(device=dev, num_class=80, input_img_size=[img, img], batch_size=B, use_focal_loss=False, focal_loss_gamma=1.5,
+                               focal_loss_alpha=0.25, iou_loss_scale=5.0, use_l1=True, l1_loss_scale=1.0, cls_loss_scale=1.0,
+                               cof_loss_scale=1.0, class_smooth_factor=1.0, cls_pos_weight=1.0, cof_pos_weight=1.0, num_anchors=1,
+                               iou_type="ciou", topk=13, center_radius=3, num_stage=3, loss_items_on_device=True))      # noqa: E731
+    bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+    assert len(bns) >= 50
+    first = None
+    for r in range(5):
+        for p_ in m.parameters():
+            p_.grad = None
+        outs = m(x)
+        loss = make_loss()(outs, t.clone())["tot_loss"]
+        loss.backward()
+        torch.cuda.synchronize()
+        flat = []
+
+        def walk(o):
+            if torch.is_tensor(o):
+                flat.append(o.detach().clone())
+            elif isinstance(o, dict):
+                for v in o.values():
+                    walk(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v)
+        walk(outs)
+        assert len(flat) >= 3
+        cur = flat + [loss.detach().clone()] + [b.weight.grad.clone() for b in bns] + [b.bias.grad.clone() for b in bns]
+        if first is None:
+            first = cur
+            assert all(torch.isfinite(c.float()).all() for c in cur)
+        else:
+            bad = [i for i, (a, b) in enumerate(zip(first, cur)) if not torch.equal(a, b)]
+            assert not bad, f"pass {r}: tensors {bad[:6]} of {len(cur)} differ from the first pass (0..{len(flat) - 1} outputs, {len(flat)} loss, then BatchNorm gradients)"
+
+
 def test_grouped_weight_gradients_in_the_backward(dev):
     """YH_WGS_GROUP (engine.flags.WGS_GROUP, default off): the weight gradients of up to eight consecutive launches of the backward
     leave in one yh_conv_wgrad_group launch — pinned gz buffers, one shared event per group, gradient-arena marks held back behind
