@@ -70,7 +70,10 @@ def test_graph_replay_matches_eager(dev):
     # the first steps must agree tightly, the later ones inside three to five times that run-to-run spread
     # (the tight comparison — 1e-3 over all steps, exact device scalars — is test_graph_replay_matches_eager_deterministic below; this
     # one runs the DEFAULT kernels, whose weight gradients sum partial tiles with fp32 atomics in arrival order)
-    np.testing.assert_allclose(l1[:2], l0[:2], rtol=2e-3)
+    # (step 0 runs on identical weights through deterministic kernels: equal; step 1 already sees the first update's atomics order —
+    # 0.26 % was observed once in ~10 runs of the suite)
+    np.testing.assert_allclose(l1[:1], l0[:1], rtol=1e-6)
+    np.testing.assert_allclose(l1[:2], l0[:2], rtol=1e-2)
     np.testing.assert_allclose(l1, l0, rtol=2e-1)
     assert np.abs(p1 - p0).max() <= 3e-2 * np.abs(p0).max()
     assert np.abs(e1 - e0).max() <= 3e-3 * np.abs(e0).max() + 1e-7
