@@ -51,6 +51,17 @@ def _rand_bf16(shape, dev, seed, scale=1.0):
     return (torch.randn(*shape, generator=g, device=dev) * scale).to(torch.bfloat16)
 
 
+def _tap_views(x_nhwc, k, stride, pad, Ho, Wo):
+    """[(kh, kw, X_tap)]: X_tap [B * Ho * Wo][C] = the input pixel every output pixel reads through tap (kh, kw) (zero outside the map):
+    a k x k convolution / its weight gradient as k * k fp32 matmuls — the same contraction as torch's convolution, without its
+    per-shape algorithm search (the reference of a 3 x 3 weight gradient took 2-3 s that way)"""
+    B, H, W, Cc = x_nhwc.shape
+    xp = F.pad(x_nhwc, (0, 0, pad, pad, pad, pad))
+    for kh in range(k):
+        for kw in range(k):
+            yield kh, kw, xp[:, kh:kh + stride * (Ho - 1) + 1:stride, kw:kw + stride * (Wo - 1) + 1:stride, :].reshape(-1, Cc)
+
+
 def _close(got, ref, rtol, atol, what):
     err = (got.float() - ref).abs()
     bad = err > atol + rtol * ref.abs()
@@ -138,9 +149,12 @@ def test_conv_entries_at_judged_shapes(dev, chunk):
         else:
             parts = []
             for si in range(nseg):
-                x = xs[si][..., :segC[si]].float().permute(0, 3, 1, 2)
-                parts.append(F.interpolate(x, scale_factor=2, mode="nearest") if segups[si] else x)
-            ref = F.conv2d(torch.cat(parts, 1), w, None, stride=stride, padding=pad).permute(0, 2, 3, 1)
+                x = xs[si][..., :segC[si]].float()
+                parts.append(x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2) if segups[si] else x)
+            ref = torch.zeros(B * Ho * Wo, N, device=dev)
+            for kh, kw, xt in _tap_views(torch.cat(parts, 3), k, stride, pad, Ho, Wo):
+                ref.addmm_(xt, w[:, :, kh, kw].t())
+            ref = ref.reshape(B, Ho, Wo, N)
         if accumulate:
             ref = ref.to(torch.bfloat16).float() + out0[..., :N].float()
         torch.cuda.synchronize()
@@ -260,9 +274,12 @@ def test_eval_entries_at_judged_shapes(dev, chunk):
             else:
                 parts = []
                 for si in range(nseg):
-                    x = xs[si][b0:b1, ..., :segC[si]].float().permute(0, 3, 1, 2)
-                    parts.append(F.interpolate(x, scale_factor=2, mode="nearest") if segups[si] else x)
-                ref = F.conv2d(torch.cat(parts, 1), w, None, stride=stride, padding=pad).permute(0, 2, 3, 1)
+                    x = xs[si][b0:b1, ..., :segC[si]].float()
+                    parts.append(x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2) if segups[si] else x)
+                ref = torch.zeros((b1 - b0) * Ho * Wo, N, device=dev)
+                for kh, kw, xt in _tap_views(torch.cat(parts, 3), k, stride, pad, Ho, Wo):
+                    ref.addmm_(xt, w[:, :, kh, kw].t())
+                ref = ref.reshape(b1 - b0, Ho, Wo, N)
             ref = F.silu(ref * sc + sh)
             if rs is not None:
                 ref[..., :n0] += rs[b0:b1].float()
@@ -319,11 +336,14 @@ def test_wgrad_entries_at_judged_shapes(dev, chunk):
             rw = (gz_ref.reshape(-1, N).t() @ xf.reshape(-1, C0)).reshape(N, 1, 1, C0)
             xin = xf
         else:
-            xin = x[..., :C0].float().permute(0, 3, 1, 2)
+            xin = x[..., :C0].float()
             if ups:
-                xin = F.interpolate(xin, scale_factor=2, mode="nearest")
-            rw = torch.nn.grad.conv2d_weight(xin, (N, C0, k, k), gz_ref.permute(0, 3, 1, 2), stride=stride, padding=pad)
-            rw = rw.permute(0, 2, 3, 1)                          # [N][kh][kw][C0]
+                xin = xin.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+            rw = torch.empty(N, k, k, C0, device=dev)            # [N][kh][kw][C0]
+            gz2 = gz_ref.reshape(-1, N).t().contiguous()
+            for kh, kw, xt in _tap_views(xin, k, stride, pad, Ho, Wo):
+                rw[:, kh, kw, :] = gz2 @ xt
+            del gz2
         torch.cuda.synchronize()
         got = dw.view(N, k, k, Ctot)
         _close(got[..., coff:], rw, 1e-2, 1e-2 * rw.abs().max().item(), key)
