@@ -55,9 +55,10 @@ def _host_threads():
     return max(1, min(cores, 16))
 
 
-def _cpu_train_leg(batch, img, budget_s, max_steps):
-    """(median seconds per step, steps timed) of the torch-CPU fp32 oracle's train step at `batch`: 1 warm-up, then up to `max_steps`
-    timed steps inside the budget (at least one)"""
+def _cpu_train_leg(batch, img, budget_s, max_steps, min_steps=3):
+    """(median seconds per step, steps timed) of the torch-CPU fp32 oracle's train step at `batch`: 1 warm-up, then `min_steps` timed
+    steps whatever they take (a median needs more than one sample) and further ones, up to `max_steps`, while
+    the budget lasts"""
     from oracle.v5loss import V5LossOracle
     from oracle.v5net import V5NetOracle
     from yoloseries_amd import models
@@ -75,7 +76,7 @@ def _cpu_train_leg(batch, img, budget_s, max_steps):
         out["tot_loss"].backward()
         net.sgd_step(0.01)
         times.append(time.time() - t0)
-        if it >= 1 and time.time() - t_begin > budget_s:
+        if it >= min_steps and time.time() - t_begin > budget_s:
             break
     steady = times[1:] if len(times) > 1 else times
     return float(np.median(steady)), len(steady)
@@ -83,14 +84,15 @@ def _cpu_train_leg(batch, img, budget_s, max_steps):
 
 def cpu_baseline(budget_s=14.0, batch=64, img=640):
     """torch-CPU / NumPy fp32 port (oracle/) of the same path on a bounded sample, both legs of BASELINE.md section 4:
-    (fwd + loss + bwd + SGD) at the judged batch (64; 1 warm-up + up to 3 steps) and at BASELINE config #1's batch 4 (`batch4`), and
+    (fwd + loss + bwd + SGD) at the judged batch (64; 1 warm-up + 3 timed steps, ~1 minute of host time) and at BASELINE config #1's
+    batch 4 (`batch4`; 1 warm-up + 3..5 steps), and
     (decode + candidate filter + class-aware NMS on the synthetic NMS stress heads), each the median of its timed runs."""
     from oracle import postproc as opp
     from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_nms_heads
     cores = _host_threads()
     torch.set_num_threads(cores)
     sec4, nst4 = _cpu_train_leg(4, img, 0.25 * budget_s, 5)
-    sec, nst = _cpu_train_leg(batch, img, 0.75 * budget_s, 2) if batch != 4 else (sec4, nst4)
+    sec, nst = _cpu_train_leg(batch, img, 0.75 * budget_s, 3) if batch != 4 else (sec4, nst4)
     nbatch = 4
     # decode + filter + NMS (NumPy fp32, one thread: the reference's evaluator is a per-image Python / numba loop)
     heads = synth_nms_heads(nbatch, img, 80, 3, seed=2, wh_shift=1.2)

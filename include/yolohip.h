@@ -185,17 +185,6 @@ const char* yh_conv_wgrad_kernel_name2(int N, int Kseg, int tile_k);
  * tiles*splits is about one resident wave of blocks */
 int yh_conv_wgrad_tiles(int N, int Kseg);
 int yh_conv_wgrad_tiles2(int N, int Kseg, int tile_k);
-/* Several weight gradients of the wave-private form (tile_k 129, yh_conv_wgrad_wave_tiles() > 0 each) in ONE launch of
- * `workgroups` workgroups (one per CU; handed to the members in chunks of 8 in proportion to their (tile, 32 pixels) units,
- * `splits` of the members is ignored).  A launch of that form ends in one 64 KB set of fp32 atomics per workgroup — 12 us at 252
- * workgroups whatever the layer — behind a ring fill and a combine: a group pays them once.  The members' operands must all be
- * ready when the launch starts (the autograd order hands them over one layer at a time: the caller keeps the earlier members'
- * `gy` alive); results are those of n separate yh_conv_wgrad calls up to the order of the fp32 additions.
- * n in 1 .. yh_conv_wgrad_group_max(), workgroups in 8 n .. 4096.   Replaces the same autograd edges as yh_conv_wgrad
- * (train_yolov5.py:337 -> utils/layer_tools.py:82-94), for the layers of one C3 block at a time. */
-int yh_conv_wgrad_group(const yh_wgrad_desc* const* descs, int n, int workgroups, yh_stream stream);
-int yh_conv_wgrad_group_ok(const yh_wgrad_desc* const* descs, int n, int workgroups);
-int yh_conv_wgrad_group_max(void);
 
 /* ------------------------------------------------------------------------ *
  * BatchNorm (training statistics) + SiLU, forward and backward

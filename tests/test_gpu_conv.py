@@ -461,59 +461,6 @@ def _wgs_case(dev, case, seed):
     return d, dw, ref.permute(0, 2, 3, 1), (gyw, xw)
 
 
-@pytest.mark.parametrize("members,workgroups", [((0, 3, 4, 5, 7, 8, 10, 11), 256), ((3, 11), 16), ((1, 2, 9), 192), ((6,), 8),
-                                                ((3, 3, 3, 3, 3, 0, 0, 6), 250)])
-def test_conv_wgrad_group(dev, members, workgroups):
-    """yh_conv_wgrad_group: several layers of the wave-private form in ONE launch (pointwise and im2col members side by side,
-    every member on its own multiple-of-8 range of workgroups with its own stream-K plan and block map; a one-unit member
-    closes a group on fewer than 8 workgroups; 250: the remainder below 8 stays unused).  Every member's result against
-    fp32 torch with the bars of the single-layer test; columns of other segments untouched."""
-    import ctypes as C
-    from yoloseries_amd import hipk
-    from yoloseries_amd._lib import lib
-    built = [_wgs_case(dev, WGS_CASES[m], 30 + 2 * i) for i, m in enumerate(members)]
-    descs = [b[0] for b in built]
-    arr = hipk.wgrad_group_array(descs)
-    assert lib().yh_conv_wgrad_group_ok(arr, len(descs), workgroups) == 1
-    hipk.wgrad_group_launch(descs, workgroups)
-    torch.cuda.synchronize()
-    for m, (d, dw, ref, _keep) in zip(members, built):
-        B, H, W, Cin, Cout, k, s, coff, Ctot, ups = WGS_CASES[m]
-        got = dw.reshape(Cout, k, k, Ctot)
-        assert not torch.isnan(dw).any()
-        _close(got[..., coff:coff + Cin] - 0.5, ref, 2e-3, 2e-3 * ref.abs().max().item())
-        mask = torch.ones(Ctot, dtype=torch.bool, device=dev)
-        mask[coff:coff + Cin] = False
-        assert (got[..., mask] == 0.5).all()
-
-
-def test_conv_wgrad_group_eligibility(dev):
-    """a group refuses (YH_EINVAL, nothing launched): a member of another form, more members than yh_conv_wgrad_group_max(),
-    fewer than 8 workgroups per member, a member without tile_k 129"""
-    import ctypes as C
-    from yoloseries_amd import hipk
-    from yoloseries_amd._lib import lib, YoloHipError
-    L = lib()
-    good = [_wgs_case(dev, WGS_CASES[3], 50 + 2 * i) for i in range(9)]
-    descs = [g[0] for g in good]
-    assert L.yh_conv_wgrad_group_max() == 8
-    assert L.yh_conv_wgrad_group_ok(hipk.wgrad_group_array(descs[:8]), 8, 64) == 1
-    assert L.yh_conv_wgrad_group_ok(hipk.wgrad_group_array(descs), 9, 256) == 0
-    assert L.yh_conv_wgrad_group_ok(hipk.wgrad_group_array(descs[:3]), 3, 16) == 0
-    gy = _nhwc(2, 16, 16, 128, dev, 22)
-    x = _nhwc(2, 16, 16, 48, dev, 23)
-    dwb = torch.zeros(128, 9 * 48, device=dev)
-    bad = hipk.wgrad_desc(hipk.full(gy), 128, hipk.full(x), 0, 48, 2, 16, 16, 16, 16, 3, 1, 1, dwb, 4)      # 48 channels: not the wave form
-    bad.tile_k = 129
-    assert L.yh_conv_wgrad_group_ok(hipk.wgrad_group_array([descs[0], bad]), 2, 64) == 0
-    with pytest.raises(YoloHipError):
-        hipk.wgrad_group_launch([descs[0], bad], 64)
-    descs[1].tile_k = 0
-    assert L.yh_conv_wgrad_group_ok(hipk.wgrad_group_array(descs[:2]), 2, 64) == 0
-    torch.cuda.synchronize()
-    assert (dwb == 0).all() and all((g[1] == 0.5).all() for g in good)
-
-
 # ---- kernel families: the register-staged kernel (algo 1) and the LDS-DMA ring kernel with its three tiles (algo 2..4)
 V3_CASES = [
     # B, H, W, Cin, Cout, k, s, p

@@ -549,53 +549,6 @@ def test_step_deterministic_parts_bit_identical_at_judged_shape(dev, name):
             assert not bad, f"pass {r}: tensors {bad[:6]} of {len(cur)} differ from the first pass (0..{len(flat) - 1} outputs, {len(flat)} loss, then BatchNorm gradients)"
 
 
-def test_grouped_weight_gradients_in_the_backward(dev):
-    """YH_WGS_GROUP (engine.flags.WGS_GROUP, default off): the weight gradients of up to eight consecutive launches of the backward
-    leave in one yh_conv_wgrad_group launch — pinned gz buffers, one shared event per group, gradient-arena marks held back behind
-    the group.  YOLOv5s at the judged shape (batch 64, 640 x 640, the shipped launch parameters): groups are formed, the forward is
-    untouched, and the flat gradient equals the ungrouped backward's up to the summation order of the fp32 atomics — with and
-    without the data-parallel bucket hooks (a bucket is handed over only behind the group that completes it)."""
-    from yoloseries_amd import engine, models
-    from yoloseries_amd.loss import YOLOV5Loss
-    from yoloseries_amd.utils.synth import COCO_ANCHORS, synth_targets
-    import bench
-    B, img = 64, 640
-    x = torch.rand(B, 3, img, img, generator=torch.Generator().manual_seed(5)).to(dev)
-    t = torch.from_numpy(synth_targets(B, img, 80, 12, seed=6, min_boxes=2)).to(dev)
-    res, saved = {}, (engine.flags.WGS_GROUP, engine.flags.WGS_GROUP_WG, engine.flags.WGS_GROUP_GFLOP)
-    try:
-        for mode in ("plain", "grouped", "grouped+buckets"):
-            engine.flags.WGS_GROUP = 0 if mode == "plain" else 8
-            engine.flags.WGS_GROUP_WG, engine.flags.WGS_GROUP_GFLOP = 192, 60.0
-            torch.manual_seed(0)
-            m = models.YOLOV5Small(3, 80).to(dev).train()
-            seen = []
-            if mode == "grouped+buckets":
-                m._yh_bucket_hook = lambda part: seen.append((part.data_ptr(), part.numel())) or None
-            outs = m(x)
-            YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), bench.make_hyp(dev, img, B))(outs, t)["tot_loss"].backward()
-            torch.cuda.synchronize()
-            prog = m._yh_program(B, img, img)
-            ngroups = sum(1 for c in prog.cmd_bwd if c[0] == 'wgrad_group')
-            members = sum(len(c[1]) for c in prog.cmd_bwd if c[0] == 'wgrad_group')
-            res[mode] = ([o.detach().float().cpu() for o in outs], m._yh_last_flat_grad.clone().cpu(), ngroups, members, (seen, prog.pack.gsize))
-            del m, outs, prog
-            torch.cuda.empty_cache()
-    finally:
-        engine.flags.WGS_GROUP, engine.flags.WGS_GROUP_WG, engine.flags.WGS_GROUP_GFLOP = saved
-    o0, g0, n0, _, _ = res["plain"]
-    assert n0 == 0
-    for mode in ("grouped", "grouped+buckets"):
-        o1, g1, n1, members, seen = res[mode]
-        assert n1 >= 5 and members >= 3 * n1 // 2, (n1, members)
-        for a, b in zip(o0, o1):
-            assert torch.equal(a, b)
-        assert (g1 - g0).abs().max() <= 1e-4 * g0.abs().max()
-    seen, gsize = res["grouped+buckets"][4]
-    assert len(seen) >= 2 and sum(n for _, n in seen) == gsize            # the buckets tile the whole packed arena ...
-    assert all(p0 == p1 + 4 * n1 for (p0, _), (p1, n1) in zip(seen, seen[1:]))      # ... from its end downwards, contiguously
-
-
 @pytest.mark.parametrize("key", ["v5s_frozen", "yolox_frozen", "v5l_frozen"])
 def test_full_graph_gradients_eval_mode_bn(dev, key):
     """A WELL-CONDITIONED check of the whole backward graph: the model in evaluation mode under autograd (BatchNorm on its

@@ -136,9 +136,6 @@ _SIGS = {
     "yh_conv_wgrad_patch_name": (_i32, [C.POINTER(WgradDesc), C.c_char_p, _i32]),
     "yh_conv_wgrad_wave_tiles": (_i32, [C.POINTER(WgradDesc)]),
     "yh_conv_wgrad_wave_name": (C.c_char_p, [C.POINTER(WgradDesc)]),
-    "yh_conv_wgrad_group": (_i32, [C.POINTER(C.POINTER(WgradDesc)), _i32, _i32, _vp]),
-    "yh_conv_wgrad_group_ok": (_i32, [C.POINTER(C.POINTER(WgradDesc)), _i32, _i32]),
-    "yh_conv_wgrad_group_max": (_i32, []),
     "yh_conv_wgrad_tiles": (_i32, [_i32, _i32]),
     "yh_conv_wgrad_tiles2": (_i32, [_i32, _i32, _i32]),
     "yh_conv_wgrad_kernel_name": (C.c_char_p, [_i32, _i32]),

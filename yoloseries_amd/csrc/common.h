@@ -81,6 +81,23 @@ __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rs, unsig
 
 // ---- host side helpers -----------------------------------------------------
 void yh_set_error(const char* fmt, ...);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that launches on a second GPU must set
+// it there too.  One flag per device (bit mask over the first 64 devices, others set the attribute at every launch), written only
+// after every hipFuncSetAttribute of the block has succeeded; two threads may both set the attributes (idempotent), none launches
+// before they are set.  A failed set leaves the flag clear and the launch behind it reports hipErrorInvalidValue (YH_CHECK_LAUNCH).
+#include <atomic>
+struct YhDevOnce {
+    std::atomic<uint64_t> mask{0};
+    bool failed = false;
+    static int dev_() { int d = -1; return hipGetDevice(&d) == hipSuccess ? d : -1; }
+    bool need() { const int d = dev_(); failed = false; return d < 0 || d >= 64 || !((mask.load(std::memory_order_acquire) >> d) & 1ull); }
+    void set(const void* fn, hipFuncAttribute attr, int value) {
+        const hipError_t e = hipFuncSetAttribute(fn, attr, value);
+        if (e != hipSuccess) { failed = true; yh_set_error("hipFuncSetAttribute(%d bytes of LDS): %s", value, hipGetErrorString(e)); }
+    }
+    void done() { const int d = dev_(); if (!failed && d >= 0 && d < 64) mask.fetch_or(1ull << d, std::memory_order_release); }
+};
 #define YH_CHECK_ARG(cond, ...) do { if (!(cond)) { yh_set_error(__VA_ARGS__); return YH_EINVAL; } } while (0)
 #define YH_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) { yh_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return YH_ELAUNCH; } } while (0)

@@ -317,10 +317,10 @@ int yh_c80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name
     C80Plan pl;
     YH_CHECK_ARG(c80_plan(d, &pl), "yh_conv_igemm: algo 12 (80 -> 160 channel tap kernel) is not eligible for this descriptor");
     if (name_out) { snprintf(name_out, name_len, "conv_c80_kernel"); return YH_OK; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_c80_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C80_SMEM);
-        attr_set = true;
+    static YhDevOnce attr_set;      
+    if (attr_set.need()) {
+        attr_set.set((const void*)conv_c80_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C80_SMEM);
+        attr_set.done(); 
     }
     conv_c80_kernel<<<dim3(pl.grid), dim3(256), C80_SMEM, (hipStream_t)stream>>>(pl.k);
     YH_CHECK_LAUNCH("yh_conv_igemm(c80)");

@@ -400,11 +400,11 @@ int yh_dg2_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name
 #define YH_LAUNCH_DG2(CT_, KC_, PT_)                                                                                   \
     do {                                                                                                               \
         const int sm = dg_smem_bytes<CT_, KC_, PT_>();                                                                 \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
-            (void)hipFuncSetAttribute((const void*)conv_dg2_kernel<CT_, KC_, 0, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            (void)hipFuncSetAttribute((const void*)conv_dg2_kernel<CT_, KC_, 3, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            attr_set = true;                                                                                           \
+        static YhDevOnce attr_set;                                                                                        \
+        if (attr_set.need()) {                                                                                               \
+            attr_set.set((const void*)conv_dg2_kernel<CT_, KC_, 0, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.set((const void*)conv_dg2_kernel<CT_, KC_, 3, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.done();                                                                                            \
         }                                                                                                              \
         if (epi == 3) conv_dg2_kernel<CT_, KC_, 3, PT_><<<grid, blk, sm, st>>>(pl.k);                                  \
         else          conv_dg2_kernel<CT_, KC_, 0, PT_><<<grid, blk, sm, st>>>(pl.k);                                  \

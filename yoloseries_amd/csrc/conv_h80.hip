@@ -435,11 +435,11 @@ int yh_h80_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(pl.gx, pl.gy), blk(512);
     constexpr int sm = H80Cfg<80, 5>::SMEM;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_h80_kernel<80, 5, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-        (void)hipFuncSetAttribute((const void*)conv_h80_kernel<80, 5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-        attr_set = true;
+    static YhDevOnce attr_set;      
+    if (attr_set.need()) {
+        attr_set.set((const void*)conv_h80_kernel<80, 5, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        attr_set.set((const void*)conv_h80_kernel<80, 5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        attr_set.done(); 
     }
     if (pl.epi == 2) conv_h80_kernel<80, 5, 2><<<grid, blk, sm, st>>>(pl.k);
     else             conv_h80_kernel<80, 5, 0><<<grid, blk, sm, st>>>(pl.k);

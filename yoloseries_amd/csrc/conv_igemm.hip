@@ -2733,13 +2733,13 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         hgeo.stamps = g_halo_stamps;
         const dim3 gridh(gx * gy), blkh(512);              // one row of workgroups: halo_block_map
         const size_t sm = conv_halo160_smem_bytes();
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_halo160_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-            (void)hipFuncSetAttribute((const void*)conv_halo160_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-            (void)hipFuncSetAttribute((const void*)conv_halo160_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-            (void)hipFuncSetAttribute((const void*)conv_halo160_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-            attr_set = true;
+        static YhDevOnce attr_set;      
+        if (attr_set.need()) {
+            attr_set.set((const void*)conv_halo160_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            attr_set.set((const void*)conv_halo160_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            attr_set.set((const void*)conv_halo160_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            attr_set.set((const void*)conv_halo160_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            attr_set.done(); 
         }
         if (epi == 2) { if (tl) conv_halo160_kernel<2, true><<<gridh, blkh, sm, sth>>>(k, hgeo); else conv_halo160_kernel<2, false><<<gridh, blkh, sm, sth>>>(k, hgeo); }
         else          { if (tl) conv_halo160_kernel<0, true><<<gridh, blkh, sm, sth>>>(k, hgeo); else conv_halo160_kernel<0, false><<<gridh, blkh, sm, sth>>>(k, hgeo); }
@@ -2761,13 +2761,13 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
 #define YH_LAUNCH_HALO(BN_, TL_)                                                                                     \
         do {                                                                                                         \
             const size_t sm = conv_halo_smem_bytes<BN_>();                                                           \
-            static bool attr_set = false;                                                                            \
-            if (!attr_set) {                                                                                         \
-                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 0, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 1, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 2, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_halo_kernel<BN_, 3, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                attr_set = true;                                                                                     \
+            static YhDevOnce attr_set;                                                                                  \
+            if (attr_set.need()) {                                                                                         \
+                attr_set.set((const void*)conv_halo_kernel<BN_, 0, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_halo_kernel<BN_, 1, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_halo_kernel<BN_, 2, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_halo_kernel<BN_, 3, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.done();                                                                                      \
             }                                                                                                        \
             if (epi == 3)      conv_halo_kernel<BN_, 3, TL_><<<gridh, blkh, sm, sth>>>(k, hgeo);                     \
             else if (epi == 2) conv_halo_kernel<BN_, 2, TL_><<<gridh, blkh, sm, sth>>>(k, hgeo);                     \
@@ -2802,13 +2802,13 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         do {                                                                                                         \
             const size_t sm = conv3_smem_bytes<BMT_, BN_, WM_, BKT_, STG_>();                                        \
             const dim3 blk(WM_ * 2 * 64);                                                                            \
-            static bool attr_set = false;                                                                            \
-            if (!attr_set) {                                                                                         \
-                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                (void)hipFuncSetAttribute((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                attr_set = true;                                                                                     \
+            static YhDevOnce attr_set;                                                                                  \
+            if (attr_set.need()) {                                                                                         \
+                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.done();                                                                                      \
             }                                                                                                        \
             if (epi == 3)      conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3, TL_><<<grid, blk, sm, st3>>>(k);     \
             else if (epi == 2) conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2, TL_><<<grid, blk, sm, st3>>>(k);     \

@@ -379,12 +379,12 @@ int yh_p3_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
 #define YH_LAUNCH_P3(CT_, KC_, PT_)                                                                                    \
     do {                                                                                                               \
         const int sm = p3_smem_bytes<CT_, KC_, PT_>();                                                                 \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
-            (void)hipFuncSetAttribute((const void*)conv_p3_kernel<CT_, KC_, 0, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            (void)hipFuncSetAttribute((const void*)conv_p3_kernel<CT_, KC_, 1, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            (void)hipFuncSetAttribute((const void*)conv_p3_kernel<CT_, KC_, 3, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            attr_set = true;                                                                                           \
+        static YhDevOnce attr_set;                                                                                        \
+        if (attr_set.need()) {                                                                                               \
+            attr_set.set((const void*)conv_p3_kernel<CT_, KC_, 0, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.set((const void*)conv_p3_kernel<CT_, KC_, 1, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.set((const void*)conv_p3_kernel<CT_, KC_, 3, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.done();                                                                                            \
         }                                                                                                              \
         if (epi == 3)      conv_p3_kernel<CT_, KC_, 3, PT_><<<grid, blk, sm, st>>>(pl.k);                              \
         else if (epi == 1) conv_p3_kernel<CT_, KC_, 1, PT_><<<grid, blk, sm, st>>>(pl.k);                              \

@@ -576,16 +576,16 @@ int yh_pt_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
         constexpr int sm = PtCfg<A_, B_>::SMEM, smo = PtCfg<A_, B_>::SMEM_OPS;                                           \
         constexpr bool OK_ = PtCfg<A_, B_>::OPS_FIT;        /* 512 channels: the forms with memory operands are not built (pt_plan) */ \
         constexpr int E3 = OK_ ? 3 : 0, E4 = OK_ ? 4 : 2;                                                                \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
-            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+        static YhDevOnce attr_set;                                                                                         \
+        if (attr_set.need()) {                                                                                                \
+            attr_set.set((const void*)conv_pt_kernel<A_, B_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.set((const void*)conv_pt_kernel<A_, B_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.set((const void*)conv_pt_kernel<A_, B_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
             if (OK_) {                                                                                                  \
-                (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, E3>, hipFuncAttributeMaxDynamicSharedMemorySize, smo); \
-                (void)hipFuncSetAttribute((const void*)conv_pt_kernel<A_, B_, E4>, hipFuncAttributeMaxDynamicSharedMemorySize, smo); \
+                attr_set.set((const void*)conv_pt_kernel<A_, B_, E3>, hipFuncAttributeMaxDynamicSharedMemorySize, smo); \
+                attr_set.set((const void*)conv_pt_kernel<A_, B_, E4>, hipFuncAttributeMaxDynamicSharedMemorySize, smo); \
             }                                                                                                           \
-            attr_set = true;                                                                                            \
+            attr_set.done();                                                                                             \
         }                                                                                                               \
         YH_CHECK_ARG(OK_ || pl.epi < 3, "yh_conv_igemm(pt): no operand slots for this width");                          \
         switch (pl.epi) {                                                                                               \
@@ -598,11 +598,11 @@ int yh_pt_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
     } while (0)
     if (pl.cs1 == 0 && pl.cs0 == 320) {
         constexpr int sm = PtCfg<320, 0>::SMEM;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<320, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-            (void)hipFuncSetAttribute((const void*)conv_pt_kernel<320, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-            attr_set = true;
+        static YhDevOnce attr_set;      
+        if (attr_set.need()) {
+            attr_set.set((const void*)conv_pt_kernel<320, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+            attr_set.set((const void*)conv_pt_kernel<320, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+            attr_set.done(); 
         }
         YH_CHECK_ARG(pl.epi == 0 || pl.epi == 2, "yh_conv_igemm(pt): 320 channels: plain / bias-BN-SiLU epilogues only");
         if (pl.epi == 2) conv_pt_kernel<320, 0, 2><<<grid, blk, sm, st>>>(pl.k);

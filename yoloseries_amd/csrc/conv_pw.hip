@@ -284,11 +284,11 @@ int yh_pw_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
 #define YH_LAUNCH_PW(CIN_, TMW_)                                                                                           \
     do {                                                                                                               \
         constexpr int sm = PwCfg<CIN_, 5, TMW_>::SMEM;                                                                    \
-        static bool attr_set = false;                                                                                  \
-        if (!attr_set) {                                                                                               \
-            (void)hipFuncSetAttribute((const void*)conv_pw_kernel<CIN_, 5, TMW_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            (void)hipFuncSetAttribute((const void*)conv_pw_kernel<CIN_, 5, TMW_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
-            attr_set = true;                                                                                           \
+        static YhDevOnce attr_set;                                                                                        \
+        if (attr_set.need()) {                                                                                               \
+            attr_set.set((const void*)conv_pw_kernel<CIN_, 5, TMW_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.set((const void*)conv_pw_kernel<CIN_, 5, TMW_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.done();                                                                                            \
         }                                                                                                              \
         if (pl.epi == 2) conv_pw_kernel<CIN_, 5, TMW_, 2><<<grid, blk, sm, st>>>(pl.k);                                      \
         else             conv_pw_kernel<CIN_, 5, TMW_, 0><<<grid, blk, sm, st>>>(pl.k);                                      \

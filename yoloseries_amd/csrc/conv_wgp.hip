@@ -351,14 +351,14 @@ int yh_wgp_run(const yh_wgrad_desc* d, yh_stream stream)
     YH_CHECK_ARG(inst >= 0, "yh_conv_wgrad: no patch-form instantiation for this layer");
 #define YH_TRY_WGP(I_, NW_, TPW_, NGI_, NXI_)                                                                     \
     if (inst == I_) {                                                                                             \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgp_kernel<NW_, TPW_, NGI_, NXI_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; } \
+        static YhDevOnce attr_set;                                                                                   \
+        if (attr_set.need()) { attr_set.set((const void*)conv_wgp_kernel<NW_, TPW_, NGI_, NXI_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set.done();  } \
         conv_wgp_kernel<NW_, TPW_, NGI_, NXI_><<<dim3(pl.gx), dim3(64 * NW_), pl.smem, st>>>(pl.k, pl.PG, pl.PX);  \
     }
 #define YH_TRY_WGPF(I_, NW_, TPW_, NGI_, NXI_)                                                                    \
     if (inst == I_ && d->bn_z) {                                                                                  \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgpf_kernel<NW_, TPW_, NGI_, NXI_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; } \
+        static YhDevOnce attr_set;                                                                                   \
+        if (attr_set.need()) { attr_set.set((const void*)conv_wgpf_kernel<NW_, TPW_, NGI_, NXI_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set.done();  } \
         conv_wgpf_kernel<NW_, TPW_, NGI_, NXI_><<<dim3(pl.gx), dim3(64 * NW_), pl.smem, st>>>(pl.k, pl.PG, pl.PX); \
         YH_CHECK_LAUNCH("yh_conv_wgrad(patch, fused BatchNorm backward)");                                        \
         return YH_OK;                                                                                             \

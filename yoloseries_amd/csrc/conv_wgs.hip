@@ -47,17 +47,6 @@ struct WgsK {
     int pw;            // 1x1 / stride 1 / pad 0 layer on a plain segment (the kernel's PW form)
 };
 
-// several layers in ONE launch (yh_conv_wgrad_group): layer l owns the hardware workgroups [base[l], base[l + 1]) — a multiple
-// of 8 each, so a layer's workgroups are dealt to the XCDs exactly as a launch of its own would be — and runs its own stream-K
-// plan on them.  What a launch costs beside its main loop (ring fill, combine, the fp32 atomics of ONE 64 KB tile per workgroup at
-// the chip-wide 1.3 TB/s: 12 us at 252 workgroups, skew of the last workgroups) is then paid once per group instead of once per layer.
-constexpr int WGS_GMAX = 8;
-struct WgsGroupK {
-    int n;
-    int base[WGS_GMAX + 1];
-    WgsK L[WGS_GMAX];
-};
-
 __device__ __forceinline__ v4s wgs_tr(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p));
 }
@@ -360,36 +349,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgs_kernel(const WgsK p)
     wgs_body<PW>(p, blockIdx.x, smem);
 }
 
-// A member's parameters sit at a run-time offset of the kernel arguments: read where they are used, the compiler re-issues the
-// scalar loads inside the main loop (an invariant load counts as free to rematerialise), and each of them joins the loop's
-// lgkmcnt(0) waits.  Every field the body reads is therefore loaded once and pinned to an SGPR behind an empty asm.
-__device__ __forceinline__ int wgs_pin(int x) { asm volatile("" : "+s"(x)); return x; }
-__device__ __forceinline__ unsigned wgs_pin(unsigned x) { asm volatile("" : "+s"(x)); return x; }
-__device__ __forceinline__ long wgs_pin(long x) { asm volatile("" : "+s"(x)); return x; }
-template <class P> __device__ __forceinline__ P* wgs_pin(P* x) { asm volatile("" : "+s"(x)); return x; }
-
-__global__ __launch_bounds__(256, 1) void conv_wgs_group_kernel(const WgsGroupK g)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int l = 0;
-    for (int i = 1; i < g.n; ++i) l = ((int)blockIdx.x >= g.base[i]) ? i : l;
-    const WgsK& s = g.L[l];
-    WgsK p;
-    p.d.gy = wgs_pin(s.d.gy); p.d.ldg = wgs_pin(s.d.ldg); p.d.N = wgs_pin(s.d.N);
-    p.d.seg.ptr = wgs_pin(s.d.seg.ptr); p.d.seg.ld = wgs_pin(s.d.seg.ld); p.d.seg.C = wgs_pin(s.d.seg.C); p.d.seg.ups = wgs_pin(s.d.seg.ups);
-    p.d.coff_k = wgs_pin(s.d.coff_k); p.d.Ctot = wgs_pin(s.d.Ctot);
-    p.d.Ho = wgs_pin(s.d.Ho); p.d.Wo = wgs_pin(s.d.Wo); p.d.Hi = wgs_pin(s.d.Hi); p.d.Wi = wgs_pin(s.d.Wi);
-    p.d.KH = wgs_pin(s.d.KH); p.d.KW = wgs_pin(s.d.KW); p.d.stride = wgs_pin(s.d.stride); p.d.pad = wgs_pin(s.d.pad);
-    p.d.dw = wgs_pin(s.d.dw);
-    p.stamps = wgs_pin(s.stamps);
-    p.Ktot = wgs_pin(s.Ktot); p.nk = wgs_pin(s.nk); p.nct = wgs_pin(s.nct); p.T = wgs_pin(s.T); p.G = wgs_pin(s.G);
-    p.mg = wgs_pin(s.mg); p.mGp = wgs_pin(s.mGp); p.minv = wgs_pin(s.minv); p.U = wgs_pin(s.U);
-    p.gybytes = wgs_pin(s.gybytes); p.xbytes = wgs_pin(s.xbytes); p.dwbytes = wgs_pin(s.dwbytes);
-    const int b = (int)blockIdx.x - wgs_pin(g.base[l]);
-    if (wgs_pin(s.pw)) wgs_body<true>(p, b, smem);
-    else               wgs_body<false>(p, b, smem);
-}
-
 // eligibility of the layer and the launch plan shared by the queries and the launcher
 struct WgsPlan { long M; int nk, ntn, nct, T, G, S, grid; bool pw; unsigned long xb; };
 
@@ -477,12 +436,11 @@ static void wgs_fill(const yh_wgrad_desc* d, const WgsPlan& pl, int G, WgsK* kp)
 
 static void wgs_attrs()
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_wgs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
-        (void)hipFuncSetAttribute((const void*)conv_wgs_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
-        attr_set = true;
+    static YhDevOnce attr_set;      
+    if (attr_set.need()) {
+        attr_set.set((const void*)conv_wgs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
+        attr_set.set((const void*)conv_wgs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS);
+        attr_set.done(); 
     }
 }
 
@@ -499,73 +457,5 @@ int yh_wgs_run(const yh_wgrad_desc* d, yh_stream stream)
     if (pl.pw) conv_wgs_kernel<true><<<dim3(pl.grid), dim3(256), WGS_LDS, st>>>(k);
     else       conv_wgs_kernel<false><<<dim3(pl.grid), dim3(256), WGS_LDS, st>>>(k);
     YH_CHECK_LAUNCH("yh_conv_wgrad(tile_k 129)");
-    return YH_OK;
-}
-
-/* Workgroups of each member of a group launch: `workgroups` (<= 4096) are handed out in chunks of 8 (one per XCD), at least one
- * chunk per layer, the rest one at a time to the layer with the most (tile, 32 pixels) units per workgroup (a remainder below 8
- * stays unused; a layer of fewer than 8 units may only close a group).  Returns 0 (and leaves out[] alone) when the descriptors are not all eligible or do not fit. */
-static int wgs_group_plan(const yh_wgrad_desc* const* descs, int n, int workgroups, WgsPlan* pls, int* out)
-{
-    if (!descs || n < 1 || n > WGS_GMAX || workgroups < 8 * n || workgroups > 4096) return 0;
-    int chunks[WGS_GMAX];
-    for (int i = 0; i < n; ++i) {
-        yh_wgrad_desc d = *descs[i];
-        d.splits = 1;
-        if (d.tile_k != 129 || !wgs_plan(&d, &pls[i])) return 0;
-        chunks[i] = 1;
-    }
-    const int nch = workgroups / 8;
-    for (int c = n; c < nch; ++c) {
-        int best = -1;
-        double load = 0.0;
-        for (int i = 0; i < n; ++i) {
-            const long U = (long)pls[i].T * pls[i].nk;
-            if ((long)(chunks[i] + 1) * 8 > U) continue;          // never more workgroups than units
-            const double li = (double)U / (chunks[i] * 8);
-            if (best < 0 || li > load) { best = i; load = li; }
-        }
-        if (best < 0) break;
-        ++chunks[best];
-    }
-    for (int i = 0; i < n; ++i) {
-        const long U = (long)pls[i].T * pls[i].nk;
-        out[i] = (long)chunks[i] * 8 > U ? (int)U : chunks[i] * 8;
-        if (out[i] % 8 != 0 && i != n - 1) return 0;              // a layer of fewer than 8 units may only close a group
-    }
-    return 1;
-}
-
-extern "C" int yh_conv_wgrad_group_max(void) { return WGS_GMAX; }
-
-/* 1 when yh_conv_wgrad_group() takes these descriptors on `workgroups` workgroups */
-extern "C" int yh_conv_wgrad_group_ok(const yh_wgrad_desc* const* descs, int n, int workgroups)
-{
-    WgsPlan pls[WGS_GMAX];
-    int gs[WGS_GMAX];
-    return wgs_group_plan(descs, n, workgroups, pls, gs);
-}
-
-extern "C" int yh_conv_wgrad_group(const yh_wgrad_desc* const* descs, int n, int workgroups, yh_stream stream)
-{
-    WgsPlan pls[WGS_GMAX];
-    int gs[WGS_GMAX];
-    YH_CHECK_ARG(wgs_group_plan(descs, n, workgroups, pls, gs),
-                 "yh_conv_wgrad_group: 1..%d descriptors with tile_k 129 that the wave-private form takes, >= 8 workgroups each", WGS_GMAX);
-    WgsGroupK g;
-    memset(&g, 0, sizeof(g));
-    g.n = n;
-    int base = 0;
-    for (int i = 0; i < n; ++i) {
-        const yh_wgrad_desc* d = descs[i];
-        YH_CHECK_ARG(d->gy && yh_aligned16(d->gy) && d->seg.ptr && yh_aligned16(d->seg.ptr) && d->dw, "yh_conv_wgrad_group: bad operands (member %d)", i);
-        wgs_fill(d, pls[i], gs[i], &g.L[i]);
-        g.base[i] = base;
-        base += gs[i];
-    }
-    for (int i = n; i <= WGS_GMAX; ++i) g.base[i] = base;
-    wgs_attrs();
-    conv_wgs_group_kernel<<<dim3(base), dim3(256), WGS_LDS, (hipStream_t)stream>>>(g);
-    YH_CHECK_LAUNCH("yh_conv_wgrad_group");
     return YH_OK;
 }

@@ -17,6 +17,32 @@ __device__ __forceinline__ uint4 ld_nt(const uint16_t* p) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// Store policy of the BN+SiLU passes' output (template parameter ST; YH_EW_STORE selects it at run time for A/B runs):
+// 0 plain, 1 non-temporal (nt), 2 write-through at agent scope (sc1): a kernel boundary waits for the write-back of whatever its
+// predecessor left dirty in the eight L2s (MI355X_MICROARCH.md, price list row 'boundary').
+template <int ST>
+__device__ __forceinline__ void st16(uint16_t* p, const uint4& v) {
+    if (ST == 1) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+        u4 w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<u4*>(p));
+    } else if (ST == 2) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+        const u4 w = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
+    } else {
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+}
+inline int ew_store_mode() { static const int v = [] { const char* e = getenv("YH_EW_STORE"); return e ? atoi(e) : 0; }(); return v; }
+#define YH_EW_LAUNCH(KERNEL, GRID, ...)                                                                                         \
+    do {                                                                                                                        \
+        const int stm_ = ew_store_mode();                                                                                       \
+        if (stm_ == 1)      hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(EW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__);        \
+        else if (stm_ == 2) hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(EW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__);        \
+        else                hipLaunchKernelGGL((KERNEL<0>), GRID, dim3(EW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__);        \
+    } while (0)
+
 // ---------------------------------------------------------------- BN finalize
 // Deterministic column sums of a [nblk][nwhich][ld] partial slab.  These kernels sit on the layer chain's critical path
 // (conv -> finalize -> apply) and move little data, so they are built for latency: one block = FIN_CPB channels
@@ -153,6 +179,7 @@ __global__ void bn_fold_batch_kernel(const yh_bn_fold_item* items)
 // ---------------------------------------------------------------- BN+SiLU apply
 // Grid-stride over 16-byte chunks with a stride that is a multiple of the chunks per row, so a thread
 // keeps its 8 channels for the whole pass and the per-channel constants live in registers.
+template <int ST>
 __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, const float* __restrict__ ws, int C, int cpr,
                                      long M, uint16_t* __restrict__ out, int ldo,
                                      const uint16_t* __restrict__ res, int ldr)
@@ -180,7 +207,7 @@ __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, co
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = bf_round(f[e]) + g[e];
         }
-        *reinterpret_cast<uint4*>(out + m * ldo + c) = pack8(f);
+        st16<ST>(out + m * ldo + c, pack8(f));
     }
 }
 
@@ -219,6 +246,7 @@ __device__ __forceinline__ int part_of(const PartsK& P, int c, int& c_in)
     return k;
 }
 
+template <int ST>
 __global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M)
 {
     const long T = (long)gridDim.x * blockDim.x;
@@ -242,7 +270,7 @@ __global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int l
         unpack8(v, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e] * sc[e] + sh[e]);
-        *reinterpret_cast<uint4*>(out + m * ldo) = pack8(f);
+        st16<ST>(out + m * ldo, pack8(f));
     }
 }
 
@@ -384,6 +412,7 @@ __global__ __launch_bounds__(FIN_NT) void colsum_finalize_kernel(const float* __
 
 // gz = gamma*is*(dz - c1 - xhat*c2) with dz = g*silu'(z), xhat = (y-mu)*is, written per channel as
 // gz = A*dz + Bc*y + D (constants in registers, see bn_silu_apply_kernel for the striding).
+template <int ST>
 __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ldga, const uint16_t* __restrict__ y, int ldy,
                                          const float* __restrict__ ws, const float* __restrict__ gamma,
                                          const float* __restrict__ coef, int C, int cpr, long M,
@@ -421,7 +450,7 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
             float dz = g[e] * (sg * (1.f + z * (1.f - sg)));
             o[e] = A[e] * dz + (Bc[e] * yy[e] + D[e]);
         }
-        *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
+        st16<ST>(gy + m * ldgy + c, pack8(o));
         if (gres) {
             uint16_t* dst = gres + m * ldgres + c;
             if (gres_acc) {
@@ -440,6 +469,7 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
 
 // bn_silu_bwd_apply over all parts of a stacked layer in one pass (see bn_silu_apply_parts_kernel): a part brings its own incoming
 // gradient tensor; gz of all parts is one buffer.
+template <int ST>
 __global__ void bn_silu_bwd_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M,
                                                uint16_t* __restrict__ gy, int ldgy)
 {
@@ -481,7 +511,7 @@ __global__ void bn_silu_bwd_apply_parts_kernel(const uint16_t* __restrict__ y, i
             float dz = g[e] * (sg * (1.f + z * (1.f - sg)));
             o[e] = A[e] * dz + (Bc[e] * yy[e] + D[e]);
         }
-        *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
+        st16<ST>(gy + m * ldgy + c, pack8(o));
     }
 }
 
@@ -732,8 +762,7 @@ extern "C" int yh_bn_silu_apply(const yh_bf16* y, int ldy, const float* ws, int 
     if (res) YH_CHECK_SLICE("yh_bn_silu_apply", res, ldr, C);
     int cpr = C / 8;
     long nch = (long)M * cpr;
-    hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       y, ldy, ws, C, cpr, (long)M, out, ldo, res, ldr);
+    YH_EW_LAUNCH(bn_silu_apply_kernel, dim3(ew_grid(nch)), y, ldy, ws, C, cpr, (long)M, out, ldo, res, ldr);
     YH_CHECK_LAUNCH("yh_bn_silu_apply");
     return YH_OK;
 }
@@ -774,8 +803,7 @@ extern "C" int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* 
     if (gres) YH_CHECK_SLICE("yh_bn_silu_bwd_apply", gres, ldgres, C);
     int cpr = C / 8;
     long nch = (long)M * cpr;
-    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       ga, ldga, y, ldy, ws, gamma, coef, C, cpr, (long)M, gy, ldgy, gres, ldgres, gres_accumulate);
+    YH_EW_LAUNCH(bn_silu_bwd_apply_kernel, dim3(ew_grid(nch)), ga, ldga, y, ldy, ws, gamma, coef, C, cpr, (long)M, gy, ldgy, gres, ldgres, gres_accumulate);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply");
     return YH_OK;
 }
@@ -844,7 +872,7 @@ extern "C" int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, cons
     YH_CHECK_ARG(M > 0, "yh_bn_silu_apply_parts: bad M");
     YH_CHECK_SLICE("yh_bn_silu_apply_parts", y, ldy, C);
     const int cpr = C / 8;
-    hipLaunchKernelGGL(bn_silu_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, ldy, P, cpr, (long)M);
+    YH_EW_LAUNCH(bn_silu_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), y, ldy, P, cpr, (long)M);
     YH_CHECK_LAUNCH("yh_bn_silu_apply_parts");
     return YH_OK;
 }
@@ -860,8 +888,7 @@ extern "C" int yh_bn_silu_bwd_apply_parts(const yh_bf16* y, int ldy, int64_t M, 
     YH_CHECK_SLICE("yh_bn_silu_bwd_apply_parts", y, ldy, C);
     YH_CHECK_SLICE("yh_bn_silu_bwd_apply_parts", gy, ldgy, C);
     const int cpr = C / 8;
-    hipLaunchKernelGGL(bn_silu_bwd_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       y, ldy, P, cpr, (long)M, gy, ldgy);
+    YH_EW_LAUNCH(bn_silu_bwd_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), y, ldy, P, cpr, (long)M, gy, ldgy);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply_parts");
     return YH_OK;
 }

@@ -25,7 +25,7 @@ struct OpEntry { const char* name; int (*thunk)(const uint64_t*); int nargs; };
 #define YH_OP(fn) { #fn, [](const uint64_t* s) -> int { return thunk_impl(&fn, s); }, arity(&fn) }
 // every entry point a Program command list may contain; the stream is each function's LAST argument
 const OpEntry kOps[] = {
-    YH_OP(yh_conv_igemm), YH_OP(yh_conv_wgrad), YH_OP(yh_conv_wgrad_group), YH_OP(yh_bn_finalize), YH_OP(yh_bn_fold_batch), YH_OP(yh_bn_silu_apply),
+    YH_OP(yh_conv_igemm), YH_OP(yh_conv_wgrad), YH_OP(yh_bn_finalize), YH_OP(yh_bn_fold_batch), YH_OP(yh_bn_silu_apply),
     YH_OP(yh_bn_silu_bwd_reduce), YH_OP(yh_bn_bwd_finalize), YH_OP(yh_bn_silu_bwd_apply), YH_OP(yh_colsum),
     YH_OP(yh_maxpool5_fwd), YH_OP(yh_maxpool5_bwd), YH_OP(yh_upsample2_bwd), YH_OP(yh_fill_u32),
     YH_OP(yh_bn_silu_apply_parts), YH_OP(yh_bn_silu_bwd_apply_parts), YH_OP(yh_bn_finalize_parts), YH_OP(yh_bn_bwd_finalize_parts),

@@ -625,12 +625,12 @@ extern "C" int yh_decode_filter(const yh_decode_desc* d, const void* const* pred
         YH_CHECK_ARG(sm <= 160 * 1024, "yh_decode_filter: prediction rows of %d elements do not fit the LDS tile", ldmax);
         const dim3 grid(nchunks, d->B);
         if (d->pred_is_f32) {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)decode_scan_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            static YhDevOnce attr;
+            if (attr.need()) { attr.set((const void*)decode_scan_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr.done(); }
             hipLaunchKernelGGL((decode_scan_kernel<float>), grid, dim3(256), sm, (hipStream_t)stream, k, conf_thr, cls_thr, stage, counts, nkeys);
         } else {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)decode_scan_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            static YhDevOnce attr;
+            if (attr.need()) { attr.set((const void*)decode_scan_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr.done(); }
             hipLaunchKernelGGL((decode_scan_kernel<uint16_t>), grid, dim3(256), sm, (hipStream_t)stream, k, conf_thr, cls_thr, stage, counts, nkeys);
         }
         YH_CHECK_LAUNCH("yh_decode_filter(scan)");

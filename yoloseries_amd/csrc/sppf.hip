@@ -193,13 +193,13 @@ extern "C" int yh_sppf_pool3_fwd(const yh_bf16* x, int ldx, int B, int H, int W,
     YH_CHECK_ARG((i1 == nullptr) == (i2 == nullptr) && (i2 == nullptr) == (i3 == nullptr), "yh_sppf_pool3_fwd: all three arg-max buffers or none");
     const int ch = sppf_ch(H * W);
     const size_t sm = sppf_smem(H * W, ch);
-    static bool attr = false;
-    if (!attr) {
+    static YhDevOnce attr;
+    if (attr.need()) {
         const int mx = (int)sppf_smem(SP_MAXPX, 32);
-        (void)hipFuncSetAttribute((const void*)sppf_pool3_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        (void)hipFuncSetAttribute((const void*)sppf_pool3_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        (void)hipFuncSetAttribute((const void*)sppf_pool3_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        attr = true;
+        attr.set((const void*)sppf_pool3_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        attr.set((const void*)sppf_pool3_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        attr.set((const void*)sppf_pool3_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        attr.done();
     }
     const dim3 grid(B, (C + ch - 1) / ch), blk(SP_NT);
     if (ch == 32)      sppf_pool3_fwd_kernel<32><<<grid, blk, sm, (hipStream_t)stream>>>(x, ldx, H, W, C, o1, o2, o3, ldo, i1, i2, i3);
@@ -217,13 +217,13 @@ extern "C" int yh_sppf_pool3_bwd(const yh_bf16* g1, const yh_bf16* g2, const yh_
                  ldg % 8 == 0 && ldx % 8 == 0, "yh_sppf_pool3_bwd: null / unaligned slices");
     const int ch = sppf_ch(H * W);
     const size_t sm = sppf_smem(H * W, ch);
-    static bool attr = false;
-    if (!attr) {
+    static YhDevOnce attr;
+    if (attr.need()) {
         const int mx = (int)sppf_smem(SP_MAXPX, 32);
-        (void)hipFuncSetAttribute((const void*)sppf_pool3_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        (void)hipFuncSetAttribute((const void*)sppf_pool3_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        (void)hipFuncSetAttribute((const void*)sppf_pool3_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        attr = true;
+        attr.set((const void*)sppf_pool3_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        attr.set((const void*)sppf_pool3_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        attr.set((const void*)sppf_pool3_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        attr.done();
     }
     const dim3 grid(B, (C + ch - 1) / ch), blk(SP_NT);
     if (ch == 32)      sppf_pool3_bwd_kernel<32><<<grid, blk, sm, (hipStream_t)stream>>>(g1, g2, g3, ldg, i1, i2, i3, H, W, C, gx, ldx, accumulate);

@@ -13,7 +13,6 @@ from ..hipk import Slice
 from ..streams import side_stream
 from . import flags as _flags
 from .executor import CompiledCmds
-from .flags import ABL_SKIP, FUSE_STEM_BWD, HEAD_COLSUM_SIDE, MERGE_PARTS
 from .graph import ConvOp, PoolOp, Ref, _rup, plan_grad_buckets, sppf_chain
 from .tune import _tune_cache_save
 
@@ -25,7 +24,7 @@ class BackwardMixin:
         scratch of its own: `part_scratch` belongs to the main stream's BatchNorm reductions (a layer wider than `head_scratch` was
         sized for — it is sized from the widest plain op of the graph, so none today — falls back to the main stream, never to a
         shared buffer on another stream)"""
-        return bool(two and HEAD_COLSUM_SIDE and op.y.C * 1024 * 2 <= self.head_scratch.numel())
+        return bool(two and _flags.HEAD_COLSUM_SIDE and op.y.C * 1024 * 2 <= self.head_scratch.numel())
 
     def _head_scratch(self, op, two):
         """partial-sum scratch of a head layer's bias gradient: its own buffer when the column sums run on the side stream"""
@@ -36,10 +35,10 @@ class BackwardMixin:
         if not isinstance(op, ConvOp) or op.kind != 'cba':
             return False
         Kseg0 = op.k * op.k * op.segs[0].C
-        return bool(FUSE_STEM_BWD and len(op.parts) == 1 and len(op.segs) == 1 and op.res is None and
+        return bool(_flags.FUSE_STEM_BWD and len(op.parts) == 1 and len(op.segs) == 1 and op.res is None and
                     not op.segs[0].buf.needs_grad and op.N % 8 == 0 and
                     ((op.N <= 32 and Kseg0 <= 256) or (op.N > 32 and 128 < Kseg0 <= 256)) and
-                    (FUSE_STEM_BWD >= 2 or (self.wg_ws is None and self._stem_patch_ok(op))))
+                    (_flags.FUSE_STEM_BWD >= 2 or (self.wg_ws is None and self._stem_patch_ok(op))))
 
     def _stem_patch_ok(self, op):
         """does the patch form of the weight gradient (conv_wgpf_kernel) take this layer with the fused BatchNorm backward?"""
@@ -73,11 +72,8 @@ class BackwardMixin:
         # layer's gz): consecutive layers alternate between two gz buffers so that a layer's wgrad may still be
         # reading its gz while the next layer's BN backward writes the other one
         self.two_streams = os.environ.get("YH_BWD_STREAMS", "1") != "0"
-        # grouped weight gradients (flags.WGS_GROUP): the members' gz buffers are pinned until the group's launch, also on one stream
-        grp_max = min(_flags.WGS_GROUP, L.yh_conv_wgrad_group_max()) if _flags.WG_WS_BYTES == 0 else 0
-        grp_on = grp_max >= 2
-        NGZ = self.ngz = max(_flags.NGZ, _flags.WGS_GROUP_CBA + 3) if grp_on else _flags.NGZ
-        self.gy_ring = [self.gy_scratch] + ([torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev) for _ in range(NGZ - 1)] if (self.two_streams or grp_on) else [self.gy_scratch] * (NGZ - 1))
+        NGZ = self.ngz = _flags.NGZ
+        self.gy_ring = [self.gy_scratch] + ([torch.zeros(max(max_gy, 8), dtype=torch.bfloat16, device=self.dev) for _ in range(NGZ - 1)] if self.two_streams else [self.gy_scratch] * (NGZ - 1))
         n_cba = 0
         self.part_scratch = torch.zeros(1024 * 2 * 2048, dtype=torch.float32, device=self.dev)
         # partial sums of the head layers' bias gradients (column sums of the head gradients): these run on the SIDE stream (they feed
@@ -90,32 +86,6 @@ class BackwardMixin:
         # workspace of the weight gradients' split-M partial tiles (plain stores + a deterministic reduce instead of fp32
         # atomics; YH_WGRAD_PARTIAL=0: atomics).  One buffer serves every launch: they all run on one stream, in order.
         self.wg_ws = torch.empty(_flags.WG_WS_BYTES // 4, dtype=torch.float32, device=self.dev) if _flags.WG_WS_BYTES > 0 else None
-
-        # ---- grouped weight gradients: launches of the wave-private form are collected and leave together (yh_conv_wgrad_group)
-        group = {'items': [], 'slots': [], 'flops': 0.0}
-        held_marks = []
-
-        def flush_group():
-            """emit the collected weight gradients (one group launch; a single member as the plain launch it was) and the
-            gradient-arena marks held back behind them"""
-            items = group['items']
-            if items:
-                cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
-                if len(items) == 1:
-                    op_, wd_, meta_ = items[0]
-                    cmds.append(('wgrad', op_, wd_, meta_))
-                else:
-                    descs = [it[1] for it in items]
-                    arr = hipk.wgrad_group_array(descs)
-                    self._keep.append(arr)
-                    assert L.yh_conv_wgrad_group_ok(arr, len(descs), _flags.WGS_GROUP_WG) == 1
-                    cmds.append(('wgrad_group', [it[0] for it in items], (arr, descs),
-                                 ('conv_wgs_group_kernel', sum(it[2][1] for it in items), sum(it[2][2] for it in items))))
-                cmds.append(('wg_end', list(group['slots']) or None, None, ('sync', 0, 0.0)))
-            for gloc in held_marks:
-                marks.append((len(cmds), gloc))
-            group['items'], group['slots'], group['flops'] = [], [], 0.0
-            del held_marks[:]
 
         writes_seen = {}
 
@@ -211,8 +181,6 @@ class BackwardMixin:
             gys = self.gy_scratch
             if op.kind == 'cba':
                 gys = self.gy_ring[n_cba % NGZ]
-                if (n_cba % NGZ) in group['slots']:
-                    flush_group()                # never reached with the ring sized for a group: a pinned buffer is not overwritten
                 cmds.append(('gz_begin', n_cba % NGZ, None, ('sync', 0, 0.0)))       # main stream: wait until this gz buffer's last wgrad is done
                 n_cba += 1
             if op.kind == 'plain':
@@ -229,7 +197,7 @@ class BackwardMixin:
                 # gradient: that kernel forms gz from (ga, z) in its operand loader (yh_wgrad_desc.bn_*), the apply pass — the
                 # last 0.2 ms of the backward's critical path on YOLOv5s — and the gz round trip through HBM disappear
                 fused_stem = self._is_fused_stem(op)
-                merged = (MERGE_PARTS and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and
+                merged = (_flags.MERGE_PARTS and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and
                           not (op.res is not None and op.res.buf.needs_grad))
                 bwd_parts = (BnPart * len(op.parts))() if merged else None
                 scratch_off = 0
@@ -322,33 +290,14 @@ class BackwardMixin:
                                           2.0 * M * gy_ld * (2 if wd.bn_z else 1) + nbytes_x)))
                 coff_k += sg.C
             slot = (n_cba - 1) % NGZ if op.kind == 'cba' else None
-            # Launches of the wave-private form join the pending group (its launch waits for the LAST member's gz; the members' gz
-            # buffers stay pinned); everything else leaves now.  Marks of the gradient arena are held back while a group is pending:
-            # a bucket is complete only when the weight gradients in front of it have been enqueued.
-            groupable = grp_on and not on_main and all(wd.tile_k == 129 and L.yh_conv_wgrad_wave_tiles(C.byref(wd)) > 0 for _o, wd, _m in launches)
-            if groupable:
-                ncba = len(group['slots']) + (1 if slot is not None else 0)
-                if len(group['items']) + len(launches) > grp_max or ncba > _flags.WGS_GROUP_CBA:
-                    flush_group()
-                group['items'] += launches
-                if slot is not None:
-                    group['slots'].append(slot)
-                group['flops'] += sum(m[1] for _o, _w, m in launches)
-                held_marks.append(pk.gloc[op.name])
-                if group['flops'] >= _flags.WGS_GROUP_GFLOP * 1e9 or len(group['items']) >= grp_max:
-                    flush_group()
-            else:
-                if not on_main:
-                    cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
-                for ln in launches:
-                    cmds.append(('wgrad',) + ln)
-                if not on_main:
-                    cmds.append(('wg_end', [slot] if slot is not None else None, None, ('sync', 0, 0.0)))
-                # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
-                if group['items']:
-                    held_marks.append(pk.gloc[op.name])
-                else:
-                    marks.append((len(cmds), pk.gloc[op.name]))
+            if not on_main:
+                cmds.append(('wg_begin', None, None, ('sync', 0, 0.0)))
+            for ln in launches:
+                cmds.append(('wgrad',) + ln)
+            if not on_main:
+                cmds.append(('wg_end', [slot] if slot is not None else None, None, ('sync', 0, 0.0)))
+            # every gradient of this op's parameters has been enqueued: its slice of the packed arena is final
+            marks.append((len(cmds), pk.gloc[op.name]))
             # dgrad per segment
             for si, sg in enumerate(op.segs):
                 if not sg.buf.needs_grad:
@@ -399,7 +348,6 @@ class BackwardMixin:
                         d.bnr_part = slab.data_ptr()
                         self.bnr_fused[(po.name, ppi)] = (slab, rows)
                     cmds.append(('dgrad', op, d, (self._kernel_name(d), 2.0 * M * op.N * op.k * op.k * sg.C, self._conv_bytes(d))))
-        flush_group()
         self.cmd_bwd = cmds
         self.cmd_bwd_frozen = None
         self.bwd_buckets = plan_grad_buckets(marks, pk.gsize, int(os.environ.get("YH_DP_BUCKETS", "4")))
@@ -465,7 +413,7 @@ class BackwardMixin:
                 if two and pending[cmd[1]] is not None:
                     e = pending[cmd[1]]
                     cc.event(YH_CMD_STREAM_WAIT, ev_wg[e], 0)
-                    pending = [None if q == e else q for q in pending]     # the buffers of one group share an event
+                    pending = [None if q == e else q for q in pending]
             elif fn == 'wg_begin':
                 if two:
                     cc.event(YH_CMD_EVENT_RECORD, ev_gz, 0)
@@ -483,19 +431,11 @@ class BackwardMixin:
                     patches.append(('colsum', None, op.name, i))
             elif fn == 'wgrad':
                 _, op, wd, _m = cmd
-                if "wgrad" in ABL_SKIP:
+                if "wgrad" in _flags.ABL_SKIP:
                     continue
                 cc.call(L.yh_conv_wgrad, (wd,), 1 if two and id(wd) not in self._wgrad_on_main else 0, op.name)
                 if op.kind == 'plain':
                     patches.append(('wgrad', wd, op.name, -1))
-            elif fn == 'wgrad_group':
-                _, ops_, (arr, descs), _m = cmd
-                if "wgrad" in ABL_SKIP:
-                    continue
-                cc.call(L.yh_conv_wgrad_group, (arr, len(descs), _flags.WGS_GROUP_WG), 1 if two else 0, f"{ops_[0].name} +{len(descs) - 1}")
-                for op_, wd in zip(ops_, descs):
-                    if op_.kind == 'plain':      # the group reads its descriptors when it is launched: patched in place
-                        patches.append(('wgrad', wd, op_.name, -1))
             elif fn == 'dgrad':
                 _, op, d, _m = cmd
                 cc.call(L.yh_conv_igemm, (d,), 0, op.name)
@@ -503,7 +443,7 @@ class BackwardMixin:
                     patches.append(('dgrad', d, op.name, -1))
             else:
                 _, args, name, _m = cmd
-                if fn.__name__ in ABL_SKIP:
+                if fn.__name__ in _flags.ABL_SKIP:
                     continue
                 cc.call(fn, args, 0, name)
         while nb < len(buckets):
@@ -511,11 +451,13 @@ class BackwardMixin:
             nb += 1
         return cc, breaks, patches
 
-    def backward(self, head_grads, bucket_hook=None, frozen=False):
+    def backward(self, head_grads, bucket_hook=None, frozen=False, param_views=True):
         """head_grads: list of [B,h,w,ld] bf16 gradient buffers matching self.outputs (plain ops).
         bucket_hook(slice of the packed fp32 gradient arena) -> finisher or None: called as soon as a bucket of
         gradients is complete (data-parallel all-reduce overlapped with the remaining backward); finishers run
-        before the gradients are scattered to parameter order."""
+        before the gradients are scattered to parameter order.
+        param_views=False: only the flat gradient is wanted (the flat-arena optimizer): the 177 per-parameter views — ~0.5 ms of
+        host time between the last backward kernel and the optimizer's first — are not built."""
         if not self.bwd_ready:
             self._build_backward()
         cmd_bwd = self.cmd_bwd
@@ -578,7 +520,7 @@ class BackwardMixin:
             for f in finishers:
                 if f is not None:
                     f()
-            return pk.grads_to_params()
+            return pk.grads_to_params(param_views)
         for ci, cmd in enumerate(cmd_bwd):
             while nb < len(buckets) and buckets[nb][0] == ci:
                 finishers.append(self._bucket_ready(bucket_hook, buckets[nb], main if two else None, side if two else None))
@@ -607,7 +549,7 @@ class BackwardMixin:
                     for slot in cmd[1]:
                         pending[slot] = cmd[1][0]
                 continue
-            on_side = two and ((fn == 'wgrad' and id(cmd[2]) not in self._wgrad_on_main) or fn == 'wgrad_group' or
+            on_side = two and ((fn == 'wgrad' and id(cmd[2]) not in self._wgrad_on_main) or 
                                (fn == 'head_colsum' and self._head_on_side(cmd[1], two)))
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -627,14 +569,6 @@ class BackwardMixin:
                 rc = L.yh_conv_wgrad(C.byref(wd), st_side if on_side else st)
                 if rc:
                     check(rc, f"yh_conv_wgrad [{op.name}]")
-            elif fn == 'wgrad_group':
-                _, ops_, (arr, descs), _m = cmd
-                for op_, wd in zip(ops_, descs):
-                    if op_.kind == 'plain':
-                        wd.gy = heads[op_.name].data_ptr()
-                rc = L.yh_conv_wgrad_group(arr, len(descs), _flags.WGS_GROUP_WG, st_side if on_side else st)
-                if rc:
-                    check(rc, f"yh_conv_wgrad_group [{ops_[0].name}]")
             elif fn == 'dgrad':
                 _, op, d, _m = cmd
                 if op.kind == 'plain':
@@ -649,7 +583,7 @@ class BackwardMixin:
                     check(rc, f"{fn.__name__} bwd [{name}]")
             if prof is not None:
                 e1.record(side if on_side else None)
-                label = f"{cmd[1][0].name} +{len(cmd[1]) - 1}" if fn == 'wgrad_group' else (cmd[1].name if hasattr(cmd[1], 'name') else cmd[2])
+                label = cmd[1].name if hasattr(cmd[1], 'name') else cmd[2]
                 prof.setdefault(cmd[3] + (label,), []).append((e0, e1))
         while nb < len(buckets):
             finishers.append(self._bucket_ready(bucket_hook, buckets[nb], main if two else None, side if two else None))
@@ -660,4 +594,4 @@ class BackwardMixin:
         for f in finishers:
             if f is not None:
                 f()
-        return pk.grads_to_params()
+        return pk.grads_to_params(param_views)

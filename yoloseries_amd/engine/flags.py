@@ -1,4 +1,5 @@
-"""Environment switches of the engine (read once at import; tests patch the attributes of this module)."""
+"""Environment switches of the engine: read once at import into the attributes of this module; the engine reads every switch as
+`flags.X` at the point of use, so a test or tool that patches an attribute here changes the next program that is built."""
 import os
 
 BN_EPS_DEFAULT = 1e-3
@@ -21,25 +22,6 @@ HEAD_COLSUM_SIDE = os.environ.get("YH_HEAD_COLSUM_SIDE", "1") != "0"    # bias g
 SPPF_FUSE = os.environ.get("YH_SPPF_FUSE", "1") != "0"      # FastSPP's three pools in one launch per direction (csrc/sppf.hip)
 WG_WS_BYTES = (256 << 20) if os.environ.get("YH_WGRAD_PARTIAL", "0") == "1" else 0
 NGZ = int(os.environ.get("YH_GZ_RING", "3"))   # gz buffers the side-stream weight gradients may lag behind by
-# YH_WGS_GROUP=<n>: weight gradients of the wave-private form (conv_wgs_kernel) of up to n consecutive launches of the backward leave
-# in ONE yh_conv_wgrad_group launch (0 / 1: one launch per layer and segment).  What such a launch costs beside its main loop — ring
-# fill, combine, one 64 KB set of fp32 atomics per workgroup (12 us at 252 workgroups), the skew of the last workgroups — is paid
-# once per group: the weight gradients of a YOLOv5s C3 block at 20 x 20 take 84 us instead of 171 (tools/bench_wgs_group.py).  The
-# members' gz stay alive until the group runs: the gz ring grows to YH_WGS_GROUP_CBA + 3 buffers.
-# Measured (one box, profiles/r05_step_experiments.txt): the weight-gradient kernels of a YOLOv5s step 3.35 -> 2.70 ms, the
-# single-stream step 12.67 -> 12.23 ms — and the two-stream step UNCHANGED (11.70 / 11.71 / 11.71 against 11.68 / 11.73 ms at
-# 192 workgroups and 60 GFLOP; every other setting slower), YOLOv5l 40.27 -> 41.40 ms, YOLOXs 14.19 -> 14.41 ms: what a group
-# removes (atomic drain, ring fill, skew: phases in which the CUs are free) the main chain's kernels already filled, and a group
-# waits for its LAST member.  Default therefore 0; 8 is the setting of the measurements above.
-#   YH_WGS_GROUP_CBA    ConvBnAct layers a group may hold (their gz buffers are pinned meanwhile)
-#   YH_WGS_GROUP_GFLOP  a group is launched as soon as it holds this much work (the weight gradients should start while the main
-#                       chain still has work to hide them behind, and while their operands are in the memory-side cache)
-#   YH_WGS_GROUP_WG     workgroups of a group launch (one per CU)
-WGS_GROUP = int(os.environ.get("YH_WGS_GROUP", "0"))
-WGS_GROUP_CBA = int(os.environ.get("YH_WGS_GROUP_CBA", "5"))
-WGS_GROUP_GFLOP = float(os.environ.get("YH_WGS_GROUP_GFLOP", "60"))
-WGS_GROUP_WG = int(os.environ.get("YH_WGS_GROUP_WG", "192"))
-
 # YH_SKIP_ALGOS=<n>[,<n>]: leave these kernel families (yh_conv_desc.algo) out of the per-layer timing — A/B runs of a new family on
 # one box (use a YH_TUNE_CACHE of its own and YH_TUNE_DEFAULTS=0 for the layers concerned)
 SKIP_ALGOS = frozenset(x for x in os.environ.get("YH_SKIP_ALGOS", "").split(",") if x)

@@ -9,7 +9,6 @@ from .. import hipk
 from .._lib import BnFoldItem, BnPart, ConvDesc, YH_BN_MAX_PARTS, YH_ACT_NONE, YH_ACT_SILU, YH_CONV_FWD, YoloHipError, check
 from . import flags as _flags
 from .executor import CompiledCmds
-from .flags import ABL_SKIP, MERGE_PARTS
 from .graph import ConvOp, PoolOp, Ref, sppf_chain
 from .tune import _tune_cache_save
 
@@ -149,6 +148,11 @@ class ForwardMixin:
         if pk.fused_ops:
             raise YoloHipError(f"a model whose ConvBnAct layers went through fuse_conv_bn ({len(pk.fused_ops)} of them) has no BatchNorm "
                                "left to train: it runs the inference program only (call .eval() under torch.no_grad())")
+        if os.environ.get("YH_BWD_STREAMS", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+            # the backward's weight-gradient stream is probed HERE — on the caller's thread, at program build, before the training
+            # tensors exist — not inside the first backward() (autograd thread, activations resident): streams.py
+            from ..streams import side_stream
+            side_stream(self.dev)
         for b in self.bufs:
             if b.t is None and not getattr(b, "is_head", False):
                 b.t = torch.zeros(B, b.H, b.W, b.C, dtype=torch.bfloat16, device=self.dev)
@@ -193,7 +197,7 @@ class ForwardMixin:
             self.cmd_train.append((L.yh_conv_igemm, (d,), op.name, self._fam_conv(op, d)))
             st['ws'] = []
             c0 = 0
-            merged = MERGE_PARTS and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and op.res is None
+            merged = _flags.MERGE_PARTS and 2 <= len(op.parts) <= YH_BN_MAX_PARTS and op.res is None
             parts_arr = (BnPart * len(op.parts))() if merged else None
             for pi, ((conv, bn), n) in enumerate(zip(op.parts, op.part_N)):
                 ws = torch.zeros(4 * n, dtype=torch.float32, device=self.dev)
@@ -240,7 +244,7 @@ class ForwardMixin:
     def _compile(self, cmds):
         cc = CompiledCmds(self.L, len(cmds))
         for fn, args, name, meta in cmds:
-            if getattr(fn, "__name__", "") in ABL_SKIP:
+            if getattr(fn, "__name__", "") in _flags.ABL_SKIP:
                 continue
             cc.call(fn, args, 0, name)
         return cc

@@ -6,7 +6,8 @@ import torch
 from .. import hipk
 from .._lib import YoloHipError
 from ..hipk import Slice
-from .flags import BN_EPS_DEFAULT, SPPF_FUSE
+from . import flags as _flags
+from .flags import BN_EPS_DEFAULT
 
 
 def _rup(x, m):
@@ -82,7 +83,7 @@ class PoolOp:
 def sppf_chain(ops, i, L):
     """ops[i], ops[i+1], ops[i+2] = FastSPP's three max-pools chained through slices of one concat buffer (utils/layer_tools.py:282-288)
     on a map the fused kernels take (csrc/sppf.hip)?  YH_SPPF_FUSE=0: never."""
-    if not SPPF_FUSE or i + 2 >= len(ops) or not all(isinstance(o, PoolOp) for o in ops[i:i + 3]):
+    if not _flags.SPPF_FUSE or i + 2 >= len(ops) or not all(isinstance(o, PoolOp) for o in ops[i:i + 3]):
         return False
     a, b_, c = ops[i:i + 3]
     same = lambda r1, r2: r1.buf is r2.buf and r1.coff == r2.coff and r1.C == r2.C and not r1.ups and not r2.ups   # noqa: E731
@@ -340,10 +341,13 @@ class ParamPack:
         off, rows, K = self.wloc[key]
         return self.wpack.data_ptr() + 2 * off, rows, K
 
-    def grads_to_params(self):
-        """packed fp32 gradients -> one flat gradient in parameter order (fresh tensor per call)."""
+    def grads_to_params(self, views=True):
+        """packed fp32 gradients -> one flat gradient in parameter order (fresh tensor per call) and, unless views=False, its
+        per-parameter views."""
         flat_g = torch.empty(self.n, dtype=torch.float32, device=self.device)
         hipk.gather_f32(self.gpack, self.unpack_idx, flat_g)
+        if not views:
+            return flat_g, None
         outs, o = [], 0
         for p in self.params:
             outs.append(flat_g[o:o + p.numel()].view(p.shape))

@@ -49,7 +49,8 @@ class _NetFn(torch.autograd.Function):
         owner = getattr(bucket_hook, "__self__", None)
         if owner is not None and not getattr(owner, "buckets_active", True):
             bucket_hook = None                                      # no_sync / accumulation boundary: no per-bucket segmentation
-        flat_g, pgrads = prog.backward(head_grads, bucket_hook, frozen=ctx.frozen)
+        flat_only = bool(getattr(ctx.host, "flat_grads_only", False))
+        flat_g, pgrads = prog.backward(head_grads, bucket_hook, frozen=ctx.frozen, param_views=not flat_only)
         ctx.host._yh_last_flat_grad = flat_g
         # whole-gradient hook of the data-parallel exchange: all-reduces flat_g when no bucket hook ran, keeps the
         # books of un-exchanged accumulation steps, and at an accumulation boundary swaps in the averaged total
@@ -59,9 +60,9 @@ class _NetFn(torch.autograd.Function):
         hook = getattr(ctx.host, "_yh_grad_hook_opt", None)    # flat-arena optimizer
         if hook is not None:
             hook(flat_g)
-        if getattr(ctx.host, "flat_grads_only", False):
+        if flat_only:
             # the flat-arena optimizer (utils/optim.py FlatSGD) consumes flat_g directly; skip 177 AccumulateGrad nodes
-            pgrads = [None] * len(pgrads)
+            pgrads = [None] * len(prog.pack.params)
         gx = None
         if ctx.needs_input_grad[2] and prog.in_buf.needs_grad and prog.in_buf.g is not None:
             gx = prog.in_buf.g.permute(0, 3, 1, 2).float()

@@ -7,7 +7,7 @@ import os
 import torch
 
 from .._lib import YH_CONV_DGRAD, check
-from .flags import SKIP_ALGOS, TUNE_ITERS
+from . import flags as _flags
 
 # the table shipped with the package lives beside the package modules
 TUNE_DEFAULTS_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tune_defaults.json")
@@ -153,7 +153,7 @@ class TunerMixin:
         d.tile_k = d.grid_cap = 0
         if os.environ.get("YH_CONV_V3", "1") != "0":
             for algo in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13):
-                if str(algo) in SKIP_ALGOS:
+                if str(algo) in _flags.SKIP_ALGOS:
                     continue
                 d.algo = algo
                 kn = self._kernel_name(d)
@@ -184,12 +184,12 @@ class TunerMixin:
             check(L.yh_conv_igemm(C.byref(d), st), f"yh_conv_igemm tune [{name}]")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(TUNE_ITERS):
+            for _ in range(_flags.TUNE_ITERS):
                 L.yh_conv_igemm(C.byref(d), st)
             e1.record()
             e1.synchronize()
             ms = e0.elapsed_time(e1)
-            if best_ms is None or ms < best_ms * (0.97 if TUNE_ITERS < 8 else 0.99):   # keep the earlier candidate unless clearly better
+            if best_ms is None or ms < best_ms * (0.97 if _flags.TUNE_ITERS < 8 else 0.99):   # keep the earlier candidate unless clearly better
                 best, best_ms = (tk, cap, algo), ms
         d.tile_k, d.grid_cap, d.algo = best
         d.seg[0].ptr, d.stats = saved
@@ -269,7 +269,7 @@ class TunerMixin:
                 check(self.L.yh_conv_wgrad(C.byref(wd), st), f"yh_conv_wgrad tune [{op.name}]")
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(TUNE_ITERS):
+                for _ in range(_flags.TUNE_ITERS):
                     self.L.yh_conv_wgrad(C.byref(wd), st)
                 e1.record()
                 e1.synchronize()
@@ -278,7 +278,7 @@ class TunerMixin:
                     best, best_ms = (sp, tk), ms
         wd.gy = gy_saved
         wd.tile_k = best[1]
-        self.wgrad_tuned[(op.name, wd.coff_k)] = (best[0], best_ms / TUNE_ITERS)
+        self.wgrad_tuned[(op.name, wd.coff_k)] = (best[0], best_ms / _flags.TUNE_ITERS)
         cache[key] = [int(best[0]), int(best[1])]
         return best[0]
 

@@ -116,19 +116,6 @@ def wgrad_launch(d: WgradDesc):
     check(lib().yh_conv_wgrad(C.byref(d), _st()), "yh_conv_wgrad")
 
 
-def wgrad_group_array(descs):
-    """the `const yh_wgrad_desc* const*` argument of yh_conv_wgrad_group for a list of descriptors (keep both alive)"""
-    arr = (C.POINTER(WgradDesc) * len(descs))()
-    for i, d in enumerate(descs):
-        arr[i] = C.pointer(d)
-    return arr
-
-
-def wgrad_group_launch(descs, workgroups):
-    arr = wgrad_group_array(descs)
-    check(lib().yh_conv_wgrad_group(arr, len(descs), workgroups, _st()), "yh_conv_wgrad_group")
-
-
 def bn_finalize(stats, nblk, ldstat, Cn, count, gamma, beta, rm, rv, nbt, eps, momentum, ws):
     check(lib().yh_bn_finalize(_p(stats), nblk, ldstat, Cn, count, _p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt),
                                eps, momentum, _p(ws), _st()), "yh_bn_finalize")

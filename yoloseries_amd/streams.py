@@ -14,7 +14,8 @@ import warnings
 
 import torch
 
-_PROBE_BYTES = 1 << 30
+_PROBE_BYTES = 128 << 20      # filled _PROBE_FILLS times per probe: ~1.5 ms of device time against 128 MiB of memory
+_PROBE_FILLS = 24
 _cache = {}
 
 
@@ -26,8 +27,8 @@ def _runs_beside(cand, others, big, tiny):
         e0, e1, c1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         with torch.cuda.stream(other):
             e0.record()
-            big.zero_()
-            big.zero_()
+            for _ in range(_PROBE_FILLS):
+                big.zero_()
             e1.record()
         with torch.cuda.stream(cand):
             tiny.zero_()
@@ -44,6 +45,21 @@ def concurrent_stream(dev, beside, priority=0, tries=8):
     dev = torch.device(dev)
     if os.environ.get("YH_STREAM_PROBE", "1") == "0":
         return torch.cuda.Stream(device=dev, priority=priority)
+    if torch.cuda.is_current_stream_capturing():
+        # the probe synchronises the device: not inside a capture.  A fresh stream, unprobed (side_stream() does not cache it).
+        warnings.warn("yoloseries_amd: stream probe skipped inside a graph capture; run one eager step before capturing",
+                      RuntimeWarning, stacklevel=2)
+        return torch.cuda.Stream(device=dev, priority=priority)
+    try:
+        return _probe(dev, beside, priority, tries)
+    except (torch.cuda.OutOfMemoryError, RuntimeError) as e:
+        # a memory-tight configuration (the probe buffer) or a HIP error of the probe itself must not end a training run
+        warnings.warn(f"yoloseries_amd: stream probe failed ({type(e).__name__}: {str(e)[:120]}); using an unprobed stream",
+                      RuntimeWarning, stacklevel=2)
+        return torch.cuda.Stream(device=dev, priority=priority)
+
+
+def _probe(dev, beside, priority, tries):
     big = torch.empty(_PROBE_BYTES, dtype=torch.uint8, device=dev)
     tiny = torch.empty(256, dtype=torch.uint8, device=dev)
     keep, found = [], None            # rejected candidates stay referenced until the choice is made, so the pool moves on
@@ -66,7 +82,8 @@ def concurrent_stream(dev, beside, priority=0, tries=8):
         warnings.warn("yoloseries_amd: no HIP stream runs beside the compute stream in this process (every candidate shares its "
                       "hardware queue): the two-stream schedule will run as one queue; GPU_MAX_HW_QUEUES=8 in the environment "
                       "gives the runtime more queues", RuntimeWarning, stacklevel=2)
-        found = keep[0] if keep else torch.cuda.Stream(device=dev, priority=priority)
+        # every kept candidate was SEEN to share the compute queue: a fresh stream is at least unknown
+        found = torch.cuda.Stream(device=dev, priority=priority)
     return found
 
 
@@ -86,7 +103,11 @@ def side_stream(dev):
     dev = _indexed(dev)
     key = ("side", dev.index)
     if key not in _cache:
-        _cache[key] = concurrent_stream(dev, _compute_streams(dev), priority=int(os.environ.get("YH_SIDE_PRIO", "0")))
+        capturing = torch.cuda.is_current_stream_capturing()
+        st = concurrent_stream(dev, _compute_streams(dev), priority=int(os.environ.get("YH_SIDE_PRIO", "0")))
+        if capturing:
+            return st
+        _cache[key] = st
     return _cache[key]
 
 

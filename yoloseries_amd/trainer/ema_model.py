@@ -84,7 +84,9 @@ class ExponentialMovingAverageModel:
             pack = st['pack'] if st else None
             from .. import hipk
             fast = self._fast
-            if fast is not None and fast[0] is pack and pack.still_valid() and self._dev_state is not None and \
+            # every 64th update takes the full path below (valid_for() walks every parameter of both modules: a re-created or
+            # replaced MIDDLE parameter, which the first / last pointer checks of still_valid() cannot see, ends the fast path there)
+            if fast is not None and (self.update_num & 63) != 0 and fast[0] is pack and pack.still_valid() and self._dev_state is not None and \
                     self._dev_state[2] == self.update_num - 1 and self._dst_unchanged(fast):
                 # steady state of a training loop: same arenas as last time — three launches and no walk over the 177 parameters
                 # (the full validity checks below cost ~0.2 ms of host time per step, a visible gap in a profiler trace)
