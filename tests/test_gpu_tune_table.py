@@ -189,8 +189,10 @@ def test_conv_entries_at_judged_shapes(dev, chunk):
 
 
 def test_conv_entries_launch_to_launch_bit_identical(dev):
-    """every conv entry of the shipped table (forward, data gradient, inference; 530 shapes) launched six times into NaN-filled
-    outputs with other kernels in between: outputs, statistics and fused-reduction slabs of every launch bit-identical to the first
+    """every conv entry of the shipped table (forward, data gradient, inference; 530 shapes) launched six times — FORTY times for the
+    families with hand-counted waits (conv_pt_kernel, conv_halo160_kernel, conv_wgs_kernel: round 5's errors showed in 1 launch of 60) —
+    into NaN-filled outputs, every launch NEXT TO A BUSY SECOND STREAM (copies and matmuls: the conditions of the two-stream step):
+    outputs, statistics and fused-reduction slabs of every launch bit-identical to the first
     (the kernels are deterministic: a difference is a missing wait or a hazard; the weight-gradient entries — fp32 atomics — within 1e-3 of
     the largest element — the screen that reproduces round 5's store hazard
     of conv_pt_kernel on every box, tools/race_screen.py) and no NaN left in a first launch's output"""
@@ -198,7 +200,7 @@ def test_conv_entries_launch_to_launch_bit_identical(dev):
     spec = importlib.util.spec_from_file_location("race_screen", os.path.join(ROOT, "tools", "race_screen.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    n, bad, fams = mod.screen(6, "", verbose=False)
+    n, bad, fams = mod.screen(6, "", verbose=False, beside=True)
     assert n >= 600 and len(fams) >= 12
     assert not bad, bad[:5]
 

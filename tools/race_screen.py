@@ -11,8 +11,15 @@ from yoloseries_amd import hipk
 from yoloseries_amd._lib import YH_ACT_SILU, YH_CONV_DGRAD, check, lib
 
 
-def screen(reps=6, sub="", verbose=True, beside=False):
-    """-> (entries walked, [(key, kernel, differences)]): see the module docstring"""
+# kernel families with hand-counted waits / inline-asm transfers (where round 5's two synchronisation errors were: 1 launch in 60 at
+# worst): screened with this many launches per entry even when the caller asks for fewer
+DEEP_FAMILIES = {"conv_pt_kernel": 40, "conv_halo160_kernel": 40, "conv_wgs_kernel": 40}
+
+
+def screen(reps=6, sub="", verbose=True, beside=False, deep=None):
+    """-> (entries walked, [(key, kernel, differences)]): see the module docstring.  deep: {kernel family: launches per entry}
+    overriding `reps` upwards for those families (default DEEP_FAMILIES; {} = none)"""
+    deep = DEEP_FAMILIES if deep is None else deep
     dev = torch.device("cuda:0")
     L = lib()
     # beside=True: every screened launch runs next to a stream of memory-bound copies and matmuls on a second stream (the conditions
@@ -62,7 +69,9 @@ def screen(reps=6, sub="", verbose=True, beside=False):
             z = torch.randn(B, Ho, Wo, N, generator=g, device=dev).to(torch.bfloat16)
             ws = torch.cat([torch.rand(N, generator=g, device=dev) + 0.5, torch.randn(N, generator=g, device=dev)])
         first, diffs, name = None, [], ""
-        for r in range(reps):
+        r, nrep = -1, reps
+        while r + 1 < nrep:
+            r += 1
             out0 = acc0.clone() if accumulate else torch.full((B, Ho, Wo, ldo), nan, dtype=torch.bfloat16, device=dev)
             out1 = torch.full((B, Ho, Wo, N - n0 + 8), nan, dtype=torch.bfloat16, device=dev) if n0 < N else None
             d = hipk.conv_desc(segs, mode, B, Ho, Wo, Hi, Wi, k, stride, pad, wp, N, hipk.Slice(out0, 0, n0), nsplit=n0,
@@ -81,6 +90,7 @@ def screen(reps=6, sub="", verbose=True, beside=False):
             if r == 0:
                 nb = C.create_string_buffer(96); L.yh_conv_kernel_name(C.byref(d), nb, 96); name = nb.value.decode()
                 fams[name.split("<")[0]] = fams.get(name.split("<")[0], 0) + 1
+                nrep = max(reps, deep.get(name.split("<")[0], 0))
             junk = torch.randn(1024, 1024, device=dev) @ torch.randn(1024, 256, device=dev)      # noqa: F841
             busy()
             check(L.yh_conv_igemm(C.byref(d), st()), key)
@@ -115,13 +125,16 @@ def screen(reps=6, sub="", verbose=True, beside=False):
         x = torch.randn(B, Hi >> ups, Wi >> ups, ld0, generator=g, device=dev).to(torch.bfloat16)
         gy = (torch.randn(B, Ho, Wo, ldg, generator=g, device=dev) * 0.25).to(torch.bfloat16)
         first, diffs, name = None, [], ""
-        for r in range(reps):
+        r, nrep = -1, reps
+        while r + 1 < nrep:
+            r += 1
             dw = torch.zeros(N, k * k * Ctot, device=dev)
             d = hipk.wgrad_desc(hipk.Slice(gy, 0, N), N, hipk.Slice(x, 0, C0, ups), Ctot - C0, Ctot, B, Ho, Wo, Hi, Wi, k, stride, pad, dw, splits)
             d.tile_k = tile_k
             if r == 0:
                 name = Program._wgrad_name(L, d)
                 fams[name.split("<")[0]] = fams.get(name.split("<")[0], 0) + 1
+                nrep = max(reps, deep.get(name.split("<")[0], 0))
             junk = torch.randn(1024, 1024, device=dev) @ torch.randn(1024, 256, device=dev)      # noqa: F841
             busy()
             check(L.yh_conv_wgrad(C.byref(d), st()), key)

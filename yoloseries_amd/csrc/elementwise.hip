@@ -17,32 +17,6 @@ __device__ __forceinline__ uint4 ld_nt(const uint16_t* p) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-// Store policy of the BN+SiLU passes' output (template parameter ST; YH_EW_STORE selects it at run time for A/B runs):
-// 0 plain, 1 non-temporal (nt), 2 write-through at agent scope (sc1): a kernel boundary waits for the write-back of whatever its
-// predecessor left dirty in the eight L2s (MI355X_MICROARCH.md, price list row 'boundary').
-template <int ST>
-__device__ __forceinline__ void st16(uint16_t* p, const uint4& v) {
-    if (ST == 1) {
-        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-        u4 w = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(w, reinterpret_cast<u4*>(p));
-    } else if (ST == 2) {
-        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-        const u4 w = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
-    } else {
-        *reinterpret_cast<uint4*>(p) = v;
-    }
-}
-inline int ew_store_mode() { static const int v = [] { const char* e = getenv("YH_EW_STORE"); return e ? atoi(e) : 0; }(); return v; }
-#define YH_EW_LAUNCH(KERNEL, GRID, ...)                                                                                         \
-    do {                                                                                                                        \
-        const int stm_ = ew_store_mode();                                                                                       \
-        if (stm_ == 1)      hipLaunchKernelGGL((KERNEL<1>), GRID, dim3(EW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__);        \
-        else if (stm_ == 2) hipLaunchKernelGGL((KERNEL<2>), GRID, dim3(EW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__);        \
-        else                hipLaunchKernelGGL((KERNEL<0>), GRID, dim3(EW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__);        \
-    } while (0)
-
 // ---------------------------------------------------------------- BN finalize
 // Deterministic column sums of a [nblk][nwhich][ld] partial slab.  These kernels sit on the layer chain's critical path
 // (conv -> finalize -> apply) and move little data, so they are built for latency: one block = FIN_CPB channels
@@ -179,10 +153,9 @@ __global__ void bn_fold_batch_kernel(const yh_bn_fold_item* items)
 // ---------------------------------------------------------------- BN+SiLU apply
 // Grid-stride over 16-byte chunks with a stride that is a multiple of the chunks per row, so a thread
 // keeps its 8 channels for the whole pass and the per-channel constants live in registers.
-template <int ST>
 __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, const float* __restrict__ ws, int C, int cpr,
                                      long M, uint16_t* __restrict__ out, int ldo,
-                                     const uint16_t* __restrict__ res, int ldr)
+                                     const uint16_t* __restrict__ res, int ldr, int rev)
 {
     const long T = (long)gridDim.x * blockDim.x;
     const long rstep = T / cpr;
@@ -193,7 +166,8 @@ __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, co
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = ws[c + e]; sh[e] = ws[C + c + e]; }
-    for (; m < M; m += rstep) {
+    for (long mi = m; mi < M; mi += rstep) {
+        m = rev ? M - 1 - mi : mi;
         uint4 v = *reinterpret_cast<const uint4*>(y + m * ldy + c);
         float f[8];
         unpack8(v, f);
@@ -207,7 +181,7 @@ __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, co
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = bf_round(f[e]) + g[e];
         }
-        st16<ST>(out + m * ldo + c, pack8(f));
+        *reinterpret_cast<uint4*>(out + m * ldo + c) = pack8(f);
     }
 }
 
@@ -246,8 +220,7 @@ __device__ __forceinline__ int part_of(const PartsK& P, int c, int& c_in)
     return k;
 }
 
-template <int ST>
-__global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M)
+__global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M, int rev)
 {
     const long T = (long)gridDim.x * blockDim.x;
     const long rstep = T / cpr;
@@ -264,13 +237,14 @@ __global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int l
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = ws[cp + e]; sh[e] = ws[Cp + cp + e]; }
-    for (; m < M; m += rstep) {
+    for (long mi = m; mi < M; mi += rstep) {
+        m = rev ? M - 1 - mi : mi;
         uint4 v = *reinterpret_cast<const uint4*>(y + m * ldy + c);
         float f[8];
         unpack8(v, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = silu_fast(f[e] * sc[e] + sh[e]);
-        st16<ST>(out + m * ldo, pack8(f));
+        *reinterpret_cast<uint4*>(out + m * ldo) = pack8(f);
     }
 }
 
@@ -412,11 +386,10 @@ __global__ __launch_bounds__(FIN_NT) void colsum_finalize_kernel(const float* __
 
 // gz = gamma*is*(dz - c1 - xhat*c2) with dz = g*silu'(z), xhat = (y-mu)*is, written per channel as
 // gz = A*dz + Bc*y + D (constants in registers, see bn_silu_apply_kernel for the striding).
-template <int ST>
 __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ldga, const uint16_t* __restrict__ y, int ldy,
                                          const float* __restrict__ ws, const float* __restrict__ gamma,
                                          const float* __restrict__ coef, int C, int cpr, long M,
-                                         uint16_t* __restrict__ gy, int ldgy, uint16_t* gres, int ldgres, int gres_acc)
+                                         uint16_t* __restrict__ gy, int ldgy, uint16_t* gres, int ldgres, int gres_acc, int rev)
 {
     const long T = (long)gridDim.x * blockDim.x;
     const long rstep = T / cpr;
@@ -435,7 +408,8 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
         Bc[e] = -gi * is * c2;
         D[e] = gi * (mu * is * c2 - c1);
     }
-    for (; m < M; m += rstep) {
+    for (long mi = m; mi < M; mi += rstep) {
+        m = rev ? M - 1 - mi : mi;
         // last readers of both tensors: streamed (non-temporal), they should not displace the gz rows written below,
         // which the weight- and data-gradient kernels read next
         uint4 gv = ld_nt(ga + m * ldga + c);
@@ -450,7 +424,7 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
             float dz = g[e] * (sg * (1.f + z * (1.f - sg)));
             o[e] = A[e] * dz + (Bc[e] * yy[e] + D[e]);
         }
-        st16<ST>(gy + m * ldgy + c, pack8(o));
+        *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
         if (gres) {
             uint16_t* dst = gres + m * ldgres + c;
             if (gres_acc) {
@@ -469,9 +443,8 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
 
 // bn_silu_bwd_apply over all parts of a stacked layer in one pass (see bn_silu_apply_parts_kernel): a part brings its own incoming
 // gradient tensor; gz of all parts is one buffer.
-template <int ST>
 __global__ void bn_silu_bwd_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M,
-                                               uint16_t* __restrict__ gy, int ldgy)
+                                               uint16_t* __restrict__ gy, int ldgy, int rev)
 {
     const long T = (long)gridDim.x * blockDim.x;
     const long rstep = T / cpr;
@@ -498,7 +471,8 @@ __global__ void bn_silu_bwd_apply_parts_kernel(const uint16_t* __restrict__ y, i
         Bc[e] = -gi * is * c2;
         D[e] = gi * (mu * is * c2 - c1);
     }
-    for (; m < M; m += rstep) {
+    for (long mi = m; mi < M; mi += rstep) {
+        m = rev ? M - 1 - mi : mi;
         uint4 gv = ld_nt(ga + m * ldga);
         uint4 yv = ld_nt(y + m * ldy + c);
         float g[8], yy[8], o[8];
@@ -511,7 +485,7 @@ __global__ void bn_silu_bwd_apply_parts_kernel(const uint16_t* __restrict__ y, i
             float dz = g[e] * (sg * (1.f + z * (1.f - sg)));
             o[e] = A[e] * dz + (Bc[e] * yy[e] + D[e]);
         }
-        st16<ST>(gy + m * ldgy + c, pack8(o));
+        *reinterpret_cast<uint4*>(gy + m * ldgy + c) = pack8(o);
     }
 }
 
@@ -698,6 +672,10 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n)
 // weight-gradient workgroup (128 KiB of the 160) and go to the CUs it leaves free (experiment: profiles/r04_step_experiments.txt, t)
 inline unsigned fin_lds_pad() { static const unsigned v = [] { const char* e = getenv("YH_FIN_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }(); return v; }
 
+// YH_EW_REV (A/B): bit 0: the forward BN+SiLU passes walk the rows last to first, bit 1: the backward passes do — a pass then starts
+// on the rows its producer wrote LAST (the part of the tensor the 256 MB memory-side cache may still hold)
+inline int ew_rev() { static const int v = [] { const char* e = getenv("YH_EW_REV"); return e ? atoi(e) : 0; }(); return v; }
+
 inline int ew_grid(long nthreads) {
     long g = (nthreads + EW_THREADS - 1) / EW_THREADS;
     if (g > 256 * 8) g = 256 * 8;          // 8 blocks of 256 threads per CU: measured against 4 / 6 / 10 / 16 / 32 and 128- / 512-thread blocks on the train step
@@ -762,7 +740,8 @@ extern "C" int yh_bn_silu_apply(const yh_bf16* y, int ldy, const float* ws, int 
     if (res) YH_CHECK_SLICE("yh_bn_silu_apply", res, ldr, C);
     int cpr = C / 8;
     long nch = (long)M * cpr;
-    YH_EW_LAUNCH(bn_silu_apply_kernel, dim3(ew_grid(nch)), y, ldy, ws, C, cpr, (long)M, out, ldo, res, ldr);
+    hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       y, ldy, ws, C, cpr, (long)M, out, ldo, res, ldr, ew_rev() & 1);
     YH_CHECK_LAUNCH("yh_bn_silu_apply");
     return YH_OK;
 }
@@ -803,7 +782,8 @@ extern "C" int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* 
     if (gres) YH_CHECK_SLICE("yh_bn_silu_bwd_apply", gres, ldgres, C);
     int cpr = C / 8;
     long nch = (long)M * cpr;
-    YH_EW_LAUNCH(bn_silu_bwd_apply_kernel, dim3(ew_grid(nch)), ga, ldga, y, ldy, ws, gamma, coef, C, cpr, (long)M, gy, ldgy, gres, ldgres, gres_accumulate);
+    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       ga, ldga, y, ldy, ws, gamma, coef, C, cpr, (long)M, gy, ldgy, gres, ldgres, gres_accumulate, (ew_rev() >> 1) & 1);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply");
     return YH_OK;
 }
@@ -872,7 +852,7 @@ extern "C" int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, cons
     YH_CHECK_ARG(M > 0, "yh_bn_silu_apply_parts: bad M");
     YH_CHECK_SLICE("yh_bn_silu_apply_parts", y, ldy, C);
     const int cpr = C / 8;
-    YH_EW_LAUNCH(bn_silu_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), y, ldy, P, cpr, (long)M);
+    hipLaunchKernelGGL(bn_silu_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, ldy, P, cpr, (long)M, ew_rev() & 1);
     YH_CHECK_LAUNCH("yh_bn_silu_apply_parts");
     return YH_OK;
 }
@@ -888,7 +868,8 @@ extern "C" int yh_bn_silu_bwd_apply_parts(const yh_bf16* y, int ldy, int64_t M, 
     YH_CHECK_SLICE("yh_bn_silu_bwd_apply_parts", y, ldy, C);
     YH_CHECK_SLICE("yh_bn_silu_bwd_apply_parts", gy, ldgy, C);
     const int cpr = C / 8;
-    YH_EW_LAUNCH(bn_silu_bwd_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), y, ldy, P, cpr, (long)M, gy, ldgy);
+    hipLaunchKernelGGL(bn_silu_bwd_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       y, ldy, P, cpr, (long)M, gy, ldgy, (ew_rev() >> 1) & 1);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply_parts");
     return YH_OK;
 }
