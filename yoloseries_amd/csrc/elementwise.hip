@@ -155,7 +155,7 @@ __global__ void bn_fold_batch_kernel(const yh_bn_fold_item* items)
 // keeps its 8 channels for the whole pass and the per-channel constants live in registers.
 __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, const float* __restrict__ ws, int C, int cpr,
                                      long M, uint16_t* __restrict__ out, int ldo,
-                                     const uint16_t* __restrict__ res, int ldr, int rev)
+                                     const uint16_t* __restrict__ res, int ldr)
 {
     const long T = (long)gridDim.x * blockDim.x;
     const long rstep = T / cpr;
@@ -166,8 +166,7 @@ __global__ void bn_silu_apply_kernel(const uint16_t* __restrict__ y, int ldy, co
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = ws[c + e]; sh[e] = ws[C + c + e]; }
-    for (long mi = m; mi < M; mi += rstep) {
-        m = rev ? M - 1 - mi : mi;
+    for (; m < M; m += rstep) {
         uint4 v = *reinterpret_cast<const uint4*>(y + m * ldy + c);
         float f[8];
         unpack8(v, f);
@@ -220,7 +219,7 @@ __device__ __forceinline__ int part_of(const PartsK& P, int c, int& c_in)
     return k;
 }
 
-__global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M, int rev)
+__global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M)
 {
     const long T = (long)gridDim.x * blockDim.x;
     const long rstep = T / cpr;
@@ -237,8 +236,7 @@ __global__ void bn_silu_apply_parts_kernel(const uint16_t* __restrict__ y, int l
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = ws[cp + e]; sh[e] = ws[Cp + cp + e]; }
-    for (long mi = m; mi < M; mi += rstep) {
-        m = rev ? M - 1 - mi : mi;
+    for (; m < M; m += rstep) {
         uint4 v = *reinterpret_cast<const uint4*>(y + m * ldy + c);
         float f[8];
         unpack8(v, f);
@@ -389,7 +387,7 @@ __global__ __launch_bounds__(FIN_NT) void colsum_finalize_kernel(const float* __
 __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ldga, const uint16_t* __restrict__ y, int ldy,
                                          const float* __restrict__ ws, const float* __restrict__ gamma,
                                          const float* __restrict__ coef, int C, int cpr, long M,
-                                         uint16_t* __restrict__ gy, int ldgy, uint16_t* gres, int ldgres, int gres_acc, int rev)
+                                         uint16_t* __restrict__ gy, int ldgy, uint16_t* gres, int ldgres, int gres_acc)
 {
     const long T = (long)gridDim.x * blockDim.x;
     const long rstep = T / cpr;
@@ -408,8 +406,7 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
         Bc[e] = -gi * is * c2;
         D[e] = gi * (mu * is * c2 - c1);
     }
-    for (long mi = m; mi < M; mi += rstep) {
-        m = rev ? M - 1 - mi : mi;
+    for (; m < M; m += rstep) {
         // last readers of both tensors: streamed (non-temporal), they should not displace the gz rows written below,
         // which the weight- and data-gradient kernels read next
         uint4 gv = ld_nt(ga + m * ldga + c);
@@ -444,7 +441,7 @@ __global__ void bn_silu_bwd_apply_kernel(const uint16_t* __restrict__ ga, int ld
 // bn_silu_bwd_apply over all parts of a stacked layer in one pass (see bn_silu_apply_parts_kernel): a part brings its own incoming
 // gradient tensor; gz of all parts is one buffer.
 __global__ void bn_silu_bwd_apply_parts_kernel(const uint16_t* __restrict__ y, int ldy, const PartsK P, int cpr, long M,
-                                               uint16_t* __restrict__ gy, int ldgy, int rev)
+                                               uint16_t* __restrict__ gy, int ldgy)
 {
     const long T = (long)gridDim.x * blockDim.x;
     const long rstep = T / cpr;
@@ -471,8 +468,7 @@ __global__ void bn_silu_bwd_apply_parts_kernel(const uint16_t* __restrict__ y, i
         Bc[e] = -gi * is * c2;
         D[e] = gi * (mu * is * c2 - c1);
     }
-    for (long mi = m; mi < M; mi += rstep) {
-        m = rev ? M - 1 - mi : mi;
+    for (; m < M; m += rstep) {
         uint4 gv = ld_nt(ga + m * ldga);
         uint4 yv = ld_nt(y + m * ldy + c);
         float g[8], yy[8], o[8];
@@ -672,10 +668,6 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n)
 // weight-gradient workgroup (128 KiB of the 160) and go to the CUs it leaves free (experiment: profiles/r04_step_experiments.txt, t)
 inline unsigned fin_lds_pad() { static const unsigned v = [] { const char* e = getenv("YH_FIN_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }(); return v; }
 
-// YH_EW_REV (A/B): bit 0: the forward BN+SiLU passes walk the rows last to first, bit 1: the backward passes do — a pass then starts
-// on the rows its producer wrote LAST (the part of the tensor the 256 MB memory-side cache may still hold)
-inline int ew_rev() { static const int v = [] { const char* e = getenv("YH_EW_REV"); return e ? atoi(e) : 0; }(); return v; }
-
 inline int ew_grid(long nthreads) {
     long g = (nthreads + EW_THREADS - 1) / EW_THREADS;
     if (g > 256 * 8) g = 256 * 8;          // 8 blocks of 256 threads per CU: measured against 4 / 6 / 10 / 16 / 32 and 128- / 512-thread blocks on the train step
@@ -741,7 +733,7 @@ extern "C" int yh_bn_silu_apply(const yh_bf16* y, int ldy, const float* ws, int 
     int cpr = C / 8;
     long nch = (long)M * cpr;
     hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       y, ldy, ws, C, cpr, (long)M, out, ldo, res, ldr, ew_rev() & 1);
+                       y, ldy, ws, C, cpr, (long)M, out, ldo, res, ldr);
     YH_CHECK_LAUNCH("yh_bn_silu_apply");
     return YH_OK;
 }
@@ -783,7 +775,7 @@ extern "C" int yh_bn_silu_bwd_apply(const yh_bf16* ga, int ldga, const yh_bf16* 
     int cpr = C / 8;
     long nch = (long)M * cpr;
     hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(ew_grid(nch)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       ga, ldga, y, ldy, ws, gamma, coef, C, cpr, (long)M, gy, ldgy, gres, ldgres, gres_accumulate, (ew_rev() >> 1) & 1);
+                       ga, ldga, y, ldy, ws, gamma, coef, C, cpr, (long)M, gy, ldgy, gres, ldgres, gres_accumulate);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply");
     return YH_OK;
 }
@@ -852,7 +844,7 @@ extern "C" int yh_bn_silu_apply_parts(const yh_bf16* y, int ldy, int64_t M, cons
     YH_CHECK_ARG(M > 0, "yh_bn_silu_apply_parts: bad M");
     YH_CHECK_SLICE("yh_bn_silu_apply_parts", y, ldy, C);
     const int cpr = C / 8;
-    hipLaunchKernelGGL(bn_silu_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, ldy, P, cpr, (long)M, ew_rev() & 1);
+    hipLaunchKernelGGL(bn_silu_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, ldy, P, cpr, (long)M);
     YH_CHECK_LAUNCH("yh_bn_silu_apply_parts");
     return YH_OK;
 }
@@ -869,7 +861,7 @@ extern "C" int yh_bn_silu_bwd_apply_parts(const yh_bf16* y, int ldy, int64_t M, 
     YH_CHECK_SLICE("yh_bn_silu_bwd_apply_parts", gy, ldgy, C);
     const int cpr = C / 8;
     hipLaunchKernelGGL(bn_silu_bwd_apply_parts_kernel, dim3(ew_grid((long)M * cpr)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       y, ldy, P, cpr, (long)M, gy, ldgy, (ew_rev() >> 1) & 1);
+                       y, ldy, P, cpr, (long)M, gy, ldgy);
     YH_CHECK_LAUNCH("yh_bn_silu_bwd_apply_parts");
     return YH_OK;
 }
