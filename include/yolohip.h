@@ -118,7 +118,9 @@ typedef struct yh_conv_desc {
                            * 13 the training pointwise kernel (conv_pt_kernel: 1x1 / s1 / p0, forward or data gradient, 128 or 256 input
                            * channels in one segment or in two equal halves (either may be upsampled), one destination; plain /
                            * statistics / generic / fused-reduction epilogues: 32-pixel tiles whole in LDS through a four-deep ring with
-                           * counted waits, the 128 x C weight tile resident, no k loop over memory) */
+                           * counted waits, the 128 x C weight tile resident, no k loop over memory);
+                           * 14 the LDS-DMA ring kernel with a 256 x 256 tile (8 waves of 128 x 64, two stages of 64 channels: half the
+                           * staged bytes per MFMA of the 256 x 128 tile): N a multiple of 256, whole 64-channel blocks in every segment */
     /* DGRAD only — fused BatchNorm+SiLU backward reduction of the layer whose output gradient this launch writes
      * (it must be the LAST writer of that gradient: out0 covers exactly the producer's N channels; with `accumulate` the earlier
      * contributions already in out0 are added first and the sums are taken over the rounded total):

@@ -490,6 +490,8 @@ def _expect_family(d, algo):
     kn = _kname(d)
     if algo in (2, 3, 4):
         assert "conv_v3_kernel" in kn, kn
+    if algo == 14:
+        assert "conv_v3_kernel<256, 256" in kn, kn
     if algo == 5 and "conv_halo_kernel" not in kn:
         pytest.skip("shape not eligible for the halo kernel")
     if algo == 7:
@@ -544,6 +546,24 @@ def test_conv_fwd_algos(dev, B, H, W, Cin, Cout, k, s, p, algo):
             tol2 = 1e-2 + 4 * 2.0 ** -8 * (o ** 4).sum(0).sqrt()
             assert ((stats[:, 0, :Cout].double().sum(0) - o.sum(0)).abs() <= tol1).all()
             assert ((stats[:, 1, :Cout].double().sum(0) - (o ** 2).sum(0)).abs() <= tol2).all()
+
+
+V3W_CASES = [
+    # B, H, W, Cin, Cout, k, s, p — the 256 x 256 tile of the LDS-DMA ring kernel (algo 14): Cin % 64 == 0 and, on the side that
+    # becomes N (Cout forward, Cin data gradient), a multiple of 256
+    (2, 24, 24, 256, 256, 3, 1, 1),
+    (1, 40, 24, 256, 512, 3, 2, 1),      # stride 2 (the data gradient runs as four parity classes), two n-tiles
+    (3, 20, 20, 512, 256, 1, 1, 0),      # pointwise, rows past M in the last tile
+    (1, 17, 33, 256, 256, 3, 1, 1),      # odd sizes
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", V3W_CASES)
+def test_conv_v3_wide_tile(dev, B, H, W, Cin, Cout, k, s, p):
+    """conv_v3_kernel<256, 256, ...> (algo 14): forward with statistics / generic epilogue and the data gradient (plain, accumulating,
+    fused reduction) against torch, with the bars of the other tiles"""
+    test_conv_fwd_algos(dev, B, H, W, Cin, Cout, k, s, p, 14)
+    _dgrad_check(dev, B, H, W, Cin, Cout, k, s, p, 14)
 
 
 @pytest.mark.parametrize("algo", [1, 2, 3, 4, 5])

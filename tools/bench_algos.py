@@ -75,13 +75,14 @@ for name, H, Cin, Cout, k, s in shapes:
             d.bnr_z, d.bnr_ldz, d.bnr_C, d.bnr_ws, d.bnr_part = z.data_ptr(), Cin, Cin, ws.data_ptr(), slab.data_ptr()
     fl = 2.0 * M * Cout * Cin * k * k
     res = []
-    for algo in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+    for algo in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14):
         d.algo = algo
         d.tile_k = int(os.environ.get("BA_TILE_K", 0)) if algo >= 7 else 0
         d.tile_n = int(os.environ.get("BA_TILE_N", 0)) if algo >= 7 else 0
         kn = kname(d)
         if (algo in (2, 3, 4) and "conv_v3" not in kn) or (algo == 5 and "conv_halo_kernel" not in kn) or (algo == 6 and "conv_halo160" not in kn) or \
-                (algo == 7 and "conv_dg2" not in kn) or (algo == 8 and "conv_p3" not in kn) or (algo == 9 and "conv_h80" not in kn) or (algo == 10 and "conv_pw" not in kn):
+                (algo == 7 and "conv_dg2" not in kn) or (algo == 8 and "conv_p3" not in kn) or (algo == 9 and "conv_h80" not in kn) or (algo == 10 and "conv_pw" not in kn) or \
+                (algo == 13 and "conv_pt" not in kn) or (algo == 14 and "conv_v3_kernel<256, 256" not in kn):
             res.append("      -")
             continue
         for _ in range(2):
@@ -95,5 +96,5 @@ for name, H, Cin, Cout, k, s in shapes:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
         res.append(f"{fl / ms / 1e9:7.0f}")
-    print(f"{mode:5s} {name:10s} {H:4d}^2 {Cin:4d}->{Cout:4d} k{k}s{s}  TFLOP/s  v2 {res[0]} | v3-256x128 {res[1]} | v3-128x128 {res[2]} | v3-128x64 {res[3]} | halo {res[4]} | halo160 {res[5]} | dg2 {res[6]} | p3 {res[7]} | h80 {res[8]} | pw {res[9]}", flush=True)
+    print(f"{mode:5s} {name:10s} {H:4d}^2 {Cin:4d}->{Cout:4d} k{k}s{s}  TFLOP/s  v2 {res[0]} | v3-256x128 {res[1]} | v3-128x128 {res[2]} | v3-128x64 {res[3]} | halo {res[4]} | halo160 {res[5]} | dg2 {res[6]} | p3 {res[7]} | h80 {res[8]} | pw {res[9]} | pt {res[10]} | v3-256x256 {res[11]}", flush=True)
     del x, w

@@ -2421,7 +2421,9 @@ int pick_bkt(const yh_conv_desc* d, int bn) {
 
 int conv_v3_bkt(const yh_conv_desc* d);
 // LDS-DMA kernel (conv_v3_kernel) variant for this descriptor: 0 = none (v2 / generic kernel), 1 = 256 x 128 tile (8 waves),
-// 2 = 128 x 128 (4 waves), 3 = 128 x 64 (4 waves).  d->algo: 0 library default, 1 force v2, 2..4 = variant 1..3 when eligible.
+// 2 = 128 x 128 (4 waves), 3 = 128 x 64 (4 waves), 4 = 256 x 256 (8 waves of 128 x 64: half the LDS-DMA bytes per MFMA of variant 1,
+// whose 48 KB per k-step need 48 B/clk of the CU's 64 B/clk intake at the full MFMA rate).
+// d->algo: 0 library default, 1 force v2, 2..4 = variant 1..3 when eligible, 14 = variant 4 when eligible.
 int conv_v3_variant(const yh_conv_desc* d)
 {
     if (d->algo == 1 || d->algo == 5 || d->algo == 6 || stem_eligible(d) || !conv_buf_ok(d, true)) return 0;
@@ -2434,6 +2436,12 @@ int conv_v3_variant(const yh_conv_desc* d)
     if (d->algo >= 2 && d->algo <= 4) {
         const int v = d->algo - 1;
         return v;
+    }
+    if (d->algo == 14) {
+        // 256 x 256 tile (variant 4): whole 64-channel blocks in every segment, N a multiple of 256, 64-channel k-steps; else the default
+        bool ok = conv_v3_bkt(d) == 64 && d->tile_k != 32 && d->N % 256 == 0;
+        for (int s = 0; s < d->nseg; ++s) ok = ok && d->seg[s].C % 64 == 0;
+        if (ok) return 4;
     }
     // default: the big tile for K-heavy layers with enough pixel tiles to fill the chip, else v2
     const long M = (long)d->B * d->Ho * d->Wo;
@@ -2527,11 +2535,11 @@ void conv_grid(const yh_conv_desc* d, int* gx, int* gy, int* bn) {
         return;
     }
     if (const int v3 = conv_v3_variant(d)) {
-        const int bmt = v3 == 1 ? 256 : 128;
-        const int b = v3 == 3 ? 64 : 128;
+        const int bmt = (v3 == 1 || v3 == 4) ? 256 : 128;
+        const int b = v3 == 3 ? 64 : (v3 == 4 ? 256 : 128);
         const int nt = (d->N + b - 1) / b;
         const int bkt = conv_v3_bkt(d);
-        const int occ = v3 == 1 ? 1 : (v3 == 2 ? 2 : (bkt == 64 ? 2 : 3));
+        const int occ = (v3 == 1 || v3 == 4) ? 1 : (v3 == 2 ? 2 : (bkt == 64 ? 2 : 3));
         const bool cls = d->mode == YH_CONV_DGRAD && d->stride == 2 && d->Ho % 2 == 0 && d->Wo % 2 == 0 && d->KH >= 2 && d->KW >= 2 && !d->stats;
         const long Mc = cls ? M / 4 : M;
         const int mt = (int)((Mc + bmt - 1) / bmt);
@@ -2784,10 +2792,10 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
         const int bkt3 = conv_v3_bkt(d);          // conv_v3_variant already checked the addressing (conv_buf_ok, re-based)
         const bool tl3 = bkt3 == 64 && (k.Ctot % 64) != 0;
         const int epi = d->bnr_part ? 3 : (generic ? 2 : (d->stats ? 1 : 0));
-        const int bmt = v3 == 1 ? 256 : 128;
-        const int stg = v3 == 1 ? (bkt3 == 64 ? 3 : 4) : (v3 == 2 ? (bkt3 == 64 ? 2 : 4) : (bkt3 == 64 ? 3 : 4));
+        const int bmt = (v3 == 1 || v3 == 4) ? 256 : 128;
+        const int stg = v3 == 4 ? 2 : (v3 == 1 ? (bkt3 == 64 ? 3 : 4) : (v3 == 2 ? (bkt3 == 64 ? 2 : 4) : (bkt3 == 64 ? 3 : 4)));
         if (name_out) {
-            snprintf(name_out, name_len, "conv_v3_kernel<%d, %d, %d, 2, %d, %d, %d%s>", bmt, bn, v3 == 1 ? 4 : 2, bkt3, stg, epi,
+            snprintf(name_out, name_len, "conv_v3_kernel<%d, %d, %d, %d, %d, %d, %d%s>", bmt, bn, v3 == 1 ? 4 : 2, v3 == 4 ? 4 : 2, bkt3, stg, epi,
                      tl3 ? ", true" : ", false");
             return YH_OK;
         }
@@ -2798,26 +2806,29 @@ int conv_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_l
             k.xgx = k.xgy = 0;
             if (!k.cls && grid.y > 1 && grid.z == 1 && !rowmajor3) { k.xgx = (int)grid.x; k.xgy = (int)grid.y; grid = dim3(grid.x * grid.y, 1, 1); }
         }
-#define YH_LAUNCH_V3(BMT_, BN_, WM_, BKT_, STG_, TL_)                                                                \
+#define YH_LAUNCH_V3W(BMT_, BN_, WM_, WN_, BKT_, STG_, TL_)                                                               \
         do {                                                                                                         \
             const size_t sm = conv3_smem_bytes<BMT_, BN_, WM_, BKT_, STG_>();                                        \
-            const dim3 blk(WM_ * 2 * 64);                                                                            \
+            const dim3 blk(WM_ * WN_ * 64);                                                                           \
             static YhDevOnce attr_set;                                                                                  \
             if (attr_set.need()) {                                                                                         \
-                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
-                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, WN_, BKT_, STG_, 0, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, WN_, BKT_, STG_, 1, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, WN_, BKT_, STG_, 2, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
+                attr_set.set((const void*)conv_v3_kernel<BMT_, BN_, WM_, WN_, BKT_, STG_, 3, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
                 attr_set.done();                                                                                      \
             }                                                                                                        \
-            if (epi == 3)      conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 3, TL_><<<grid, blk, sm, st3>>>(k);     \
-            else if (epi == 2) conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 2, TL_><<<grid, blk, sm, st3>>>(k);     \
-            else if (epi == 1) conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 1, TL_><<<grid, blk, sm, st3>>>(k);     \
-            else               conv_v3_kernel<BMT_, BN_, WM_, 2, BKT_, STG_, 0, TL_><<<grid, blk, sm, st3>>>(k);     \
+            if (epi == 3)      conv_v3_kernel<BMT_, BN_, WM_, WN_, BKT_, STG_, 3, TL_><<<grid, blk, sm, st3>>>(k);     \
+            else if (epi == 2) conv_v3_kernel<BMT_, BN_, WM_, WN_, BKT_, STG_, 2, TL_><<<grid, blk, sm, st3>>>(k);     \
+            else if (epi == 1) conv_v3_kernel<BMT_, BN_, WM_, WN_, BKT_, STG_, 1, TL_><<<grid, blk, sm, st3>>>(k);     \
+            else               conv_v3_kernel<BMT_, BN_, WM_, WN_, BKT_, STG_, 0, TL_><<<grid, blk, sm, st3>>>(k);     \
         } while (0)
-        if (v3 == 1) { if (tl3) YH_LAUNCH_V3(256, 128, 4, 64, 3, true); else if (bkt3 == 64) YH_LAUNCH_V3(256, 128, 4, 64, 3, false); else YH_LAUNCH_V3(256, 128, 4, 32, 4, false); }
+#define YH_LAUNCH_V3(BMT_, BN_, WM_, BKT_, STG_, TL_) YH_LAUNCH_V3W(BMT_, BN_, WM_, 2, BKT_, STG_, TL_)
+        if (v3 == 4) YH_LAUNCH_V3W(256, 256, 2, 4, 64, 2, false);
+        else if (v3 == 1) { if (tl3) YH_LAUNCH_V3(256, 128, 4, 64, 3, true); else if (bkt3 == 64) YH_LAUNCH_V3(256, 128, 4, 64, 3, false); else YH_LAUNCH_V3(256, 128, 4, 32, 4, false); }
         else if (v3 == 2) { if (tl3) YH_LAUNCH_V3(128, 128, 2, 64, 2, true); else if (bkt3 == 64) YH_LAUNCH_V3(128, 128, 2, 64, 2, false); else YH_LAUNCH_V3(128, 128, 2, 32, 4, false); }
         else { if (tl3) YH_LAUNCH_V3(128, 64, 2, 64, 3, true); else if (bkt3 == 64) YH_LAUNCH_V3(128, 64, 2, 64, 3, false); else YH_LAUNCH_V3(128, 64, 2, 32, 4, false); }
+#undef YH_LAUNCH_V3W
 #undef YH_LAUNCH_V3
         YH_CHECK_LAUNCH("yh_conv_igemm(v3)");
         return YH_OK;

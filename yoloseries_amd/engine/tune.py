@@ -152,14 +152,14 @@ class TunerMixin:
                 cands.append((1, tk, cap))
         d.tile_k = d.grid_cap = 0
         if os.environ.get("YH_CONV_V3", "1") != "0":
-            for algo in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13):
+            for algo in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14):
                 if str(algo) in _flags.SKIP_ALGOS:
                     continue
                 d.algo = algo
                 kn = self._kernel_name(d)
                 if ("conv_v3" in kn and algo < 5) or ("conv_halo_kernel" in kn and algo == 5) or ("conv_halo160" in kn and algo == 6) or \
                         ("conv_dg2" in kn and algo == 7) or ("conv_p3" in kn and algo == 8) or ("conv_h80" in kn and algo == 9) or ("conv_pw" in kn and algo == 10) or ("conv_c80" in kn and algo == 12) or \
-                        ("conv_pt" in kn and algo == 13):
+                        ("conv_pt" in kn and algo == 13) or ("conv_v3_kernel<256, 256" in kn and algo == 14):
                     cands.append((algo, 0, 0))
                     if algo < 5 and kn.endswith(", true>") and all(d.seg[i].C % 32 == 0 for i in range(d.nseg)):
                         cands.append((algo, 32, 0))    # ragged last channel block: 32-channel steps instead of 64 + tail
