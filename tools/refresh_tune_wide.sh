@@ -1,0 +1,52 @@
+#!/bin/bash
+# Re-time the layer shapes of the shipped launch-parameter table that a NEW kernel family could take (here: the 256 x 256 tile of
+# conv_v3_kernel, yh_conv_desc.algo 14: N a multiple of 256, whole 64-channel blocks in every segment) against all their other
+# candidates, and merge the result.  The BASELINE workloads are built once with those entries removed from the table and a local
+# cache of their own; every other entry is kept as shipped.  Run on an MI355X from the repo root; writes gpurun_out/tune/tune_defaults.json.
+set -e
+OUT=gpurun_out/tune
+mkdir -p $OUT
+cp yoloseries_amd/tune_defaults.json $OUT/shipped_before.json
+python3 - <<'PY'
+import json
+t = json.load(open("yoloseries_amd/tune_defaults.json"))
+def wide_ok(k):
+    p = k.split(":")
+    if not p[0].startswith("conv") or len(p) != 3:
+        return False
+    f = [int(x) for x in p[2].split(",")]
+    N, nseg, C0, C1 = f[9], f[10], f[11], f[14]
+    return N % 256 == 0 and C0 % 64 == 0 and (nseg == 1 or C1 % 64 == 0)
+drop = [k for k in t if wide_ok(k)]
+json.dump({k: v for k, v in t.items() if k not in drop}, open("yoloseries_amd/tune_defaults.json", "w"), indent=0, sort_keys=True)
+print(f"{len(drop)} of {len(t)} entries to re-time")
+PY
+export YH_TUNE_CACHE=$PWD/$OUT/wide_local.json YH_TUNE_ITERS=${YH_TUNE_ITERS:-12}
+rm -f $YH_TUNE_CACHE
+NOB="--no-cpu-baseline --no-roofline"
+restore() { cp $OUT/shipped_before.json yoloseries_amd/tune_defaults.json; }
+trap restore EXIT
+python3 bench.py --steps 3 --warmup 2 $NOB > /dev/null 2>&1
+python3 bench.py --workload yolox --steps 3 --warmup 2 $NOB > /dev/null 2>&1
+python3 bench.py --model large --steps 3 --warmup 2 $NOB > /dev/null 2>&1
+python3 bench.py --model middle --steps 3 --warmup 2 $NOB > /dev/null 2>&1
+python3 bench.py --workload infer --model xlarge --img 1280 --batch 128 --steps 2 --warmup 1 $NOB > /dev/null 2>&1
+python3 bench.py --workload infer --model xlarge --img 1280 --batch 32 --steps 2 --warmup 1 $NOB > /dev/null 2>&1
+python3 bench.py --workload infer --model small --img 640 --batch 64 --steps 2 --warmup 1 $NOB > /dev/null 2>&1
+python3 - <<'PY'
+import json, os
+kept = json.load(open("yoloseries_amd/tune_defaults.json"))
+before = json.load(open("gpurun_out/tune/shipped_before.json"))
+local = json.load(open(os.environ["YH_TUNE_CACHE"])) if os.path.exists(os.environ["YH_TUNE_CACHE"]) else {}
+new = {k: v for k, v in local.items() if k in before and k not in kept}
+lost = [k for k in before if k not in kept and k not in new]
+for k in lost:                  # a shape no workload above builds any more keeps its old entry
+    new[k] = before[k]
+n14 = sum(1 for v in new.values() if len(v) == 3 and v[2] == 14)
+for k, v in sorted(new.items()):
+    if v != before[k]:
+        print("  ", k, before[k], "->", v)
+kept.update(new)
+json.dump(kept, open("gpurun_out/tune/tune_defaults.json", "w"), indent=0, sort_keys=True)
+print(f"re-timed {len(new) - len(lost)} entries ({len(lost)} kept as shipped: not built by the workloads), {n14} take the 256 x 256 tile; {len(kept)} entries in all")
+PY

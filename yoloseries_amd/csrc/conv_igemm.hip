@@ -1107,10 +1107,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
         __syncthreads();                           // nothing in flight (last wait was vmcnt(0)); ring -> epilogue buffer
 
         // ---- epilogue (as v2): accumulators -> LDS (bf16, row-major) -> 16-byte global stores
+        // EPI 3 reads the producer's raw output z of every output chunk: requested ahead of the accumulator conversion — except on the
+        // 256 x 256 tile (16 chunks per thread: 64 registers beside 128 accumulators spill), which loads z where it is used
         constexpr int CPRz = BN / 8;
         constexpr int NCHz = BMT * CPRz / NT;
-        uint4 zpre[EPI == 3 ? NCHz : 1];
-        if (EPI == 3) {
+        constexpr bool ZPRE = NCHz <= 8;
+        uint4 zpre[(EPI == 3 && ZPRE) ? NCHz : 1];
+        if (EPI == 3 && ZPRE) {
 #pragma unroll
             for (int i = 0; i < NCHz; ++i) {
                 const int id = t + i * NT;
@@ -1211,7 +1214,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
                     }
                     *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
                     if (EPI == 3) {
-                        const uint4 zv = zpre[i];
+                        const uint4 zv = ZPRE ? zpre[ZPRE ? i : 0] : *reinterpret_cast<const uint4*>(d.bnr_z + orow * d.bnr_ldz + n);
                         float g[8], z[8];
                         unpack8(v, g);
                         unpack8(zv, z);
