@@ -636,6 +636,58 @@ def test_conv_patch3_kernel(dev, B, H, W, Cin, Cout, tile_n):
         _dgrad_check(dev, B, H, W, Cin, Cout, 3, 1, 1, 8, tile_n=tile_n)
 
 
+P3S2_CASES = [
+    # B, H, W (input), Cin, Cout: ConvBnAct(Cin, Cout, 3, 2, 1) — the downsampling layers (models/normal/yolov5s.py:18-40)
+    (2, 64, 64, 32, 64),        # YOLOv5s backbone_stage1_conv class: weights resident, one 32-channel block, two channel tiles
+    (1, 48, 80, 64, 128),       # two 32-channel blocks (weights reloaded per block), two blocks along the output channels
+    (2, 33, 17, 32, 32),        # odd input sizes: output 17 x 9, ragged tiles, the patch reaches past the right / lower edge
+    (1, 40, 24, 128, 128),      # four channel blocks
+    (3, 16, 16, 96, 40),        # 96 channels (three blocks), output channels not a multiple of 32
+    (1, 130, 70, 32, 64),       # several tiles per image row and column
+]
+
+
+@pytest.mark.parametrize("tile_n", [0, 32])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", P3S2_CASES)
+def test_conv_patch3_stride2_forward(dev, B, H, W, Cin, Cout, tile_n):
+    """conv_p3_kernel<..., 2> (algo 8 on a 3x3 / stride-2 / pad-1 forward layer): the (2 TH + 1) x (2 TW + 1) patch staged once, its
+    columns de-interleaved by parity — output and BatchNorm partial sums against torch; the data gradient of such a layer is not
+    this kernel's (conv_dg2_kernel) and the descriptor falls back to the library default"""
+    from yoloseries_amd import hipk
+    x = _nhwc(B, H, W, Cin, dev, 83)
+    g = torch.Generator().manual_seed(84)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(torch.bfloat16).float().to(dev)
+    wp = hipk.pack_weight_fwd(w)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    ref = F.conv2d(_nchw(x), w, stride=2, padding=1).permute(0, 2, 3, 1)
+    for with_stats in (True, False):
+        out = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.bfloat16, device=dev)
+        d = hipk.conv_desc([hipk.full(x)], hipk.YH_CONV_FWD, B, Ho, Wo, H, W, 3, 2, 1, wp, Cout, hipk.full(out))
+        d.algo, d.tile_n = 8, tile_n
+        assert "conv_p3_kernel" in _kname(d) and _kname(d).endswith(", 2>"), _kname(d)
+        stats = None
+        if with_stats:
+            stats = torch.full((hipk.conv_stat_blocks(d), 2, wp.shape[0]), float("nan"), device=dev)
+            d.stats = stats.data_ptr()
+            assert hipk.conv_stat_blocks(d) == stats.shape[0]
+        hipk.conv_launch(d)
+        torch.cuda.synchronize()
+        assert not torch.isnan(out.float()).any()
+        _close(out, ref, 8e-3, 2e-2)
+        if stats is not None:
+            o = out.float().reshape(-1, Cout).double()
+            assert not torch.isnan(stats[:, :, :Cout]).any()
+            assert ((stats[:, 0, :Cout].double().sum(0) - o.sum(0)).abs() <= 1e-3 + 1e-5 * o.abs().sum(0)).all()
+            assert ((stats[:, 1, :Cout].double().sum(0) - (o ** 2).sum(0)).abs() <= 1e-3 + 1e-5 * (o ** 2).sum(0)).all()
+    # data gradient of the same layer with algo 8: not eligible -> the default family, still correct
+    gy = _nhwc(B, Ho, Wo, Cout, dev, 85)
+    gx = torch.zeros(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
+    if Cout % 8 == 0 and H % 2 == 0 and W % 2 == 0:
+        dd = hipk.conv_desc([hipk.full(gy)], hipk.YH_CONV_DGRAD, B, H, W, Ho, Wo, 3, 2, 1, hipk.pack_weight_dgrad(w), Cin, hipk.full(gx))
+        dd.algo = 8
+        assert "conv_p3_kernel" not in _kname(dd)
+
+
 H80_CASES = [
     # B, H, W, Cout: ConvBnAct(80, Cout, 3, 1, 1) on an H x W map (YOLOv5x stage-1 bottlenecks: 80 -> 80 at 320 x 320)
     (2, 32, 32, 80),            # whole 16 x 16 tiles

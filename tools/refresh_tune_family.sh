@@ -1,23 +1,29 @@
 #!/bin/bash
-# Re-time the layer shapes of the shipped launch-parameter table that a NEW kernel family could take (here: the 256 x 256 tile of
-# conv_v3_kernel, yh_conv_desc.algo 14: N a multiple of 256, whole 64-channel blocks in every segment) against all their other
-# candidates, and merge the result.  The BASELINE workloads are built once with those entries removed from the table and a local
-# cache of their own; every other entry is kept as shipped.  Run on an MI355X from the repo root; writes gpurun_out/tune/tune_defaults.json.
+# Re-time the layer shapes of the shipped launch-parameter table that a NEW kernel family could take against all their other
+# candidates, and merge the result.  usage: refresh_tune_family.sh <family>
+#   wide   the 256 x 256 tile of conv_v3_kernel (yh_conv_desc.algo 14): N a multiple of 256, whole 64-channel blocks in every segment
+#   p3s2   conv_p3_kernel at stride 2 (algo 8): 3x3 / stride-2 forward layers of the training programs with <= 128 channels in and out
+# The BASELINE workloads are built once with those entries removed from the table and a local cache of their own; every other
+# entry is kept as shipped.  Run on an MI355X from the repo root; writes gpurun_out/tune/tune_defaults.json.
 set -e
+export REFRESH_FAMILY=${1:-wide}
 OUT=gpurun_out/tune
 mkdir -p $OUT
 cp yoloseries_amd/tune_defaults.json $OUT/shipped_before.json
 python3 - <<'PY'
 import json
 t = json.load(open("yoloseries_amd/tune_defaults.json"))
-def wide_ok(k):
+import os
+def family_ok(k):
     p = k.split(":")
     if not p[0].startswith("conv") or len(p) != 3:
         return False
     f = [int(x) for x in p[2].split(",")]
-    N, nseg, C0, C1 = f[9], f[10], f[11], f[14]
+    mode, KH, stride, N, nseg, C0, C1 = f[0], f[6], f[7], f[9], f[10], f[11], f[14]
+    if os.environ["REFRESH_FAMILY"] == "p3s2":
+        return p[1] == "fwd" and mode == 0 and KH == 3 and stride == 2 and nseg == 1 and C0 % 32 == 0 and C0 <= 128 and N <= 128
     return N % 256 == 0 and C0 % 64 == 0 and (nseg == 1 or C1 % 64 == 0)
-drop = [k for k in t if wide_ok(k)]
+drop = [k for k in t if family_ok(k)]
 json.dump({k: v for k, v in t.items() if k not in drop}, open("yoloseries_amd/tune_defaults.json", "w"), indent=0, sort_keys=True)
 print(f"{len(drop)} of {len(t)} entries to re-time")
 PY
@@ -42,11 +48,12 @@ new = {k: v for k, v in local.items() if k in before and k not in kept}
 lost = [k for k in before if k not in kept and k not in new]
 for k in lost:                  # a shape no workload above builds any more keeps its old entry
     new[k] = before[k]
-n14 = sum(1 for v in new.values() if len(v) == 3 and v[2] == 14)
+fam_algo = 8 if os.environ["REFRESH_FAMILY"] == "p3s2" else 14
+n14 = sum(1 for v in new.values() if len(v) == 3 and v[2] == fam_algo)
 for k, v in sorted(new.items()):
     if v != before[k]:
         print("  ", k, before[k], "->", v)
 kept.update(new)
 json.dump(kept, open("gpurun_out/tune/tune_defaults.json", "w"), indent=0, sort_keys=True)
-print(f"re-timed {len(new) - len(lost)} entries ({len(lost)} kept as shipped: not built by the workloads), {n14} take the 256 x 256 tile; {len(kept)} entries in all")
+print(f"re-timed {len(new) - len(lost)} entries ({len(lost)} kept as shipped: not built by the workloads), {n14} take the new family (algo {fam_algo}); {len(kept)} entries in all")
 PY

@@ -28,34 +28,44 @@ __device__ __forceinline__ void p3_st_nt16(uint16_t* p, uint4 v) {
     __builtin_nontemporal_store(w, reinterpret_cast<u32x4_nt*>(p));
 }
 
-constexpr int p3_pmax(int pt) { return pt == 1 ? 200 : 340; }     // most patch pixels (TH+2)*(TW+2) for 128 * PT region pixels
+// most patch pixels for 128 * PT region pixels: stride 1 (TH+2)*(TW+2), stride 2 (2 TH+1)*(2 TW+1)
+constexpr int p3_pmax(int pt, int s = 1) { return s == 2 ? (pt == 1 ? 600 : 1120) : (pt == 1 ? 200 : 340); }
 
 struct P3K {
     const uint16_t* x; int ldx, Cin;
     const uint16_t* w; int Ktot;
     uint16_t* out; int ld0, N, Npad;
-    int B, H, W;
+    int B, H, W;                           // output grid
+    int Hi, Wi;                            // input grid (== output grid at stride 1)
     int TH, TW, tx, ty, ntiles, nchunk, npatch;
+    int PW;                                // patch row length in pixels: TW + 2 (stride 1), 2 TW + 1 (stride 2)
     int accumulate, flip;                  // flip: data gradient (tap (kh, kw) reads the patch at (2 - kh, 2 - kw))
     float* stats;                          // EPI 1: [gridDim.x][2][Npad]
     const uint16_t* z; int ldz; const float* ws; int wsC; float* part;      // EPI 3
     unsigned xbytes, wbytes;
 };
 
-template <int CT, int KC, int PT>
+template <int CT, int KC, int PT, int S = 1>
 constexpr int p3_smem_bytes() {
-    const int main_b = (p3_pmax(PT) + 9 * 32 * CT) * (KC + 8) * 2;
+    const int main_b = (p3_pmax(PT, S) + 9 * 32 * CT) * (KC + 8) * 2;
     const int stg_b = 128 * PT * (32 * CT + 8) * 2;
     return (main_b > stg_b ? main_b : stg_b) + 2 * 32 * CT * 4;
 }
 
-// block = 4*CT waves: wave (ct, q) multiplies PT tiles of 32 region pixels with the ct-th 32 output channels
-template <int CT, int KC, int EPI, int PT>
+// block = 4*CT waves: wave (ct, q) multiplies PT tiles of 32 region pixels with the ct-th 32 output channels.
+// S = 2 (forward only): the stride-2 downsampling layers (utils/layer_tools.py:82-94 with models/normal/yolov5s.py:18-40's
+// ConvBnAct(.., 3, 2, 1)).  The patch of a TH x TW output tile is (2 TH + 1) x (2 TW + 1) input pixels; its columns are stored
+// DE-INTERLEAVED by parity (even input columns first, then the odd ones), so the 32 consecutive output pixels of a fragment read
+// consecutive patch slots for every tap — the same conflict-free LDS stride as at stride 1 (an interleaved patch would put the
+// lanes 2 slots apart: a two-way bank conflict on every fragment read).  The im2col ring kernel these layers ran on stages every
+// input pixel 2.25 times through the CU's LDS-DMA path (512 B per MFMA at 64 output channels); here each is staged once.
+template <int CT, int KC, int EPI, int PT, int S = 1>
 __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
 {
+    static_assert(S == 1 || (S == 2 && EPI != 3), "stride 2: forward only");
     constexpr int NT = 256 * CT;
     constexpr int RPX = 128 * PT;
-    constexpr int PMAX = p3_pmax(PT);
+    constexpr int PMAX = p3_pmax(PT, S);
     constexpr int PITCH = KC + 8;
     constexpr int CHR = KC / 8;
     constexpr int CB = 32 * CT;
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* sP = reinterpret_cast<uint16_t*>(smem);
     uint16_t* sW = sP + PMAX * PITCH;
-    float* sStat = reinterpret_cast<float*>(smem + p3_smem_bytes<CT, KC, PT>() - 2 * CB * 4);
+    float* sStat = reinterpret_cast<float*>(smem + p3_smem_bytes<CT, KC, PT, S>() - 2 * CB * 4);
     uint16_t* sStg = reinterpret_cast<uint16_t*>(smem);
 
     const int t = threadIdx.x;
@@ -80,7 +90,8 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
     const int wave = t >> 6;
     const int wq = wave & 3, wct = wave >> 2;
     const int c0 = blockIdx.y * CB;
-    const int TWp = p.TW + 2;
+    const int TWp = p.PW;
+    const int PWe = p.TW + 1;              // stride 2: even-column slots of a patch row (the odd columns follow them)
 
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
@@ -98,7 +109,9 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
     for (int j = 0; j < NPI; ++j) {
         const int pp = row0 + j * PPP;
         const int pi = pp / TWp;
-        ppij[j] = pp < p.npatch ? (pi << 8) | (pp - pi * TWp) : -1;
+        int pj = pp - pi * TWp;
+        if (S == 2) pj = pj < PWe ? 2 * pj : 2 * (pj - PWe) + 1;          // slot -> input column of the patch
+        ppij[j] = pp < p.npatch ? (pi << 8) | pj : -1;
     }
     const int koff = (lane >> 5) * 8;
     int rpx[PT];
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
         const bool rvalid = rpx[pt] < p.TH * p.TW;
         const int ri = rvalid ? rpx[pt] / p.TW : 0;
         const int rj = rvalid ? rpx[pt] - ri * p.TW : 0;
-        xbase[pt] = sP + (ri * TWp + rj) * PITCH + koff;
+        xbase[pt] = sP + (S * ri * TWp + rj) * PITCH + koff;
     }
     const uint16_t* const wbase = sW + (wct * 32 + (lane & 31)) * PITCH + koff;
 
@@ -139,9 +152,9 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
         const int so = kc * KC * 2;
 #pragma unroll
         for (int j = 0; j < NPI; ++j) {
-            const int gi = i0 - 1 + (ppij[j] >> 8), gj = j0 - 1 + (ppij[j] & 0xff);
-            const bool ok = ppij[j] >= 0 && gi >= 0 && gj >= 0 && gi < p.H && gj < p.W;
-            const unsigned off = ok ? (unsigned)(((b * p.H + gi) * p.W + gj) * (p.ldx * 2) + ch * 16) : OOB;
+            const int gi = S * i0 - 1 + (ppij[j] >> 8), gj = S * j0 - 1 + (ppij[j] & 0xff);
+            const bool ok = ppij[j] >= 0 && gi >= 0 && gj >= 0 && gi < p.Hi && gj < p.Wi;
+            const unsigned off = ok ? (unsigned)(((b * p.Hi + gi) * p.Wi + gj) * (p.ldx * 2) + ch * 16) : OOB;
             rp[j] = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, so, 0);
         }
         if (with_w) {
@@ -189,12 +202,14 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
                     // the tap that reads the patch at (sy, sx): forward (kh, kw) = (sy, sx); data gradient (2 - sy, 2 - sx)
                     const int tap_f = sy * 3 + sx, tap_d = (2 - sy) * 3 + (2 - sx);
                     const uint16_t* wt = wbase + (p.flip ? tap_d : tap_f) * CB * PITCH;
+                    // patch slot of this tap relative to the pixel's: stride 2 reads input column 2 rj + sx = slot (sx & 1) * PWe + rj + (sx >> 1)
+                    const int tslot = S == 2 ? sy * TWp + (sx & 1) * PWe + (sx >> 1) : sy * TWp + sx;
 #pragma unroll
                     for (int ks = 0; ks < KC / 16; ++ks) {
                         const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wt + ks * 16));
 #pragma unroll
                         for (int pt = 0; pt < PT; ++pt) {
-                            const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xbase[pt] + (sy * TWp + sx) * PITCH + ks * 16));
+                            const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xbase[pt] + tslot * PITCH + ks * 16));
                             acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[pt], 0, 0, 0);
                         }
                     }
@@ -293,28 +308,35 @@ __global__ __launch_bounds__(256 * CT, 1) void conv_p3_kernel(const P3K p)
     }
 }
 
-bool p3_geom(int H, int W, int pt, int* TH, int* TW, int* tx, int* ty)
+bool p3_geom(int H, int W, int pt, int* TH, int* TW, int* tx, int* ty, int s = 1)
 {
     double best = -1.0;
     const int rpx = 128 * pt;
     for (int tw = 4; tw <= 64; ++tw)
         for (int th = 1; th * tw <= rpx; ++th) {
-            if ((th + 2) * (tw + 2) > p3_pmax(pt)) continue;
+            const int ph = s == 2 ? 2 * th + 1 : th + 2, pw = s == 2 ? 2 * tw + 1 : tw + 2;
+            if (ph * pw > p3_pmax(pt, s)) continue;
             const int nx = (W + tw - 1) / tw, ny = (H + th - 1) / th;
             double eff = (double)H * W / ((double)nx * ny * rpx);
-            eff *= (double)(th * tw) / ((th + 2) * (tw + 2));       // halo overhead of the patch
+            eff *= (double)(s * s * th * tw) / (ph * pw);           // halo overhead of the patch
             eff += 1e-4 * tw;
             if (eff > best) { best = eff; *TH = th; *TW = tw; *tx = nx; *ty = ny; }
         }
     return best > 0.0;
 }
 
-struct P3Plan { int ct, kc, pt, gx, gy; P3K k; };
+struct P3Plan { int ct, kc, pt, gx, gy, s; P3K k; };
 
 bool p3_plan(const yh_conv_desc* d, P3Plan* pl)
 {
     if (d->nseg != 1 || d->seg[0].ups) return false;
-    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hi || d->Wo != d->Wi) return false;
+    if (d->KH != 3 || d->KW != 3 || d->pad != 1) return false;
+    const int S = d->stride;
+    if (S == 1) { if (d->Ho != d->Hi || d->Wo != d->Wi) return false; }
+    else if (S == 2) {      // the downsampling layers, forward only (their data gradient is conv_dg2_kernel's)
+        if (d->mode != YH_CONV_FWD || d->Ho != (d->Hi - 1) / 2 + 1 || d->Wo != (d->Wi - 1) / 2 + 1) return false;
+    } else return false;
+    pl->s = S;
     if (d->bias || d->scale || d->shift || d->act != YH_ACT_NONE || d->res || d->nsplit < d->N) return false;
     if (d->mode == YH_CONV_FWD && (d->bnr_part || d->accumulate)) return false;
     if (d->mode == YH_CONV_DGRAD && d->stats) return false;
@@ -325,26 +347,29 @@ bool p3_plan(const yh_conv_desc* d, P3Plan* pl)
     if (xb >= (1ul << 31) || wb >= (1ul << 31) || (unsigned long)d->B * d->Ho * d->Wo >= (1ul << 31)) return false;
     P3K& k = pl->k;
     pl->ct = d->N <= 32 ? 1 : 2;
-    pl->kc = (Cin % 64 == 0 && d->tile_k != 32) ? 64 : 32;
+    pl->kc = (Cin % 64 == 0 && d->tile_k != 32 && S == 1) ? 64 : 32;      // stride 2: the patch of 64-channel blocks does not fit beside the weights
     pl->pt = (d->tile_n == 32) ? 1 : 2;
-    if (!p3_geom(d->Ho, d->Wo, pl->pt, &k.TH, &k.TW, &k.tx, &k.ty)) return false;
+    if (!p3_geom(d->Ho, d->Wo, pl->pt, &k.TH, &k.TW, &k.tx, &k.ty, S)) return false;
     const int cb = 32 * pl->ct;
     pl->gy = (d->N + cb - 1) / cb;
     if (pl->gy * cb > d->Npad) return false;
     k.x = d->seg[0].ptr; k.ldx = d->seg[0].ld; k.Cin = Cin;
     k.w = d->w; k.Ktot = 9 * Cin;
     k.out = d->out0; k.ld0 = d->ld0; k.N = d->N; k.Npad = d->Npad;
-    k.B = d->B; k.H = d->Ho; k.W = d->Wo;
+    k.B = d->B; k.H = d->Ho; k.W = d->Wo; k.Hi = d->Hi; k.Wi = d->Wi;
     k.ntiles = d->B * k.tx * k.ty;
     k.nchunk = Cin / pl->kc;
-    k.npatch = (k.TH + 2) * (k.TW + 2);
+    k.PW = S == 2 ? 2 * k.TW + 1 : k.TW + 2;
+    k.npatch = (S == 2 ? 2 * k.TH + 1 : k.TH + 2) * k.PW;
     k.accumulate = d->accumulate;
     k.flip = d->mode == YH_CONV_DGRAD ? 1 : 0;
     k.stats = d->stats;
     k.z = d->bnr_z; k.ldz = d->bnr_ldz; k.ws = d->bnr_ws; k.wsC = d->bnr_C; k.part = d->bnr_part;
     k.xbytes = (unsigned)xb; k.wbytes = (unsigned)wb;
     // resident blocks per CU by LDS: the grid is one resident wave of blocks (bounds the partial-sum rows too)
-    const int smem = (pl->ct == 1) ? (pl->kc == 64 ? (pl->pt == 2 ? p3_smem_bytes<1, 64, 2>() : p3_smem_bytes<1, 64, 1>())
+    const int smem = S == 2 ? ((pl->ct == 1) ? (pl->pt == 2 ? p3_smem_bytes<1, 32, 2, 2>() : p3_smem_bytes<1, 32, 1, 2>())
+                                             : (pl->pt == 2 ? p3_smem_bytes<2, 32, 2, 2>() : p3_smem_bytes<2, 32, 1, 2>()))
+                   : (pl->ct == 1) ? (pl->kc == 64 ? (pl->pt == 2 ? p3_smem_bytes<1, 64, 2>() : p3_smem_bytes<1, 64, 1>())
                                                    : (pl->pt == 2 ? p3_smem_bytes<1, 32, 2>() : p3_smem_bytes<1, 32, 1>()))
                                    : (pl->kc == 64 ? (pl->pt == 2 ? p3_smem_bytes<2, 64, 2>() : p3_smem_bytes<2, 64, 1>())
                                                    : (pl->pt == 2 ? p3_smem_bytes<2, 32, 2>() : p3_smem_bytes<2, 32, 1>()));
@@ -373,7 +398,11 @@ int yh_p3_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
     const int epi = d->bnr_part ? 3 : (d->stats ? 1 : 0);
     if (d->bnr_part)
         YH_CHECK_ARG(d->bnr_z && yh_aligned16(d->bnr_z) && d->bnr_ldz % 8 == 0 && d->bnr_ws && d->bnr_C >= d->N, "yh_conv_igemm: bad fused-reduction operands");
-    if (name_out) { snprintf(name_out, name_len, "conv_p3_kernel<%d, %d, %d, %d>", pl.ct, pl.kc, epi, pl.pt); return YH_OK; }
+    if (name_out) {
+        if (pl.s == 2) snprintf(name_out, name_len, "conv_p3_kernel<%d, %d, %d, %d, 2>", pl.ct, pl.kc, epi, pl.pt);
+        else           snprintf(name_out, name_len, "conv_p3_kernel<%d, %d, %d, %d>", pl.ct, pl.kc, epi, pl.pt);
+        return YH_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(pl.gx, pl.gy), blk(256 * pl.ct);
 #define YH_LAUNCH_P3(CT_, KC_, PT_)                                                                                    \
@@ -390,10 +419,27 @@ int yh_p3_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
         else if (epi == 1) conv_p3_kernel<CT_, KC_, 1, PT_><<<grid, blk, sm, st>>>(pl.k);                              \
         else               conv_p3_kernel<CT_, KC_, 0, PT_><<<grid, blk, sm, st>>>(pl.k);                              \
     } while (0)
+#define YH_LAUNCH_P3S2(CT_, PT_)                                                                                        \
+    do {                                                                                                               \
+        const int sm = p3_smem_bytes<CT_, 32, PT_, 2>();                                                               \
+        static YhDevOnce attr_set;                                                                                     \
+        if (attr_set.need()) {                                                                                         \
+            attr_set.set((const void*)conv_p3_kernel<CT_, 32, 0, PT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.set((const void*)conv_p3_kernel<CT_, 32, 1, PT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, sm); \
+            attr_set.done();                                                                                           \
+        }                                                                                                              \
+        if (epi == 1) conv_p3_kernel<CT_, 32, 1, PT_, 2><<<grid, blk, sm, st>>>(pl.k);                                 \
+        else          conv_p3_kernel<CT_, 32, 0, PT_, 2><<<grid, blk, sm, st>>>(pl.k);                                 \
+    } while (0)
 #define YH_P3_PT(CT_, KC_) do { if (pl.pt == 2) YH_LAUNCH_P3(CT_, KC_, 2); else YH_LAUNCH_P3(CT_, KC_, 1); } while (0)
-    if (pl.ct == 1) { if (pl.kc == 64) YH_P3_PT(1, 64); else YH_P3_PT(1, 32); }
-    else            { if (pl.kc == 64) YH_P3_PT(2, 64); else YH_P3_PT(2, 32); }
+    if (pl.s == 2) {
+        if (pl.ct == 1) { if (pl.pt == 2) YH_LAUNCH_P3S2(1, 2); else YH_LAUNCH_P3S2(1, 1); }
+        else            { if (pl.pt == 2) YH_LAUNCH_P3S2(2, 2); else YH_LAUNCH_P3S2(2, 1); }
+    }
+    else if (pl.ct == 1) { if (pl.kc == 64) YH_P3_PT(1, 64); else YH_P3_PT(1, 32); }
+    else                 { if (pl.kc == 64) YH_P3_PT(2, 64); else YH_P3_PT(2, 32); }
 #undef YH_P3_PT
+#undef YH_LAUNCH_P3S2
 #undef YH_LAUNCH_P3
     YH_CHECK_LAUNCH("yh_conv_igemm(p3)");
     return YH_OK;
