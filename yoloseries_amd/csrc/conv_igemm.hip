@@ -1166,8 +1166,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
 
         constexpr int CPR = BN / 8;
         constexpr int NCH = BMT * CPR / NT;
+        uint4 zq[(EPI == 3 && !ZPRE) ? 4 : 1];       // the 256 x 256 tile: z of the next four chunks, requested together
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
+            if (EPI == 3 && !ZPRE && (i & 3) == 0) {
+                // (the stores of the previous chunks may alias z for all the compiler knows: loads left inside the chunk's own
+                // iteration were issued one by one behind them — sixteen dependent round trips per tile)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int id2 = t + (i + g) * NT;
+                    const int row2 = id2 / CPR;
+                    const int m2 = m0 + row2;
+                    const int n2 = n0 + (id2 - row2 * CPR) * 8;
+                    zq[g] = make_uint4(0, 0, 0, 0);
+                    if (m2 < p.M && n2 < d.N) {
+                        const size_t orow2 = p.cls ? (size_t)sPix[row2] : (size_t)m2;
+                        zq[g] = *reinterpret_cast<const uint4*>(d.bnr_z + orow2 * d.bnr_ldz + n2);
+                    }
+                }
+            }
             const int id = t + i * NT;
             const int row = id / CPR;
             const int cch = id - row * CPR;
@@ -1214,7 +1231,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
                     }
                     *reinterpret_cast<uint4*>(d.out0 + orow * d.ld0 + n) = v;
                     if (EPI == 3) {
-                        const uint4 zv = ZPRE ? zpre[ZPRE ? i : 0] : *reinterpret_cast<const uint4*>(d.bnr_z + orow * d.bnr_ldz + n);
+                        const uint4 zv = ZPRE ? zpre[ZPRE ? i : 0] : zq[ZPRE ? 0 : (i & 3)];
                         float g[8], z[8];
                         unpack8(v, g);
                         unpack8(zv, z);
