@@ -190,14 +190,23 @@ __global__ __launch_bounds__(256) void decode_scan_kernel(const DecK k, float co
     const int p0 = c * DPIX;
     const int npix = min(DPIX, hw - p0);
     const int ldp = k.d.ldp[s];
+    // LDS rows are 16 bytes longer than the prediction rows: with the rows back to back (256 floats / 256 bf16 = a multiple of the
+    // 64 banks) the 64 lanes of a wave — one pixel each — read the same bank for every element: a 32-way conflict on each of the
+    // 85 reads per lane, which is what the pass took most of its time for (2.7 of 8 TB/s, round 5)
+    constexpr int LPAD = 16 / (int)sizeof(T);
+    const int lds_ld = ldp + LPAD;
     const T* src = reinterpret_cast<const T*>(k.pred[s]) + ((size_t)b * hw + p0) * ldp;
     const int nelem = npix * ldp;
     const int t = threadIdx.x;
-    if (((size_t)src & 15) == 0 && (nelem * (int)sizeof(T)) % 16 == 0) {
-        const int nv = nelem * (int)sizeof(T) / 16;
-        for (int i = t; i < nv; i += 256) reinterpret_cast<uint4*>(tile)[i] = reinterpret_cast<const uint4*>(src)[i];
+    if (((size_t)src & 15) == 0 && (ldp * (int)sizeof(T)) % 16 == 0) {
+        const int cpr = ldp * (int)sizeof(T) / 16;            // 16-byte chunks per row
+        const int nv = npix * cpr;
+        for (int i = t; i < nv; i += 256) {
+            const int r = i / cpr, c16 = i - r * cpr;
+            *reinterpret_cast<uint4*>(tile + r * lds_ld + c16 * LPAD) = reinterpret_cast<const uint4*>(src)[i];
+        }
     } else {
-        for (int i = t; i < nelem; i += 256) tile[i] = src[i];
+        for (int i = t; i < nelem; i += 256) { const int r = i / ldp; tile[r * lds_ld + (i - r * ldp)] = src[i]; }
     }
     __syncthreads();
     const int a = t >> 6, lane = t & 63;
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256) void decode_scan_kernel(const DecK k, float co
     if (lane < npix) {
         const int pidx = p0 + lane;
         const int y = pidx / k.d.W[s], x = pidx - y * k.d.W[s];
-        const T* row = tile + lane * ldp + a * (5 + k.d.num_class);
+        const T* row = tile + lane * lds_ld + a * (5 + k.d.num_class);
         flag = eval_pred<T>(k, row, s, a, y, x, conf_thr, cls_thr, box, conf, cls);
     }
     const unsigned long long bal = __ballot(flag);
@@ -621,7 +630,7 @@ extern "C" int yh_decode_filter(const yh_decode_desc* d, const void* const* pred
         int32_t* counts = reinterpret_cast<int32_t*>(stage + (size_t)d->B * nkeys * DPIX * 6);
         int ldmax = 0;
         for (int s = 0; s < d->num_stage; ++s) ldmax = d->ldp[s] > ldmax ? d->ldp[s] : ldmax;
-        const size_t sm = (size_t)DPIX * ldmax * (d->pred_is_f32 ? 4 : 2);
+        const size_t sm = (size_t)DPIX * ((size_t)ldmax * (d->pred_is_f32 ? 4 : 2) + 16);      // rows padded by 16 bytes (bank conflicts)
         YH_CHECK_ARG(sm <= 160 * 1024, "yh_decode_filter: prediction rows of %d elements do not fit the LDS tile", ldmax);
         const dim3 grid(nchunks, d->B);
         if (d->pred_is_f32) {
