@@ -201,9 +201,25 @@ __global__ __launch_bounds__(256) void decode_scan_kernel(const DecK k, float co
     if (((size_t)src & 15) == 0 && (ldp * (int)sizeof(T)) % 16 == 0) {
         const int cpr = ldp * (int)sizeof(T) / 16;            // 16-byte chunks per row
         const int nv = npix * cpr;
-        for (int i = t; i < nv; i += 256) {
-            const int r = i / cpr, c16 = i - r * cpr;
-            *reinterpret_cast<uint4*>(tile + r * lds_ld + c16 * LPAD) = reinterpret_cast<const uint4*>(src)[i];
+        // every load of the tile is requested before the first LDS store (a load -> store loop kept one or two in flight per thread:
+        // with two 65 KB blocks per CU the pass was bound by the round trips, 2.7 TB/s)
+        constexpr int NLD = 16;
+        for (int i0 = 0; i0 < nv; i0 += 256 * NLD) {
+            uint4 v[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int i = i0 + u * 256 + t;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (i < nv) v[u] = reinterpret_cast<const uint4*>(src)[i];
+            }
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int i = i0 + u * 256 + t;
+                if (i < nv) {
+                    const int r = i / cpr, c16 = i - r * cpr;
+                    *reinterpret_cast<uint4*>(tile + r * lds_ld + c16 * LPAD) = v[u];
+                }
+            }
         }
     } else {
         for (int i = t; i < nelem; i += 256) { const int r = i / ldp; tile[r * lds_ld + (i - r * ldp)] = src[i]; }
