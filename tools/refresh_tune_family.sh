@@ -3,6 +3,8 @@
 # candidates, and merge the result.  usage: refresh_tune_family.sh <family>
 #   wide   the 256 x 256 tile of conv_v3_kernel (yh_conv_desc.algo 14): N a multiple of 256, whole 64-channel blocks in every segment
 #   p3s2   conv_p3_kernel at stride 2 (algo 8): 3x3 / stride-2 forward layers of the training programs with <= 128 channels in and out
+#   v3w8   the 8-wave tiles of conv_v3_kernel (algo 2 / 14) after a change to their main loop: every shape with N > 64 and 32-channel blocks
+#   allconv  every forward / data-gradient / inference entry
 # The BASELINE workloads are built once with those entries removed from the table and a local cache of their own; every other
 # entry is kept as shipped.  Run on an MI355X from the repo root; writes gpurun_out/tune/tune_defaults.json.
 set -e
@@ -20,6 +22,10 @@ def family_ok(k):
         return False
     f = [int(x) for x in p[2].split(",")]
     mode, KH, stride, N, nseg, C0, C1 = f[0], f[6], f[7], f[9], f[10], f[11], f[14]
+    if os.environ["REFRESH_FAMILY"] == "allconv":
+        return True
+    if os.environ["REFRESH_FAMILY"] == "v3w8":        # shapes the 8-wave tiles of the ring kernel can take (K-heavy, N > 64)
+        return N > 64 and C0 % 32 == 0 and (nseg == 1 or C1 % 32 == 0)
     if os.environ["REFRESH_FAMILY"] == "p3s2":
         return p[1] == "fwd" and mode == 0 and KH == 3 and stride == 2 and nseg == 1 and C0 % 32 == 0 and C0 <= 128 and N <= 128
     return N % 256 == 0 and C0 % 64 == 0 and (nseg == 1 or C1 % 64 == 0)

@@ -1079,7 +1079,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
             else if (STG == 3 || younger == 1) YH_VMCNT(LPS);
             else YH_VMCNT(2 * LPS);
             __builtin_amdgcn_s_barrier();          // stage kt complete for every wave; stage kt-1 no longer read by anyone
-            if (kt + STG - 1 < nkt) issue(islot);
+            // The 8-wave tiles: a wave issues 6-8 transfers per step (~100 cycles of issue each, no MFMA of that wave meanwhile).  Both
+            // waves of a SIMD (w and w + 4) doing so right behind the barrier leaves the matrix pipe idle for that long: waves 4-7
+            // issue theirs behind their first sub-step — which every channel block has, also a tail block — beside their partners'
+            // MFMAs (the slot they fill was freed by the barrier; a wave still issues once per step, in order: the counted waits
+            // hold).  Isolated +3...+11 % on both 8-wave tiles (profiles/r06_step_experiments.txt j).
+            constexpr bool W8 = NWV == 8;
+            const bool more = kt + STG - 1 < nkt;
+            if (more && (!W8 || wave < NWV / 2)) issue(islot);
             const unsigned char* sbase = smem + slot * STAGE_BYTES;
             int ksn = BKT / 16;                    // wave-uniform: sub-steps of this channel block
             if (TL) {
@@ -1100,6 +1107,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_v3_kernel(const ConvK p)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                if (W8 && ks == 0 && more && wave >= NWV / 2) issue(islot);
             }
             slot = slot + 1 == STG ? 0 : slot + 1;
             islot = islot + 1 == STG ? 0 : islot + 1;
