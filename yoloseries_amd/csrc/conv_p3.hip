@@ -399,8 +399,7 @@ int yh_p3_run(const yh_conv_desc* d, yh_stream stream, char* name_out, int name_
     if (d->bnr_part)
         YH_CHECK_ARG(d->bnr_z && yh_aligned16(d->bnr_z) && d->bnr_ldz % 8 == 0 && d->bnr_ws && d->bnr_C >= d->N, "yh_conv_igemm: bad fused-reduction operands");
     if (name_out) {
-        if (pl.s == 2) snprintf(name_out, name_len, "conv_p3_kernel<%d, %d, %d, %d, 2>", pl.ct, pl.kc, epi, pl.pt);
-        else           snprintf(name_out, name_len, "conv_p3_kernel<%d, %d, %d, %d>", pl.ct, pl.kc, epi, pl.pt);
+        snprintf(name_out, name_len, "conv_p3_kernel<%d, %d, %d, %d, %d>", pl.ct, pl.kc, epi, pl.pt, pl.s);     // as profilers print it
         return YH_OK;
     }
     hipStream_t st = (hipStream_t)stream;
