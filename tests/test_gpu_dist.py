@@ -275,3 +275,19 @@ def test_overlapped_bucket_allreduce_two_ranks_judged_shape(dev):
         assert res["mean_err"] < 1e-3, (rank, res)
         assert res["differs_from_local"] > 1e-2, (rank, res)
         assert res["buckets"] >= 3 and res["two_streams"], (rank, res)
+
+
+def test_loss_backward_reproducible_beside_second_process():
+    """400 YOLOv5 loss backwards on fixed inputs (batch 64, 640 x 640) while ANOTHER PROCESS trains on the same GPU: one distinct
+    result.  Round 6 found 15 % of such passes with a wrong cell or more (y / h gradients of positives): packed fp32 instructions
+    of the -O3 build, only with a second process on the card; the exact sources compile without the vectorizers since
+    (csrc/Makefile EXACT).  The children own the GPU; this process only reads their report."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "loss_race_diag.py"), "2", "20", "bwd_repeat"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    m = re.search(r"rank 0: (\d+) backward passes, (\d+) distinct results", r.stdout)
+    assert r.returncode == 0 and m, r.stdout[-2000:]
+    assert int(m.group(1)) == 400 and int(m.group(2)) == 1, m.group(0)
