@@ -13,6 +13,7 @@ usage: loss_race_diag.py [procs] [iters] [mode]
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import torch.multiprocessing as mp
 
@@ -61,9 +62,31 @@ def worker(rank, iters, q, mode="random"):
             lf = YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), bench.make_hyp(dev, img, B))
             out = lf(preds, t)
             hist = {}
-            side = torch.cuda.Stream(dev) if os.environ.get("SAME_PROCESS_LOAD") else None
+            spl = os.environ.get("SAME_PROCESS_LOAD", "")
+            side = torch.cuda.Stream(dev) if spl and not spl.startswith("family:") else None
             ma = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16) if side else None
+            stop = []
+            if spl.startswith("family:"):          # a THREAD of this process launches one kernel family on its own stream meanwhile
+                import threading
+                import race_screen
+                def _load():
+                    with torch.cuda.stream(torch.cuda.Stream(dev)):
+                        while not stop:
+                            race_screen.screen(reps=2, verbose=False, deep={}, family=spl.split(":", 1)[1], burst=25)
+                th = threading.Thread(target=_load, daemon=True)
+                th.start()
+                import time
+                time.sleep(5)
+            poison = None
+            if os.environ.get("POISON"):          # every vector register of every SIMD := a pattern right before each backward (same stream)
+                import ctypes as C
+                PL = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libpk_victim.so"))
+                PL.pk_poison_launch.argtypes = [C.c_uint, C.c_int, C.c_void_p]
+                pats = [int(v, 16) for v in os.environ["POISON"].split(",")]
+                poison = lambda it: PL.pk_poison_launch(pats[it % len(pats)], 4096, torch.cuda.current_stream().cuda_stream)      # noqa: E731
             for it in range(iters * 20):
+                if poison is not None:
+                    assert poison(it) == 0
                 if side is not None and it % 2 == 0:          # MFMA-heavy kernels of THIS process beside the loss backward
                     with torch.cuda.stream(side):
                         mb = ma @ ma
@@ -73,8 +96,44 @@ def worker(rank, iters, q, mode="random"):
                 grads = [p_.grad.detach().clone() for p_ in preds]
                 sig = tuple(int(g_.view(torch.int16).to(torch.int64).sum().item()) for g_ in grads)
                 hist[sig] = hist.get(sig, 0) + 1
+            stop.append(1)
             torch.cuda.synchronize()
             print("rank 0: %d backward passes, %d distinct results, counts %s" % (iters * 20, len(hist), sorted(hist.values(), reverse=True)[:10]), flush=True)
+            q.put((rank, bad, dict(chk), detail))
+            return
+        kind = os.environ.get("LOAD_KIND", "train")     # what the OTHER process runs: train | matmul | copy | fp32 | sleep
+        if kind != "train":
+            import time
+            a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+            f = torch.randn(1 << 26, device=dev)
+            t0 = time.time()
+            while time.time() - t0 < float(os.environ.get("LOAD_SECONDS", "25")):
+                if kind == "matmul":
+                    for _ in range(20):
+                        a @ a
+                elif kind == "copy":
+                    for _ in range(20):
+                        busy[:1 << 27].copy_(busy[1 << 27:])
+                elif kind.startswith("family:"):          # launches of ONE kernel family of the shipped table, in bursts
+                    import race_screen
+                    race_screen.screen(reps=2, verbose=False, deep={}, family=kind.split(":", 1)[1], burst=25)
+                elif kind in ("fwd_train", "fwd_eval", "fwd_loss"):
+                    if model.training != (kind != "fwd_eval"):
+                        model.train(kind != "fwd_eval")
+                    if kind == "fwd_loss":
+                        outs_ = model(x)
+                        pr_ = [o.detach().requires_grad_(True) for o in outs_]
+                        lf_ = YOLOV5Loss(torch.from_numpy(COCO_ANCHORS).to(dev), bench.make_hyp(dev, img, B))
+                        lf_(pr_, t)["tot_loss"].backward()
+                    else:
+                        with torch.no_grad():
+                            model(x)
+                elif kind == "fp32":
+                    for _ in range(20):
+                        f.mul_(1.0001).add_(0.5)
+                else:
+                    time.sleep(0.5)
+                torch.cuda.synchronize()
             q.put((rank, bad, dict(chk), detail))
             return
         mode = "model_full_load"

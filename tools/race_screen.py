@@ -16,7 +16,7 @@ from yoloseries_amd._lib import YH_ACT_SILU, YH_CONV_DGRAD, check, lib
 DEEP_FAMILIES = {"conv_pt_kernel": 40, "conv_halo160_kernel": 40, "conv_wgs_kernel": 40}
 
 
-def screen(reps=6, sub="", verbose=True, beside=False, deep=None):
+def screen(reps=6, sub="", verbose=True, beside=False, deep=None, family=None, burst=1):
     """-> (entries walked, [(key, kernel, differences)]): see the module docstring.  deep: {kernel family: launches per entry}
     overriding `reps` upwards for those families (default DEEP_FAMILIES; {} = none)"""
     deep = DEEP_FAMILIES if deep is None else deep
@@ -91,9 +91,13 @@ def screen(reps=6, sub="", verbose=True, beside=False, deep=None):
                 nb = C.create_string_buffer(96); L.yh_conv_kernel_name(C.byref(d), nb, 96); name = nb.value.decode()
                 fams[name.split("<")[0]] = fams.get(name.split("<")[0], 0) + 1
                 nrep = max(reps, deep.get(name.split("<")[0], 0))
+                if family is not None and not name.startswith(family):          # family: only entries of this kernel (name prefix)
+                    fams[name.split("<")[0]] -= 1
+                    break
             junk = torch.randn(1024, 1024, device=dev) @ torch.randn(1024, 256, device=dev)      # noqa: F841
             busy()
-            check(L.yh_conv_igemm(C.byref(d), st()), key)
+            for _ in range(burst):          # burst > 1: the screen as a LOAD for another process (tools/loss_race_diag.py), results not compared
+                check(L.yh_conv_igemm(C.byref(d), st()), key)
             torch.cuda.synchronize()
             cur = [out0[..., :n0].view(torch.int16)] + ([out1[..., :N - n0].view(torch.int16)] if out1 is not None else []) + \
                   ([stt.view(torch.int32)] if stt is not None else []) + ([slab.view(torch.int32)] if slab is not None else [])
@@ -115,7 +119,7 @@ def screen(reps=6, sub="", verbose=True, beside=False, deep=None):
             print(f"... {ki + 1} of {len(keys)} entries, {len(bad_entries)} with differences", flush=True)
     # ---- weight gradients: fp32 atomics — not bit-reproducible — so launch to launch within 1e-3 of the largest element
     from yoloseries_amd.engine import Program
-    wkeys = [k for k in sorted(t) if k.startswith("wgrad") and sub in k]
+    wkeys = [k for k in sorted(t) if k.startswith("wgrad") and sub in k and (family is None or family.startswith("conv_wg"))]
     for ki, key in enumerate(wkeys):
         N, ldg, C0, ld0, ups, Ctot, B, Ho, Wo, Hi, Wi, k, stride, pad = [int(x) for x in key.split(":")[-1].split(",")]
         if key.split(":")[0].endswith("f"):
@@ -135,9 +139,13 @@ def screen(reps=6, sub="", verbose=True, beside=False, deep=None):
                 name = Program._wgrad_name(L, d)
                 fams[name.split("<")[0]] = fams.get(name.split("<")[0], 0) + 1
                 nrep = max(reps, deep.get(name.split("<")[0], 0))
+                if family is not None and not name.startswith(family):          # family: only entries of this kernel (name prefix)
+                    fams[name.split("<")[0]] -= 1
+                    break
             junk = torch.randn(1024, 1024, device=dev) @ torch.randn(1024, 256, device=dev)      # noqa: F841
             busy()
-            check(L.yh_conv_wgrad(C.byref(d), st()), key)
+            for _ in range(burst):
+                check(L.yh_conv_wgrad(C.byref(d), st()), key)
             torch.cuda.synchronize()
             if first is None:
                 first = dw.clone()
