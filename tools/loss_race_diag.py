@@ -18,7 +18,7 @@ import torch
 import torch.multiprocessing as mp
 
 
-def worker(rank, iters, q, mode="random"):
+def worker(rank, iters, q, mode="random", done=None):
     import bench
     from yoloseries_amd.loss import YOLOV5Loss
     from yoloseries_amd.layout import cell_major_view
@@ -98,6 +98,8 @@ def worker(rank, iters, q, mode="random"):
                 hist[sig] = hist.get(sig, 0) + 1
             stop.append(1)
             torch.cuda.synchronize()
+            if done is not None:
+                done.set()
             print("rank 0: %d backward passes, %d distinct results, counts %s" % (iters * 20, len(hist), sorted(hist.values(), reverse=True)[:10]), flush=True)
             q.put((rank, bad, dict(chk), detail))
             return
@@ -137,7 +139,15 @@ def worker(rank, iters, q, mode="random"):
             q.put((rank, bad, dict(chk), detail))
             return
         mode = "model_full_load"
-    for it in range(iters):
+    import time
+    it, t_start = -1, time.time()
+    while True:
+        it += 1
+        if mode == "model_full_load":          # the load lasts as long as rank 0's loop (at least `iters` passes, at most two minutes)
+            if it >= iters and (done is None or done.is_set() or time.time() - t_start > 120):
+                break
+        elif it >= iters:
+            break
         if mode == "model_full_load":
             outs = model(x)
             preds = list(outs)
@@ -189,7 +199,8 @@ if __name__ == "__main__":
     mode = sys.argv[3] if len(sys.argv) > 3 else "random"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=worker, args=(r, iters, q, mode)) for r in range(procs)]
+    done = ctx.Event()
+    ps = [ctx.Process(target=worker, args=(r, iters, q, mode, done)) for r in range(procs)]
     for p in ps:
         p.start()
     for _ in range(procs):
