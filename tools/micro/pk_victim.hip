@@ -124,6 +124,26 @@ __global__ __launch_bounds__(256) void pk_victim_kernel(int iters, const float* 
         } else if (FORM == 121) {
             asm volatile("v_pk_add_f32 %0, %1, -0.5 op_sel_hi:[1,0]" : "=v"(r) : "v"(x));
             lo = sadd(x.x, -0.5f); hi = sadd(x.y, -0.5f);
+        } else if (FORM == 200) {
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(y));                 // lo = x.lo * y.hi, hi = x.hi * y.hi
+            lo = smul(x.x, y.y); hi = smul(x.y, y.y);
+        } else if (FORM == 201) {
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(r) : "v"(x), "v"(y)); // both sources swapped
+            lo = sadd(x.y, y.y); hi = sadd(x.x, y.x);
+        } else if (FORM == 202) {
+            f2 z = {d, a};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+            lo = sfma(x.x, y.y, z.x); hi = sfma(x.y, y.x, z.y);
+        } else if (FORM == 203) {
+            f2 z = {d, a};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+            lo = sfma(x.x, y.x, z.y); hi = sfma(x.y, y.y, z.x);
+        } else if (FORM == 204) {
+            asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(y));                 // lo = x.lo, hi = y.hi
+            lo = x.x; hi = y.y;
+        } else if (FORM == 205) {
+            asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(x), "v"(y));                 // lo = x.hi, hi = y.hi
+            lo = x.y; hi = y.y;
         } else {
             asm volatile("v_pk_mul_f32 %0, %1, 0 op_sel_hi:[1,0]" : "=v"(r) : "v"(x));
             lo = smul(a, 0.f); hi = smul(b, 0.f);
@@ -172,6 +192,12 @@ extern "C" int pk_victim_launch(int form, int blocks, int iters, const float* in
     case 119: pk_victim_kernel<119><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
     case 120: pk_victim_kernel<120><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
     case 121: pk_victim_kernel<121><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
+    case 200: pk_victim_kernel<200><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
+    case 201: pk_victim_kernel<201><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
+    case 202: pk_victim_kernel<202><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
+    case 203: pk_victim_kernel<203><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
+    case 204: pk_victim_kernel<204><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
+    case 205: pk_victim_kernel<205><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
     default: pk_victim_kernel<7><<<blocks, 256, 0, st>>>(iters, in, mism, first); break;
     }
     return (int)hipGetLastError();
@@ -206,7 +232,7 @@ __global__ __launch_bounds__(256) void pk_trigger_kernel(int iters, float* __res
     __shared__ __attribute__((aligned(16))) unsigned short lds[4096];
     const int t = threadIdx.x;
     float x = 1.0f + t * 1e-3f, y = 0.5f;
-    f16v acc = {0};
+    f16v acc = {0}, accb = {0}, accc = {0}, accd = {0};
     f4v acc4 = {0};
     s8v a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
     for (int i = t; i < 4096; i += 256) lds[i] = (unsigned short)i;
@@ -226,13 +252,27 @@ __global__ __launch_bounds__(256) void pk_trigger_kernel(int iters, float* __res
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
         } else if (KIND == 4) {
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc4) : "v"(a), "v"(b));
+        } else if (KIND == 6) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc4) : "v"(a), "v"(b));
+        } else if (KIND == 7) {
+            typedef short s4v_ __attribute__((ext_vector_type(4)));
+            s4v_ a4 = {1, 2, 3, 4}, b4 = {4, 3, 2, 1};
+            asm volatile("v_mfma_f32_32x32x8bf16_1k %0, %1, %2, %0\n\tv_mfma_f32_32x32x8bf16_1k %0, %1, %2, %0" : "+v"(acc) : "v"(a4), "v"(b4));
+        } else if (KIND == 8) {
+            typedef short s4v_ __attribute__((ext_vector_type(4)));
+            s4v_ a4 = {1, 2, 3, 4}, b4 = {4, 3, 2, 1};
+            asm volatile("v_mfma_f32_16x16x16bf16_1k %0, %1, %2, %0\n\tv_mfma_f32_16x16x16bf16_1k %0, %1, %2, %0" : "+v"(acc4) : "v"(a4), "v"(b4));
+        } else if (KIND == 9) {           // four INDEPENDENT 32x32x16 accumulators: the matrix pipe never waits for a result
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %4, %5, %1\n\t"
+                         "v_mfma_f32_32x32x16_bf16 %2, %4, %5, %2\n\tv_mfma_f32_32x32x16_bf16 %3, %4, %5, %3"
+                         : "+v"(acc), "+v"(accb), "+v"(accc), "+v"(accd) : "v"(a), "v"(b));
         } else if (KIND == 5) {
             typedef short s4v __attribute__((ext_vector_type(4)));
             s4v r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(lds + ((t * 4 + it * 64) & 4092)));
             a[0] += r[0]; a[1] += r[1];
         }
     }
-    if (sink && (x == 12345.678f || acc[0] == 3.f || acc4[0] == 5.f || a[0] == 77)) sink[t] = x + acc[1] + acc4[1] + a[1];
+    if (sink && (x == 12345.678f || acc[0] == 3.f || acc4[0] == 5.f || a[0] == 77)) sink[t] = x + acc[1] + accb[1] + accc[1] + accd[1] + acc4[1] + a[1];
 }
 
 extern "C" int pk_trigger_launch(int kind, int blocks, int iters, float* sink, void* stream)
@@ -244,6 +284,10 @@ extern "C" int pk_trigger_launch(int kind, int blocks, int iters, float* sink, v
     case 2: pk_trigger_kernel<2><<<blocks, 256, 0, st>>>(iters, sink); break;
     case 3: pk_trigger_kernel<3><<<blocks, 256, 0, st>>>(iters, sink); break;
     case 4: pk_trigger_kernel<4><<<blocks, 256, 0, st>>>(iters, sink); break;
+    case 6: pk_trigger_kernel<6><<<blocks, 256, 0, st>>>(iters, sink); break;
+    case 7: pk_trigger_kernel<7><<<blocks, 256, 0, st>>>(iters, sink); break;
+    case 8: pk_trigger_kernel<8><<<blocks, 256, 0, st>>>(iters, sink); break;
+    case 9: pk_trigger_kernel<9><<<blocks, 256, 0, st>>>(iters, sink); break;
     default: pk_trigger_kernel<5><<<blocks, 256, 0, st>>>(iters, sink); break;
     }
     return (int)hipGetLastError();

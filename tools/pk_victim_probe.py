@@ -43,7 +43,12 @@ FORMS = [(0, "v_pk_mul_f32"), (1, "v_pk_mul_f32 neg_lo neg_hi"), (4, "v_pk_fma_f
          (119, "v_pk_add_f32 D, X, Y op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]"),
          (120, "v_pk_add_f32 D, X, 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]"),
          (121, "v_pk_add_f32 D, X, -0.5 op_sel_hi:[1,0]"),
+         # more selectors on the second / third source
+         (200, "v_pk_mul_f32 D, X, Y op_sel:[0,1]"), (201, "v_pk_add_f32 D, X, Y op_sel:[1,1] op_sel_hi:[0,0]"),
+         (202, "v_pk_fma_f32 D, X, Y, Z op_sel:[0,1,0] op_sel_hi:[1,0,1]"), (203, "v_pk_fma_f32 D, X, Y, Z op_sel:[0,0,1] op_sel_hi:[1,1,0]"),
+         (204, "v_pk_mov_b32 D, X, Y op_sel:[0,1]"), (205, "v_pk_mov_b32 D, X, Y op_sel:[1,1]"),
          ]
+VICTIMS_MICRO = tuple(int(v) for v in os.environ.get("PK_VICTIMS", "0,105,106").split(","))
 
 
 def main():
@@ -59,11 +64,12 @@ def main():
     inp = (torch.rand(1 << 16, device=dev) * 4 - 2)
     stop = []
     if family.startswith("micro:"):          # a micro trigger of pk_victim.hip on a second stream, victim = the op_sel:[0,1] forms only
-        kinds = {"valu": 0, "accvgpr": 1, "mfma32_vgpr": 2, "mfma32_agpr": 3, "mfma16_vgpr": 4, "ds_read_tr": 5}
+        kinds = {"valu": 0, "accvgpr": 1, "mfma32_vgpr": 2, "mfma32_agpr": 3, "mfma16_vgpr": 4, "ds_read_tr": 5, "mfma16_agpr": 6,
+                 "mfma32x8_vgpr": 7, "mfma16x16_vgpr": 8, "mfma32_vgpr_x4": 9}
         L.pk_trigger_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         side = torch.cuda.Stream(dev)
         for kname in (family.split(":", 1)[1].split(",") if family != "micro:all" else list(kinds)):
-            for form, name in [f for f in FORMS if f[0] in (0, 105, 106)]:
+            for form, name in [f for f in FORMS if f[0] in VICTIMS_MICRO]:
                 mism = torch.zeros(4, dtype=torch.int64, device=dev)
                 first = torch.zeros(1, dtype=torch.int32, device=dev)
                 t0, launches = time.time(), 0
