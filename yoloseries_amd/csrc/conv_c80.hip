@@ -58,7 +58,9 @@ static_assert(4 * 32 * C80_SP <= C80_STAGE, "epilogue staging fits a stage buffe
 static_assert(C80_SMEM <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ void c80_dma(unsigned lds, unsigned voff, const __amdgpu_buffer_rsrc_t rs) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rs) : "memory", "m0");
+    // M0 is written in the SAME statement that reads it: the compiler reserves M0 and keeps nothing in it across an asm statement
+    // (an "m0" clobber only draws -Winline-asm "clobber list contains reserved registers"; cdna_hip_programming.md §5.7)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds), "v"(voff), "s"(rs) : "memory");
 }
 __device__ __forceinline__ bf16x8_t c80_lds16(const unsigned char* p) {
     return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p));

@@ -101,7 +101,9 @@ typedef unsigned int pt_u32x4 __attribute__((ext_vector_type(4)));
 // One LDS-DMA wave instruction: 64 lanes x 16 bytes -> LDS bytes [lds, lds + 1024)
 // (soff: a scalar byte offset added to every lane's; it is not part of the descriptor's range check, voff is)
 __device__ __forceinline__ void pt_dma(unsigned lds, unsigned voff, const __amdgpu_buffer_rsrc_t rs, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+    // M0 is written in the SAME statement that reads it: the compiler reserves M0 and keeps nothing in it across an asm statement
+    // (an "m0" clobber only draws -Winline-asm "clobber list contains reserved registers"; cdna_hip_programming.md §5.7)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 __device__ __forceinline__ uint4 pt_u4(const pt_u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
 // A 16-byte store with a SCALAR tile offset.  Inline asm with its own wait states: behind the builtin form the compiler placed a

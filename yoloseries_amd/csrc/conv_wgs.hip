@@ -65,7 +65,9 @@ template <int I> __device__ __forceinline__ unsigned wgs_quad(unsigned v) {
 // of EVERY LDS read: SIInsertWaitcnts cannot tell the slots of the ring apart).  The waits for these transfers are the
 // hand-counted YH_VMCNT() of the main loop; soff is excluded from the descriptor's range check, voff is not (0x80000000: zeros).
 __device__ __forceinline__ void wgs_dma(unsigned lds, unsigned voff, const __amdgpu_buffer_rsrc_t rs, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+    // M0 is written in the SAME statement that reads it: the compiler reserves M0 and keeps nothing in it across an asm statement
+    // (an "m0" clobber only draws -Winline-asm "clobber list contains reserved registers"; cdna_hip_programming.md §5.7)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
 // PW: 1x1 / stride 1 / pad 0 layer on a plain segment (the im2col row IS the pixel's row: scalar walk)
